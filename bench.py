@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- BCn block-transform hot path on MI355X: GiB/s of BC blocks transformed (forward + inverse).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload at every N: BASELINE.json configs[1] taken with the north-star's "forward+inverse" reading -- BC1, default
+settings {YCoCg Variant1, split colour endpoints}, an 8 GiB block buffer per GPU (2^30 blocks) of splitmix64 random
+blocks generated on the device.  One step = one forward transform of the buffer + one inverse transform of the
+result, both through the C ABI of libdxtlt_gfx950.so, inputs resident in HBM.  `value` counts the block bytes fed to
+each direction: (len + len) * steps * N / time.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), used only for the barrier and the max-over-ranks
+reduction of the timing.  The block array shards by contiguous range; every rank transforms its own 8 GiB shard
+(weak scaling); there is no data-path collective (DESIGN.md "Multi-GPU").
+
+The JSON line also carries
+  roofline      for the dominant kernel (BC1 forward, fwd_tiled): algorithmic bytes = 16 B/block = 2*len per launch,
+                divided by the launch's average duration measured with HIP events on the launch stream
+  cpu_baseline  the C oracle (a port of the reference's scalar loops) timed on this box's host cores on a bounded
+                sample of the same workload, rank 0 at N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--size-gib", type=float, default=8.0, help="block buffer per GPU (default: the 8 GiB config)")
+    p.add_argument("--format", default="bc1", choices=["bc1", "bc2", "bc3"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-mib", type=int, default=1024)
+    p.add_argument("--wgs-per-cu", type=int, default=0, help="tuning experiment: persistent grid = CUs * this")
+    return p.parse_args()
+
+
+def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
+    """Oracle timed on the host: single thread (comparable to the reference's per-core figures) and all cores."""
+    import numpy as np
+
+    from oracle import oracle_c
+
+    nbytes = sample_mib << 20
+    x = oracle_c.fill_splitmix64(nbytes, 0x0BC10002)
+    y = np.zeros_like(x)
+    z = np.zeros_like(x)
+    v, sa, sc = settings
+    cores = os.cpu_count() or 1
+
+    def run(threads, reps):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            oracle_c.run_mt(fmt, x, y, v, sc, sa, False, threads)
+            oracle_c.run_mt(fmt, y, z, v, sc, sa, True, threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return 2 * nbytes / best / 2**30
+
+    run(cores, 1)  # touch all pages
+    one = run(1, 3)
+    allc = run(cores, 3)
+    assert np.array_equal(z, x)
+    return {
+        "value": round(one, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+        "sample": f"{sample_mib} MiB of the same {fmt.upper()} splitmix64 workload, forward+inverse, best of 3, "
+                  f"scalar C oracle (gcc -O3)",
+        "all_cores_value": round(allc, 3), "all_cores": cores,
+    }
+
+
+def main() -> None:
+    args = parse_args()
+    import torch
+
+    import dxt_lossless_transform_amd as pkg
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg.load()
+    if args.wgs_per_cu:
+        pkg.set_tuning(args.wgs_per_cu, False)
+    fmt = args.format
+    block = pkg.BLOCK_BYTES[fmt]
+    settings = {"bc1": pkg.Bc1TransformSettings(), "bc2": pkg.Bc2TransformSettings(),
+                "bc3": pkg.Bc3TransformSettings()}[fmt]
+    fwd = getattr(pkg, f"transform_{fmt}_with_settings")
+    inv = getattr(pkg, f"untransform_{fmt}_with_settings")
+
+    nbytes = int(args.size_gib * (1 << 30))
+    nbytes -= nbytes % (block * 2048)
+    blocks = nbytes // block
+    seed = {"bc1": 0x0BC10002, "bc2": 0x0BC20002, "bc3": 0x0BC30003}[fmt]
+
+    x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    # rank r holds blocks [r*blocks, (r+1)*blocks) of one logical array
+    pkg.fill_splitmix64(x, seed, rank * (nbytes // 8))
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        fwd(x, y, settings)
+        inv(y, z, settings)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # per-kernel timing: HIP events on the stream the kernels are launched on (torch's current stream)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        fwd(x, y, settings)
+        ev[k][1].record()
+        inv(y, z, settings)
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    # correctness inside the run: exact round trip, and one window against the oracle
+    bit_exact = bool(torch.equal(z, x))
+    if rank == 0:
+        import numpy as np
+
+        from oracle import oracle_c
+
+        win = 1 << 16
+        first = blocks // 2 + 4097
+        xin = x[first * block:(first + win) * block].cpu().numpy()
+        want = oracle_c.transform(fmt, xin, int(settings.decorrelation_mode), settings.split_colour_endpoints,
+                                  getattr(settings, "split_alpha_endpoints", True))
+        got = np.empty_like(want)
+        for off, w in pkg.stream_table(fmt, settings):
+            got[off * win: off * win + w * win] = y[off * blocks + w * first: off * blocks + w * (first + win)].cpu().numpy()
+        bit_exact = bit_exact and bool(np.array_equal(got, want))
+    assert bit_exact, "GPU result differs from the oracle / round trip failed"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_in = 2 * nbytes * args.steps * world
+    value = total_in / elapsed / 2**30
+    achieved = 2 * nbytes / (fwd_ms * 1e-3) / 1e9  # algorithmic bytes: read len + write len
+    achieved_inv = 2 * nbytes / (inv_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                rec = json.load(f)
+            if rec.get("workload_bytes") == nbytes and rec.get("format") == fmt:
+                traffic = rec.get("fwd_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "GiB/s BC blocks transformed (fwd+inv)",
+        "value": round(value, 2),
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{fmt.upper()} forward+inverse, default settings "
+                        f"({'YCoCg Variant1, split colour endpoints' if fmt != 'bc3' else 'YCoCg Variant1, split alpha + colour endpoints'}), "
+                        f"{nbytes / 2**30:g} GiB random block buffer per GPU (BASELINE.json configs[1])",
+            "format": fmt, "blocks_per_gpu": blocks, "bytes_per_gpu": nbytes, "seed": hex(seed),
+            "sharding": "contiguous block range per rank, no collective",
+            "bit_exact_roundtrip_and_oracle_window": bit_exact,
+            "fwd_ms": round(fwd_ms, 4), "inv_ms": round(inv_ms, 4),
+            "fwd_GiBps": round(nbytes / (fwd_ms * 1e-3) / 2**30, 1), "inv_GiBps": round(nbytes / (inv_ms * 1e-3) / 2**30, 1),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": f"fwd_tiled<{fmt}>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": 2 * nbytes,
+            "inverse_kernel": {"kernel": f"inv_tiled<{fmt}>", "achieved": round(achieved_inv, 1),
+                               "frac": round(achieved_inv / HBM_PEAK_GBPS, 4)},
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        s = (int(settings.decorrelation_mode), bool(getattr(settings, "split_alpha_endpoints", True)),
+             bool(settings.split_colour_endpoints))
+        out["cpu_baseline"] = cpu_baseline(fmt, s, args.cpu_sample_mib)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

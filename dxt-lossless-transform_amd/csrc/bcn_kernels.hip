@@ -1,0 +1,638 @@
+// bcn_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the BCn block transform hot path.
+//
+// What is computed (reference, paths under /root/reference/src/core/):
+//   BC1  dxt-lossless-transform-bc1/src/transform/transform_with_settings.rs:31-72 / 92-135
+//   BC2  dxt-lossless-transform-bc2/src/transform/transform_with_settings.rs:30-73 / 93-138
+//   BC3  dxt-lossless-transform-bc3/src/transform/transform_with_settings.rs:32-142 / 162-272
+//   YCoCg-R  dxt-lossless-transform-common/src/color_565/decorrelate.rs:101-344 (ycocg_swar.h)
+// i.e. an AoS -> SoA field split of 8-/16-byte blocks into 2..6 adjacent streams, optional endpoint
+// split, optional YCoCg-R of the two RGB565 endpoints; and the inverse.  Output length == input length.
+//
+// How it is mapped to the machine (this is NOT how the reference does it; the reference is x86 SIMD):
+//   * HBM-bound byte shuffling: 2 bytes of traffic per byte of input, ~20 integer ops per colour pair.
+//     No MFMA.  The only thing that matters is that every HBM access is a full-width, fully coalesced
+//     16 B/lane vector access and that enough of them are in flight.
+//   * One 256-thread workgroup owns a contiguous 16 KiB tile of blocks (2048 BC1 / 1024 BC2,BC3 blocks).
+//     Forward: 4 x global_load_dwordx4 per lane (1 KiB contiguous per wave-instruction) -> YCoCg-R in
+//     registers -> each field is written to its place in an LDS image that is laid out exactly like the
+//     output (stream after stream) -> barrier -> the image is read back linearly with ds_read_b128 and
+//     every stream slice leaves with global_store_dwordx4, again 1 KiB contiguous per wave-instruction.
+//     Inverse: the mirror (linear 16-B stream loads -> LDS image -> per-block gather -> AoS dwordx4 stores).
+//   * Stream slices of a tile are multiples of 1 KiB, so one wave-instruction never straddles two
+//     streams and the stream of a store is wave-uniform (selected on SGPRs).
+//   * Persistent grid (CUs x 8 workgroups), grid-stride over tiles; the next tile's loads are issued
+//     before the current tile's store phase so HBM reads stay in flight across the barrier.
+//   * Non-temporal loads/stores: every byte is touched exactly once.
+//   * 64-bit block indices and byte offsets everywhere (8 GiB of BC1 = 2^30 blocks).
+//   * Anything the tiled path cannot take (tail blocks, stream bases or pointers that are not 16-byte
+//     aligned) goes to an element-granular kernel: one lane per block, natural-width or byte accesses.
+#include <hip/hip_runtime.h>
+
+#include "bcn_launch.h"
+#include "ycocg_swar.h"
+
+namespace dxtlt {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;        // 4 waves
+constexpr int kTileBytes = 16384;    // LDS image == one tile of input == one tile of output
+constexpr int kVecs = kTileBytes / 16 / kThreads;  // 16-byte vectors per lane per tile (4)
+
+#ifndef DXTLT_NONTEMPORAL
+#define DXTLT_NONTEMPORAL 1
+#endif
+
+__device__ __forceinline__ u32x4 gload16(const void* p)
+{
+#if DXTLT_NONTEMPORAL
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+    return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
+
+__device__ __forceinline__ void gstore16(void* p, u32x4 v)
+{
+#if DXTLT_NONTEMPORAL
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#else
+    *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+
+__host__ __device__ constexpr int fmt_block(int fmt) { return fmt == kBc1 ? 8 : 16; }
+__host__ __device__ constexpr int fmt_tile_blocks(int fmt) { return kTileBytes / fmt_block(fmt); }
+
+// Byte offset, inside the whole transformed buffer, of the 1 KiB LDS-image chunk that starts at image
+// byte `chunk_byte` (wave-uniform), for the tile whose first block is `blk0` (global block index).
+template <int FMT, bool SA, bool SC>
+__device__ __forceinline__ uint64_t soa_offset_of_chunk(int chunk_byte, uint64_t total_blocks, uint64_t blk0)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int T = fmt_tile_blocks(FMT);
+    uint64_t r = 0;
+#pragma unroll
+    for (int s = 0; s < S.n; ++s) {
+        const int lo = S.off[s] * T;
+        const int hi = lo + S.width[s] * T;
+        if (chunk_byte >= lo && chunk_byte < hi)
+            r = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 + (uint64_t)(chunk_byte - lo);
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS image <-> block registers.  `u` is the index of the lane's 16-byte vector inside the tile.
+// BC1: the vector holds blocks 2u and 2u+1; BC2/BC3: block u.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T& lds_at(uint8_t* lds, int byte_off)
+{
+    return *reinterpret_cast<T*>(lds + byte_off);
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
+{
+    constexpr int T = fmt_tile_blocks(FMT);
+    if constexpr (FMT == kBc1) {
+        // q = { colours A, indices A, colours B, indices B }
+        const uint32_t ca = decorrelate2<VARIANT>(q.x);
+        const uint32_t cb = decorrelate2<VARIANT>(q.z);
+        if constexpr (SC) {
+            lds_at<uint32_t>(lds, 0 * T + 4 * u) = (ca & 0xFFFFu) | (cb << 16);          // c0 of A, B
+            lds_at<uint32_t>(lds, 2 * T + 4 * u) = (ca >> 16) | (cb & 0xFFFF0000u);      // c1 of A, B
+        } else {
+            lds_at<u32x2>(lds, 0 * T + 8 * u) = u32x2{ca, cb};
+        }
+        lds_at<u32x2>(lds, 4 * T + 8 * u) = u32x2{q.y, q.w};
+    } else if constexpr (FMT == kBc2) {
+        // q = { alpha lo, alpha hi, colours, indices }
+        const uint32_t c = decorrelate2<VARIANT>(q.z);
+        lds_at<u32x2>(lds, 0 * T + 8 * u) = u32x2{q.x, q.y};
+        if constexpr (SC) {
+            lds_at<uint16_t>(lds, 8 * T + 2 * u) = (uint16_t)c;
+            lds_at<uint16_t>(lds, 10 * T + 2 * u) = (uint16_t)(c >> 16);
+        } else {
+            lds_at<uint32_t>(lds, 8 * T + 4 * u) = c;
+        }
+        lds_at<uint32_t>(lds, 12 * T + 4 * u) = q.w;
+    } else {
+        // q = { a0 a1 i0 i1, i2 i3 i4 i5, colours, indices }
+        const uint32_t c = decorrelate2<VARIANT>(q.z);
+        if constexpr (SA) {
+            lds_at<uint8_t>(lds, 0 * T + u) = (uint8_t)q.x;
+            lds_at<uint8_t>(lds, 1 * T + u) = (uint8_t)(q.x >> 8);
+        } else {
+            lds_at<uint16_t>(lds, 0 * T + 2 * u) = (uint16_t)q.x;
+        }
+        // 6-byte alpha-index record, only 2-byte aligned: three halfword stores
+        lds_at<uint16_t>(lds, 2 * T + 6 * u + 0) = (uint16_t)(q.x >> 16);
+        lds_at<uint16_t>(lds, 2 * T + 6 * u + 2) = (uint16_t)q.y;
+        lds_at<uint16_t>(lds, 2 * T + 6 * u + 4) = (uint16_t)(q.y >> 16);
+        if constexpr (SC) {
+            lds_at<uint16_t>(lds, 8 * T + 2 * u) = (uint16_t)c;
+            lds_at<uint16_t>(lds, 10 * T + 2 * u) = (uint16_t)(c >> 16);
+        } else {
+            lds_at<uint32_t>(lds, 8 * T + 4 * u) = c;
+        }
+        lds_at<uint32_t>(lds, 12 * T + 4 * u) = q.w;
+    }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
+{
+    constexpr int T = fmt_tile_blocks(FMT);
+    u32x4 q;
+    if constexpr (FMT == kBc1) {
+        uint32_t ca, cb;
+        if constexpr (SC) {
+            const uint32_t c0 = lds_at<uint32_t>(lds, 0 * T + 4 * u);
+            const uint32_t c1 = lds_at<uint32_t>(lds, 2 * T + 4 * u);
+            ca = (c0 & 0xFFFFu) | (c1 << 16);
+            cb = (c0 >> 16) | (c1 & 0xFFFF0000u);
+        } else {
+            const u32x2 p = lds_at<u32x2>(lds, 0 * T + 8 * u);
+            ca = p.x;
+            cb = p.y;
+        }
+        const u32x2 idx = lds_at<u32x2>(lds, 4 * T + 8 * u);
+        q.x = recorrelate2<VARIANT>(ca);
+        q.y = idx.x;
+        q.z = recorrelate2<VARIANT>(cb);
+        q.w = idx.y;
+    } else if constexpr (FMT == kBc2) {
+        const u32x2 a = lds_at<u32x2>(lds, 0 * T + 8 * u);
+        uint32_t c;
+        if constexpr (SC)
+            c = (uint32_t)lds_at<uint16_t>(lds, 8 * T + 2 * u) | ((uint32_t)lds_at<uint16_t>(lds, 10 * T + 2 * u) << 16);
+        else
+            c = lds_at<uint32_t>(lds, 8 * T + 4 * u);
+        q.x = a.x;
+        q.y = a.y;
+        q.z = recorrelate2<VARIANT>(c);
+        q.w = lds_at<uint32_t>(lds, 12 * T + 4 * u);
+    } else {
+        uint32_t a01;
+        if constexpr (SA)
+            a01 = (uint32_t)lds_at<uint8_t>(lds, 0 * T + u) | ((uint32_t)lds_at<uint8_t>(lds, 1 * T + u) << 8);
+        else
+            a01 = lds_at<uint16_t>(lds, 0 * T + 2 * u);
+        const uint32_t i01 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 0);
+        const uint32_t i23 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 2);
+        const uint32_t i45 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 4);
+        uint32_t c;
+        if constexpr (SC)
+            c = (uint32_t)lds_at<uint16_t>(lds, 8 * T + 2 * u) | ((uint32_t)lds_at<uint16_t>(lds, 10 * T + 2 * u) << 16);
+        else
+            c = lds_at<uint32_t>(lds, 8 * T + 4 * u);
+        q.x = a01 | (i01 << 16);
+        q.y = i23 | (i45 << 16);
+        q.z = recorrelate2<VARIANT>(c);
+        q.w = lds_at<uint32_t>(lds, 12 * T + 4 * u);
+    }
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiled kernels.  `aos` points at the range's first block, `soa` at byte 0 of the whole transformed
+// buffer.  Preconditions (checked on the host): both pointers 16-byte aligned; every stream base
+// off*total_blocks + width*first_block is a multiple of 16; the range starts with `num_tiles` full tiles.
+// ------------------------------------------------------------------------------------------------
+template <int FMT, int VARIANT, bool SA, bool SC>
+__global__ void __launch_bounds__(kThreads)
+fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks,
+          uint64_t first_block, uint64_t num_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kTileBytes];
+    constexpr int T = fmt_tile_blocks(FMT);
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+
+    uint64_t tile = blockIdx.x;
+    if (tile >= num_tiles)
+        return;
+
+    u32x4 q[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j)
+        q[j] = gload16(aos + tile * kTileBytes + (uint64_t)(t + kThreads * j) * 16);
+
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j)
+            scatter_to_image<FMT, VARIANT, SA, SC>(lds, t + kThreads * j, q[j]);
+        __syncthreads();
+
+        const uint64_t next = tile + gridDim.x;
+        const bool has_next = next < num_tiles;
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < kVecs; ++j)
+                q[j] = gload16(aos + next * kTileBytes + (uint64_t)(t + kThreads * j) * 16);
+        }
+
+        const uint64_t blk0 = first_block + tile * T;
+#pragma unroll
+        for (int k = 0; k < kVecs; ++k) {
+            const int chunk_byte = (wave + 4 * k) * 1024;  // SGPR
+            const u32x4 v = lds_at<u32x4>(lds, chunk_byte + lane * 16);
+            const uint64_t o = soa_offset_of_chunk<FMT, SA, SC>(chunk_byte, total_blocks, blk0);
+            gstore16(soa + o + lane * 16, v);
+        }
+        if (!has_next)
+            break;
+        __syncthreads();
+        tile = next;
+    }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__global__ void __launch_bounds__(kThreads)
+inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks,
+          uint64_t first_block, uint64_t num_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kTileBytes];
+    constexpr int T = fmt_tile_blocks(FMT);
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+
+    uint64_t tile = blockIdx.x;
+    if (tile >= num_tiles)
+        return;
+
+    u32x4 v[kVecs];
+#pragma unroll
+    for (int k = 0; k < kVecs; ++k) {
+        const int chunk_byte = (wave + 4 * k) * 1024;
+        const uint64_t o = soa_offset_of_chunk<FMT, SA, SC>(chunk_byte, total_blocks, first_block + tile * T);
+        v[k] = gload16(soa + o + lane * 16);
+    }
+
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < kVecs; ++k)
+            lds_at<u32x4>(lds, (wave + 4 * k) * 1024 + lane * 16) = v[k];
+        __syncthreads();
+
+        const uint64_t next = tile + gridDim.x;
+        const bool has_next = next < num_tiles;
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < kVecs; ++k) {
+                const int chunk_byte = (wave + 4 * k) * 1024;
+                const uint64_t o =
+                    soa_offset_of_chunk<FMT, SA, SC>(chunk_byte, total_blocks, first_block + next * T);
+                v[k] = gload16(soa + o + lane * 16);
+            }
+        }
+
+#pragma unroll
+        for (int j = 0; j < kVecs; ++j) {
+            const int u = t + kThreads * j;
+            const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC>(lds, u);
+            gstore16(aos + tile * kTileBytes + (uint64_t)u * 16, q);
+        }
+        if (!has_next)
+            break;
+        __syncthreads();
+        tile = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Element-granular kernels: one lane per block, any alignment, any block count.  Used for the tail of a
+// tiled range and for buffers whose pointers / stream bases are not 16-byte aligned.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, bool natural)
+{
+    // W in {1,2,4,8}; `natural` = p is W-aligned (uniform per stream)
+    if (natural) {
+        if constexpr (W == 1) *p = (uint8_t)v;
+        if constexpr (W == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)v;
+        if constexpr (W == 4) *reinterpret_cast<uint32_t*>(p) = (uint32_t)v;
+        if constexpr (W == 8) *reinterpret_cast<uint64_t*>(p) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            p[i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
+template <int W>
+__device__ __forceinline__ uint64_t load_bytes(const uint8_t* p, bool natural)
+{
+    if (natural) {
+        if constexpr (W == 1) return *p;
+        if constexpr (W == 2) return *reinterpret_cast<const uint16_t*>(p);
+        if constexpr (W == 4) return *reinterpret_cast<const uint32_t*>(p);
+        if constexpr (W == 8) return *reinterpret_cast<const uint64_t*>(p);
+    }
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+        v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+
+__device__ __forceinline__ bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
+__global__ void __launch_bounds__(kThreads)
+generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t total_blocks,
+               uint64_t first_block, uint64_t local_first, uint64_t count)
+{
+    // AoS side: block (local_first + i) of the range lives at aos + (local_first + i) * BLOCK.
+    // SoA side: global block index first_block + local_first + i.
+    constexpr int B = fmt_block(FMT);
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= count)
+        return;
+    const uint64_t lb = local_first + i;
+    const uint64_t gb = first_block + lb;
+    const uint64_t N = total_blocks;
+
+    const uint8_t* aos_c = INVERSE ? nullptr : src + lb * B;
+    uint8_t* aos_m = INVERSE ? dst + lb * B : nullptr;
+    const uint8_t* soa_c = INVERSE ? src : nullptr;
+    uint8_t* soa_m = INVERSE ? nullptr : dst;
+
+    const void* aos_any = INVERSE ? (const void*)aos_m : (const void*)aos_c;
+    const void* soa_any = INVERSE ? (const void*)soa_c : (const void*)soa_m;
+    const bool aos4 = aligned_to(aos_any, 4);  // block size is a multiple of 8, so uniform per launch
+    const bool aos2 = aligned_to(aos_any, 2);
+    const uintptr_t soa_base = reinterpret_cast<uintptr_t>(soa_any);
+
+    // field values of the block
+    uint64_t alpha8 = 0;          // BC2 alpha
+    uint32_t a0 = 0, a1 = 0;      // BC3 alpha endpoints
+    uint32_t i01 = 0, i23 = 0, i45 = 0;  // BC3 alpha index halfwords
+    uint32_t colours = 0, indices = 0;
+    constexpr int CO = (FMT == kBc1) ? 0 : 8;   // colour dword offset in block
+
+    if constexpr (!INVERSE) {
+        if constexpr (FMT == kBc2)
+            alpha8 = load_bytes<4>(aos_c, aos4) | (load_bytes<4>(aos_c + 4, aos4) << 32);
+        if constexpr (FMT == kBc3) {
+            a0 = aos_c[0];
+            a1 = aos_c[1];
+            i01 = (uint32_t)load_bytes<2>(aos_c + 2, aos2);
+            i23 = (uint32_t)load_bytes<2>(aos_c + 4, aos2);
+            i45 = (uint32_t)load_bytes<2>(aos_c + 6, aos2);
+        }
+        colours = decorrelate2<VARIANT>((uint32_t)load_bytes<4>(aos_c + CO, aos4));
+        indices = (uint32_t)load_bytes<4>(aos_c + CO + 4, aos4);
+    }
+
+    // stream addresses (byte offsets from the start of the transformed buffer)
+    uint64_t o_alpha = 0, o_a1 = 0, o_aidx = 0, o_col, o_c1 = 0, o_idx;
+    if constexpr (FMT == kBc1) {
+        o_col = SC ? 2 * gb : 4 * gb;
+        o_c1 = 2 * N + 2 * gb;
+        o_idx = 4 * N + 4 * gb;
+    } else {
+        if constexpr (FMT == kBc2) {
+            o_alpha = 8 * gb;
+        } else {
+            o_alpha = SA ? gb : 2 * gb;
+            o_a1 = N + gb;
+            o_aidx = 2 * N + 6 * gb;
+        }
+        o_col = 8 * N + (SC ? 2 * gb : 4 * gb);
+        o_c1 = 10 * N + 2 * gb;
+        o_idx = 12 * N + 4 * gb;
+    }
+    const bool n2 = ((soa_base) & 1) == 0;  // every 2-byte stream element offset is even, so parity = base parity
+    // 4-/8-byte alignment of a stream depends on base + off*N (uniform per launch)
+    auto al = [&](uint64_t off, int a) { return ((soa_base + off) & (uint64_t)(a - 1)) == 0; };
+
+    if constexpr (!INVERSE) {
+        if constexpr (FMT == kBc2)
+            store_bytes<8>(soa_m + o_alpha, alpha8, al(o_alpha, 8));
+        if constexpr (FMT == kBc3) {
+            if constexpr (SA) {
+                soa_m[o_alpha] = (uint8_t)a0;
+                soa_m[o_a1] = (uint8_t)a1;
+            } else {
+                store_bytes<2>(soa_m + o_alpha, a0 | (a1 << 8), n2);
+            }
+            store_bytes<2>(soa_m + o_aidx + 0, i01, al(o_aidx, 2));
+            store_bytes<2>(soa_m + o_aidx + 2, i23, al(o_aidx, 2));
+            store_bytes<2>(soa_m + o_aidx + 4, i45, al(o_aidx, 2));
+        }
+        if constexpr (SC) {
+            store_bytes<2>(soa_m + o_col, colours & 0xFFFFu, al(o_col, 2));
+            store_bytes<2>(soa_m + o_c1, colours >> 16, al(o_c1, 2));
+        } else {
+            store_bytes<4>(soa_m + o_col, colours, al(o_col, 4));
+        }
+        store_bytes<4>(soa_m + o_idx, indices, al(o_idx, 4));
+    } else {
+        if constexpr (FMT == kBc2)
+            alpha8 = load_bytes<8>(soa_c + o_alpha, al(o_alpha, 8));
+        if constexpr (FMT == kBc3) {
+            if constexpr (SA) {
+                a0 = soa_c[o_alpha];
+                a1 = soa_c[o_a1];
+            } else {
+                const uint32_t p = (uint32_t)load_bytes<2>(soa_c + o_alpha, n2);
+                a0 = p & 0xFF;
+                a1 = p >> 8;
+            }
+            i01 = (uint32_t)load_bytes<2>(soa_c + o_aidx + 0, al(o_aidx, 2));
+            i23 = (uint32_t)load_bytes<2>(soa_c + o_aidx + 2, al(o_aidx, 2));
+            i45 = (uint32_t)load_bytes<2>(soa_c + o_aidx + 4, al(o_aidx, 2));
+        }
+        if constexpr (SC)
+            colours = (uint32_t)load_bytes<2>(soa_c + o_col, al(o_col, 2)) |
+                      ((uint32_t)load_bytes<2>(soa_c + o_c1, al(o_c1, 2)) << 16);
+        else
+            colours = (uint32_t)load_bytes<4>(soa_c + o_col, al(o_col, 4));
+        indices = (uint32_t)load_bytes<4>(soa_c + o_idx, al(o_idx, 4));
+        colours = recorrelate2<VARIANT>(colours);
+
+        if constexpr (FMT == kBc2) {
+            store_bytes<4>(aos_m, (uint32_t)alpha8, aos4);
+            store_bytes<4>(aos_m + 4, (uint32_t)(alpha8 >> 32), aos4);
+        }
+        if constexpr (FMT == kBc3) {
+            aos_m[0] = (uint8_t)a0;
+            aos_m[1] = (uint8_t)a1;
+            store_bytes<2>(aos_m + 2, i01, aos2);
+            store_bytes<2>(aos_m + 4, i23, aos2);
+            store_bytes<2>(aos_m + 6, i45, aos2);
+        }
+        store_bytes<4>(aos_m + CO, colours, aos4);
+        store_bytes<4>(aos_m + CO + 4, indices, aos4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic data: counter-based splitmix64, one qword per lane-iteration (bench / test plumbing).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t index)
+{
+    uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(kThreads)
+fill_splitmix64_kernel(uint8_t* __restrict__ dst, uint64_t len_bytes, uint64_t seed, uint64_t first_qword)
+{
+    const uint64_t qwords = len_bytes / 8;
+    const uint64_t stride = (uint64_t)gridDim.x * kThreads;
+    const bool al8 = aligned_to(dst, 8);
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < qwords; i += stride)
+        store_bytes<8>(dst + 8 * i, splitmix64_at(seed, first_qword + i), al8);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t rem = len_bytes - 8 * qwords;
+        const uint64_t v = splitmix64_at(seed, first_qword + qwords);
+        for (uint64_t k = 0; k < rem; ++k)
+            dst[8 * qwords + k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-side dispatch
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t);
+using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
+
+struct KernelSet {
+    TiledFn tiled;
+    GenericFn generic;
+};
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+KernelSet kernels_for(bool inverse)
+{
+    if (inverse)
+        return {inv_tiled<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, true>};
+    return {fwd_tiled<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, false>};
+}
+
+template <int FMT, int VARIANT>
+KernelSet pick_splits(bool sa, bool sc, bool inverse)
+{
+    if constexpr (FMT == kBc3) {
+        if (sa)
+            return sc ? kernels_for<FMT, VARIANT, true, true>(inverse) : kernels_for<FMT, VARIANT, true, false>(inverse);
+        return sc ? kernels_for<FMT, VARIANT, false, true>(inverse) : kernels_for<FMT, VARIANT, false, false>(inverse);
+    } else {
+        return sc ? kernels_for<FMT, VARIANT, false, true>(inverse) : kernels_for<FMT, VARIANT, false, false>(inverse);
+    }
+}
+
+template <int FMT>
+KernelSet pick_variant(int variant, bool sa, bool sc, bool inverse)
+{
+    switch (variant) {
+    case kNone: return pick_splits<FMT, kNone>(sa, sc, inverse);
+    case kVar1: return pick_splits<FMT, kVar1>(sa, sc, inverse);
+    case kVar2: return pick_splits<FMT, kVar2>(sa, sc, inverse);
+    default: return pick_splits<FMT, kVar3>(sa, sc, inverse);
+    }
+}
+
+int cached_cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256;
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+}  // namespace
+
+hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const void* src, void* dst,
+                            const Range& r, hipStream_t stream, const LaunchTuning* tuning)
+{
+    if (r.num_blocks == 0)
+        return hipSuccess;
+    if (s.variant < 0 || s.variant > 3 || r.first_block + r.num_blocks > r.total_blocks)
+        return hipErrorInvalidValue;
+
+    const bool sa = (fmt == kBc3) && s.split_alpha;
+    const bool sc = s.split_colour;
+    KernelSet ks;
+    switch (fmt) {
+    case kBc1: ks = pick_variant<kBc1>(s.variant, false, sc, inverse); break;
+    case kBc2: ks = pick_variant<kBc2>(s.variant, false, sc, inverse); break;
+    case kBc3: ks = pick_variant<kBc3>(s.variant, sa, sc, inverse); break;
+    default: return hipErrorInvalidValue;
+    }
+
+    const uint8_t* src8 = static_cast<const uint8_t*>(src);
+    uint8_t* dst8 = static_cast<uint8_t*>(dst);
+    const void* aos = inverse ? (const void*)dst : src;
+    const void* soa = inverse ? src : (const void*)dst;
+
+    // Can the tiled path take the range?  Both pointers and every stream base must be 16-byte aligned.
+    const Streams S = make_streams(fmt, sa, sc);
+    bool tiled_ok = ((reinterpret_cast<uintptr_t>(aos) | reinterpret_cast<uintptr_t>(soa)) & 15) == 0;
+    for (int i = 0; i < S.n && tiled_ok; ++i)
+        tiled_ok = (((uint64_t)S.off[i] * r.total_blocks + (uint64_t)S.width[i] * r.first_block) & 15) == 0;
+    if (tuning && tuning->force_generic)
+        tiled_ok = false;
+
+    const uint64_t T = (uint64_t)fmt_tile_blocks(fmt);
+    const uint64_t num_tiles = tiled_ok ? r.num_blocks / T : 0;
+    if (num_tiles > 0) {
+        int per_cu = (tuning && tuning->wgs_per_cu > 0) ? tuning->wgs_per_cu : 8;
+        uint64_t grid = (uint64_t)cached_cu_count() * (uint64_t)per_cu;
+        if (grid > num_tiles)
+            grid = num_tiles;
+        hipLaunchKernelGGL(ks.tiled, dim3((unsigned)grid), dim3(kThreads), 0, stream, src8, dst8, r.total_blocks,
+                           r.first_block, num_tiles);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    const uint64_t done = num_tiles * T;
+    const uint64_t rest = r.num_blocks - done;
+    if (rest > 0) {
+        const uint64_t grid = (rest + kThreads - 1) / kThreads;
+        if (grid > 0x7FFFFFFFull)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ks.generic, dim3((unsigned)grid), dim3(kThreads), 0, stream, src8, dst8, r.total_blocks,
+                           r.first_block, done, rest);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_fill_splitmix64(void* dst, size_t len_bytes, uint64_t seed, uint64_t first_qword,
+                                  hipStream_t stream)
+{
+    if (len_bytes == 0)
+        return hipSuccess;
+    uint64_t qwords = len_bytes / 8 + 1;
+    uint64_t grid = (qwords + kThreads - 1) / kThreads;
+    const uint64_t cap = (uint64_t)cached_cu_count() * 16;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(fill_splitmix64_kernel, dim3((unsigned)grid), dim3(kThreads), 0, stream,
+                       static_cast<uint8_t*>(dst), (uint64_t)len_bytes, seed, first_qword);
+    return hipGetLastError();
+}
+
+}  // namespace dxtlt

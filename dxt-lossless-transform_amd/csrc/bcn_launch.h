@@ -1,0 +1,84 @@
+// bcn_launch.h -- internal launch interface between the C ABI layer and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dxtlt {
+
+enum Format : int { kBc1 = 1, kBc2 = 2, kBc3 = 3 };
+
+struct Settings {
+    int variant;        // core YCoCgVariant numbering: 0 None, 1..3
+    bool split_alpha;   // BC3 only
+    bool split_colour;
+};
+
+// One contiguous range of blocks of a larger block array (the whole array when first_block == 0 and
+// num_blocks == total_blocks).  `aos` points at the AoS data of the RANGE's first block; `soa` points
+// at byte 0 of the WHOLE transformed buffer (stream bases are functions of total_blocks).
+struct Range {
+    uint64_t total_blocks;
+    uint64_t first_block;
+    uint64_t num_blocks;
+};
+
+struct LaunchTuning {
+    int wgs_per_cu;   // persistent grid = CUs * wgs_per_cu (0 = default)
+    int force_generic;  // 1 = always take the element-granular kernel (testing)
+};
+
+// Forward: aos (input) -> soa (output).  Inverse: soa (input) -> aos (output).
+// Enqueues on `stream`; returns the first HIP error.
+hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const void* src, void* dst,
+                            const Range& r, hipStream_t stream, const LaunchTuning* tuning = nullptr);
+
+// Deterministic synthetic data: qword i = splitmix64(seed, first_qword + i) (matches oracle_fill_splitmix64).
+hipError_t launch_fill_splitmix64(void* dst, size_t len_bytes, uint64_t seed, uint64_t first_qword,
+                                  hipStream_t stream);
+
+inline int block_bytes(Format f) { return f == kBc1 ? 8 : 16; }
+
+// ------------------------------------------------------------------------------------------------
+// Stream table.  A transformed buffer is a concatenation of streams; stream s holds `width` bytes per
+// block and starts at byte `off * N` (N = total blocks).  `off` also equals the field's byte offset
+// inside the AoS block, and the LDS image of a T-block tile uses the same table with N := T.
+//   BC1  split: c0 2@0, c1 2@2, idx 4@4          no split: colours 4@0, idx 4@4
+//   BC2  alpha 8@0, then colours at 8 (2+2 or 4), idx 4@12
+//   BC3  alpha endpoints at 0 (1+1 or 2), alpha indices 6@2, colours at 8 (2+2 or 4), idx 4@12
+// (reference: bc1 transform_with_settings.rs:43-58, bc2 :43-46, bc3 :54-56,76-80)
+// ------------------------------------------------------------------------------------------------
+struct Streams {
+    int n;
+    int width[6];
+    int off[6];
+};
+
+constexpr Streams make_streams(int fmt, bool split_alpha, bool split_colour)
+{
+    Streams s{};
+    int n = 0, off = 0;
+    if (fmt == kBc3) {
+        if (split_alpha) {
+            s.width[n] = 1; s.off[n] = off; off += 1; ++n;
+            s.width[n] = 1; s.off[n] = off; off += 1; ++n;
+        } else {
+            s.width[n] = 2; s.off[n] = off; off += 2; ++n;
+        }
+        s.width[n] = 6; s.off[n] = off; off += 6; ++n;
+    }
+    if (fmt == kBc2) {
+        s.width[n] = 8; s.off[n] = off; off += 8; ++n;
+    }
+    if (split_colour) {
+        s.width[n] = 2; s.off[n] = off; off += 2; ++n;
+        s.width[n] = 2; s.off[n] = off; off += 2; ++n;
+    } else {
+        s.width[n] = 4; s.off[n] = off; off += 4; ++n;
+    }
+    s.width[n] = 4; s.off[n] = off; off += 4; ++n;
+    s.n = n;
+    return s;
+}
+
+}  // namespace dxtlt

@@ -1,0 +1,398 @@
+// dxtlt_api.cpp -- C ABI of libdxtlt_gfx950.so (include/dxtlt_gfx950.h): argument validation, the
+// host-pointer staging path, the device-pointer path and the single-process multi-GPU shard path.
+// All arithmetic lives in bcn_kernels.hip; nothing here touches block bytes on the CPU.
+#include "../../include/dxtlt_gfx950.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bcn_launch.h"
+
+namespace {
+
+using dxtlt::Format;
+using dxtlt::Range;
+using dxtlt::Settings;
+
+thread_local std::string g_last_error;
+std::atomic<int> g_wgs_per_cu{0};
+std::atomic<int> g_force_generic{0};
+
+int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[256];
+    if (e != hipSuccess)
+        std::snprintf(buf, sizeof buf, "dxtlt: %s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    else
+        std::snprintf(buf, sizeof buf, "dxtlt: %s", what);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr, what)                                \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess)                              \
+            return fail(DXTLT_E_DEVICE, what, e_);         \
+    } while (0)
+
+dxtlt::LaunchTuning current_tuning()
+{
+    dxtlt::LaunchTuning t;
+    t.wgs_per_cu = g_wgs_per_cu.load(std::memory_order_relaxed);
+    t.force_generic = g_force_generic.load(std::memory_order_relaxed);
+    return t;
+}
+
+int32_t check_common(int32_t format, size_t len, uint8_t mode, const void* a, const void* b)
+{
+    if (format < 1 || format > 3)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
+    if (len % (size_t)dxtlt::block_bytes((Format)format) != 0)
+        return fail(DXTLT_E_INVALID_LENGTH, "len is not a multiple of the block size");
+    if (mode > 3)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "decorrelation_mode must be 0..3");
+    if (len > 0 && (a == nullptr || b == nullptr))
+        return fail(DXTLT_E_INVALID_ARGUMENT, "NULL buffer with len > 0");
+    return DXTLT_OK;
+}
+
+int32_t device_range(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t total, uint64_t first,
+                     uint64_t num, uint8_t mode, bool sa, bool sc, hipStream_t stream)
+{
+    if (format < 1 || format > 3)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
+    if (mode > 3)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "decorrelation_mode must be 0..3");
+    if (first > total || num > total - first)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "block range exceeds total_blocks");
+    if (num == 0)
+        return DXTLT_OK;
+    if (d_src == nullptr || d_dst == nullptr)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "NULL device buffer with a non-empty range");
+    Settings s{(int)mode, sa, sc};
+    Range r{total, first, num};
+    dxtlt::LaunchTuning t = current_tuning();
+    HIP_TRY(dxtlt::launch_transform((Format)format, inverse, s, d_src, d_dst, r, stream, &t), "kernel launch");
+    return DXTLT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host-pointer path.  Per thread and device: one stream and a grow-only pair of device buffers, so that
+// repeated calls (the reference's callers transform file after file) pay allocation once.
+// ---------------------------------------------------------------------------------------------------
+struct HostCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    size_t cap = 0;
+
+    ~HostCtx() { release(); }
+
+    void release()
+    {
+        if (device >= 0) {
+            // best effort; the runtime may already be shutting down at thread exit
+            if (d_in) (void)hipFree(d_in);
+            if (d_out) (void)hipFree(d_out);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+        d_in = d_out = nullptr;
+        stream = nullptr;
+        cap = 0;
+        device = -1;
+    }
+
+    int32_t prepare(size_t bytes)
+    {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            return fail(DXTLT_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)", e);
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+        if (dev != device) {
+            release();
+            device = dev;
+            HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+        }
+        if (bytes > cap) {
+            if (d_in) (void)hipFree(d_in);
+            if (d_out) (void)hipFree(d_out);
+            d_in = d_out = nullptr;
+            cap = 0;
+            size_t want = bytes + bytes / 8;  // a little headroom for the next, slightly larger file
+            if (hipMalloc(&d_in, want) != hipSuccess || hipMalloc(&d_out, want) != hipSuccess) {
+                (void)hipGetLastError();
+                if (d_in) (void)hipFree(d_in);
+                d_in = d_out = nullptr;
+                want = bytes;
+                HIP_TRY(hipMalloc(&d_in, want), "hipMalloc(input staging)");
+                HIP_TRY(hipMalloc(&d_out, want), "hipMalloc(output staging)");
+            }
+            cap = want;
+        }
+        return DXTLT_OK;
+    }
+};
+
+thread_local HostCtx g_host_ctx;
+
+int32_t host_call(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode, bool sa,
+                  bool sc)
+{
+    int32_t rc = check_common(format, len, mode, in, out);
+    if (rc != DXTLT_OK)
+        return rc;
+    if (len == 0)
+        return DXTLT_OK;  // zero blocks: nothing to do, no device needed
+    HostCtx& c = g_host_ctx;
+    rc = c.prepare(len);
+    if (rc != DXTLT_OK)
+        return rc;
+    const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
+    HIP_TRY(hipMemcpyAsync(c.d_in, in, len, hipMemcpyHostToDevice, c.stream), "H2D copy");
+    rc = device_range(format, inverse, c.d_in, c.d_out, blocks, 0, blocks, mode, sa, sc, c.stream);
+    if (rc != DXTLT_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, c.d_out, len, hipMemcpyDeviceToHost, c.stream), "D2H copy");
+    HIP_TRY(hipStreamSynchronize(c.stream), "stream synchronize");
+    return DXTLT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Single-process multi-GPU shard path: contiguous block ranges, one host thread per
+// device, no collective.  A shard is transformed as a stand-alone buffer on its device (blocks are
+// independent, so its compact SoA result holds exactly this shard's slice of every stream); the
+// "host concat" is one D2H copy per stream straight to the slice's final place.
+// ---------------------------------------------------------------------------------------------------
+struct ShardPlan {
+    uint64_t first;
+    uint64_t count;
+};
+
+std::vector<ShardPlan> plan_shards(uint64_t total_blocks, int shards, uint64_t align_blocks)
+{
+    // equal shares rounded down to a multiple of `align_blocks` (keeps every per-stream slice 16-byte
+    // aligned and tile-sized); the last shard takes the remainder
+    std::vector<ShardPlan> p((size_t)shards);
+    uint64_t share = total_blocks / (uint64_t)shards;
+    share -= share % align_blocks;
+    uint64_t at = 0;
+    for (int i = 0; i < shards; ++i) {
+        uint64_t n = (i == shards - 1) ? total_blocks - at : share;
+        p[(size_t)i] = {at, n};
+        at += n;
+    }
+    return p;
+}
+
+int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, uint8_t* out, uint64_t total,
+                     ShardPlan sp, uint8_t mode, bool sa, bool sc)
+{
+    if (sp.count == 0)
+        return DXTLT_OK;
+    const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
+    const size_t bytes = (size_t)(sp.count * B);
+    const dxtlt::Streams S = dxtlt::make_streams(format, format == 3 && sa, sc);
+    HIP_TRY(hipSetDevice(dev), "hipSetDevice");
+    hipStream_t st = nullptr;
+    void *d_a = nullptr, *d_b = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    int32_t rc = DXTLT_OK;
+    auto done = [&](int32_t code) {
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        (void)hipStreamDestroy(st);
+        return code;
+    };
+    if (hipMalloc(&d_a, bytes) != hipSuccess || hipMalloc(&d_b, bytes) != hipSuccess)
+        return done(fail(DXTLT_E_DEVICE, "hipMalloc(shard buffers)", hipGetLastError()));
+
+    hipError_t e = hipSuccess;
+    if (!inverse) {
+        // AoS slice in, compact SoA out, then scatter the stream slices to their final host offsets
+        e = hipMemcpyAsync(d_a, in + sp.first * B, bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+            rc = device_range(format, false, d_a, d_b, sp.count, 0, sp.count, mode, sa, sc, st);
+        for (int s = 0; s < S.n && e == hipSuccess && rc == DXTLT_OK; ++s) {
+            const uint64_t w = (uint64_t)S.width[s], off = (uint64_t)S.off[s];
+            e = hipMemcpyAsync(out + off * total + w * sp.first, (const uint8_t*)d_b + off * sp.count,
+                               (size_t)(w * sp.count), hipMemcpyDeviceToHost, st);
+        }
+    } else {
+        // gather this shard's slice of every stream into a compact SoA buffer, untransform, copy AoS back
+        for (int s = 0; s < S.n && e == hipSuccess; ++s) {
+            const uint64_t w = (uint64_t)S.width[s], off = (uint64_t)S.off[s];
+            e = hipMemcpyAsync((uint8_t*)d_a + off * sp.count, in + off * total + w * sp.first,
+                               (size_t)(w * sp.count), hipMemcpyHostToDevice, st);
+        }
+        if (e == hipSuccess)
+            rc = device_range(format, true, d_a, d_b, sp.count, 0, sp.count, mode, sa, sc, st);
+        if (e == hipSuccess && rc == DXTLT_OK)
+            e = hipMemcpyAsync(out + sp.first * B, d_b, bytes, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess && rc == DXTLT_OK)
+        e = hipStreamSynchronize(st);
+    if (rc != DXTLT_OK)
+        return done(rc);
+    if (e != hipSuccess)
+        return done(fail(DXTLT_E_DEVICE, "shard copy/launch", e));
+    return done(DXTLT_OK);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- host pointers ------------------------------------------------------------------------------
+int32_t dxtlt_transform_bc1_with_settings(const uint8_t* i, uint8_t* o, size_t len, uint8_t mode, bool sc)
+{
+    return host_call(1, false, i, o, len, mode, false, sc);
+}
+int32_t dxtlt_untransform_bc1_with_settings(const uint8_t* i, uint8_t* o, size_t len, uint8_t mode, bool sc)
+{
+    return host_call(1, true, i, o, len, mode, false, sc);
+}
+int32_t dxtlt_transform_bc2_with_settings(const uint8_t* i, uint8_t* o, size_t len, uint8_t mode, bool sc)
+{
+    return host_call(2, false, i, o, len, mode, false, sc);
+}
+int32_t dxtlt_untransform_bc2_with_settings(const uint8_t* i, uint8_t* o, size_t len, uint8_t mode, bool sc)
+{
+    return host_call(2, true, i, o, len, mode, false, sc);
+}
+int32_t dxtlt_transform_bc3_with_settings(const uint8_t* i, uint8_t* o, size_t len, uint8_t mode, bool sa, bool sc)
+{
+    return host_call(3, false, i, o, len, mode, sa, sc);
+}
+int32_t dxtlt_untransform_bc3_with_settings(const uint8_t* i, uint8_t* o, size_t len, uint8_t mode, bool sa, bool sc)
+{
+    return host_call(3, true, i, o, len, mode, sa, sc);
+}
+
+// ---- device pointers, whole buffer -------------------------------------------------------------------
+static int32_t device_whole(int32_t format, bool inverse, const void* d_in, void* d_out, size_t len, uint8_t mode,
+                            bool sa, bool sc, void* stream)
+{
+    int32_t rc = check_common(format, len, mode, d_in, d_out);
+    if (rc != DXTLT_OK)
+        return rc;
+    const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
+    return device_range(format, inverse, d_in, d_out, blocks, 0, blocks, mode, sa, sc, (hipStream_t)stream);
+}
+
+int32_t dxtlt_transform_bc1_with_settings_device(const void* i, void* o, size_t len, uint8_t mode, bool sc, void* st)
+{
+    return device_whole(1, false, i, o, len, mode, false, sc, st);
+}
+int32_t dxtlt_untransform_bc1_with_settings_device(const void* i, void* o, size_t len, uint8_t mode, bool sc, void* st)
+{
+    return device_whole(1, true, i, o, len, mode, false, sc, st);
+}
+int32_t dxtlt_transform_bc2_with_settings_device(const void* i, void* o, size_t len, uint8_t mode, bool sc, void* st)
+{
+    return device_whole(2, false, i, o, len, mode, false, sc, st);
+}
+int32_t dxtlt_untransform_bc2_with_settings_device(const void* i, void* o, size_t len, uint8_t mode, bool sc, void* st)
+{
+    return device_whole(2, true, i, o, len, mode, false, sc, st);
+}
+int32_t dxtlt_transform_bc3_with_settings_device(const void* i, void* o, size_t len, uint8_t mode, bool sa, bool sc,
+                                                 void* st)
+{
+    return device_whole(3, false, i, o, len, mode, sa, sc, st);
+}
+int32_t dxtlt_untransform_bc3_with_settings_device(const void* i, void* o, size_t len, uint8_t mode, bool sa, bool sc,
+                                                   void* st)
+{
+    return device_whole(3, true, i, o, len, mode, sa, sc, st);
+}
+
+int32_t dxtlt_transform_range_device(int32_t format, bool inverse, const void* d_src, void* d_dst,
+                                     uint64_t total_blocks, uint64_t first_block, uint64_t num_blocks, uint8_t mode,
+                                     bool sa, bool sc, void* stream)
+{
+    return device_range(format, inverse, d_src, d_dst, total_blocks, first_block, num_blocks, mode, sa, sc,
+                        (hipStream_t)stream);
+}
+
+// ---- single-process multi-GPU ---------------------------------------------------------------------------
+int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len,
+                                uint8_t mode, bool sa, bool sc, int32_t num_devices)
+{
+    int32_t rc = check_common(format, len, mode, in, out);
+    if (rc != DXTLT_OK)
+        return rc;
+    if (len == 0)
+        return DXTLT_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(DXTLT_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)", e);
+    int shards = (num_devices <= 0 || num_devices > count) ? count : num_devices;
+    const uint64_t total = len / (size_t)dxtlt::block_bytes((Format)format);
+    if ((uint64_t)shards > total)
+        shards = (int)total;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+
+    // 2048 blocks = one BC1 tile = two BC2/BC3 tiles; also a multiple of 16 so all slices stay 16-B aligned
+    std::vector<ShardPlan> plan = plan_shards(total, shards, 2048);
+    std::vector<int32_t> codes((size_t)shards, DXTLT_OK);
+    std::vector<std::string> msgs((size_t)shards);
+    std::vector<std::thread> threads;
+    for (int d = 0; d < shards; ++d) {
+        threads.emplace_back([&, d] {
+            codes[(size_t)d] = shard_worker(d, format, inverse, in, out, total, plan[(size_t)d], mode, sa, sc);
+            if (codes[(size_t)d] != DXTLT_OK)
+                msgs[(size_t)d] = g_last_error;
+        });
+    }
+    for (auto& t : threads)
+        t.join();
+    (void)hipSetDevice(prev);
+    for (int d = 0; d < shards; ++d) {
+        if (codes[(size_t)d] != DXTLT_OK) {
+            g_last_error = msgs[(size_t)d];
+            return codes[(size_t)d];
+        }
+    }
+    return DXTLT_OK;
+}
+
+// ---- plumbing -------------------------------------------------------------------------------------------
+int32_t dxtlt_fill_splitmix64_device(void* d_dst, size_t len_bytes, uint64_t seed, uint64_t first_qword, void* stream)
+{
+    if (len_bytes > 0 && d_dst == nullptr)
+        return fail(DXTLT_E_INVALID_ARGUMENT, "NULL device buffer");
+    HIP_TRY(dxtlt::launch_fill_splitmix64(d_dst, len_bytes, seed, first_qword, (hipStream_t)stream), "fill launch");
+    return DXTLT_OK;
+}
+
+const char* dxtlt_last_error(void) { return g_last_error.c_str(); }
+
+int32_t dxtlt_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess)
+        return 0;
+    return count;
+}
+
+void dxtlt_set_tuning(int32_t wgs_per_cu, int32_t force_generic)
+{
+    g_wgs_per_cu.store(wgs_per_cu);
+    g_force_generic.store(force_generic);
+}
+
+const char* dxtlt_version(void) { return "dxtlt-gfx950 0.1.0"; }
+
+}  // extern "C"

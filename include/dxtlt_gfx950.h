@@ -1,0 +1,131 @@
+/*
+ * dxtlt_gfx950.h -- C ABI of libdxtlt_gfx950.so: the MI355X (gfx950) implementation of the BCn block
+ * transform hot path of Sewer56/dxt-lossless-transform.
+ *
+ * These are the entry points the reference's Rust crates bind through `extern "C"` so that the bodies of
+ * their `transform_bcN_with_settings` / `untransform_bcN_with_settings` become one FFI call (the shim is
+ * shown in INTEGRATION.md).  Reference signatures replaced (paths under /root/reference/src/core/):
+ *
+ *   transform_bc1_with_settings     dxt-lossless-transform-bc1/src/transform/transform_with_settings.rs:31
+ *   untransform_bc1_with_settings   dxt-lossless-transform-bc1/src/transform/transform_with_settings.rs:92
+ *   transform_bc2_with_settings     dxt-lossless-transform-bc2/src/transform/transform_with_settings.rs:30
+ *   untransform_bc2_with_settings   dxt-lossless-transform-bc2/src/transform/transform_with_settings.rs:93
+ *   transform_bc3_with_settings     dxt-lossless-transform-bc3/src/transform/transform_with_settings.rs:32
+ *   untransform_bc3_with_settings   dxt-lossless-transform-bc3/src/transform/transform_with_settings.rs:162
+ *
+ * Settings travel as scalars (the Rust settings structs are not repr(C)):
+ *   decorrelation_mode  = core YCoCgVariant numbering, None=0 Variant1=1 Variant2=2 Variant3=3
+ *                         (dxt-lossless-transform-common/src/color_565/decorrelate.rs:72-84)
+ *   split_*_endpoints   = Bc1/Bc2/Bc3TransformSettings fields (bc1 settings.rs:16-27, bc3 settings.rs:16-30)
+ *
+ * Contract kept from the reference: `len` is in bytes and must be a multiple of the block size (8 for BC1,
+ * 16 for BC2/BC3); output length == input length; any pointer alignment; any block count including 0;
+ * input and output must not overlap; reentrant, no global mutable state visible to the caller.
+ * Difference: the reference's unsafe fns return nothing; these return a status (0 = ok) because a device can
+ * fail where a CPU loop cannot.  DXTLT_E_* values below; dxtlt_last_error() gives the text for this thread.
+ *
+ * Three families:
+ *   *_with_settings           host pointers in, host pointers out (H2D + kernel + D2H on the current device)
+ *   *_with_settings_device    device pointers, enqueued on a caller-provided HIP stream, no synchronisation
+ *   *_with_settings_range     device pointers, one contiguous block range of a larger array
+ *                             (multi-GPU shards, chunked host staging)
+ */
+#ifndef DXTLT_GFX950_H
+#define DXTLT_GFX950_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define DXTLT_OK 0
+#define DXTLT_E_INVALID_LENGTH 1   /* len not a multiple of the block size */
+#define DXTLT_E_INVALID_ARGUMENT 2 /* bad decorrelation mode, NULL pointer with len > 0, bad range */
+#define DXTLT_E_NO_DEVICE 3        /* no usable HIP device */
+#define DXTLT_E_DEVICE 4           /* HIP runtime error (allocation, copy, launch) */
+
+/* YCoCgVariant, core numbering */
+#define DXTLT_YCOCG_NONE 0
+#define DXTLT_YCOCG_VARIANT1 1
+#define DXTLT_YCOCG_VARIANT2 2
+#define DXTLT_YCOCG_VARIANT3 3
+
+/* ---- host pointers: drop-in bodies of the reference's unsafe fns -------------------------------- */
+int32_t dxtlt_transform_bc1_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                          uint8_t decorrelation_mode, bool split_colour_endpoints);
+int32_t dxtlt_untransform_bc1_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                            uint8_t decorrelation_mode, bool split_colour_endpoints);
+int32_t dxtlt_transform_bc2_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                          uint8_t decorrelation_mode, bool split_colour_endpoints);
+int32_t dxtlt_untransform_bc2_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                            uint8_t decorrelation_mode, bool split_colour_endpoints);
+int32_t dxtlt_transform_bc3_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                          uint8_t decorrelation_mode, bool split_alpha_endpoints,
+                                          bool split_colour_endpoints);
+int32_t dxtlt_untransform_bc3_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                            uint8_t decorrelation_mode, bool split_alpha_endpoints,
+                                            bool split_colour_endpoints);
+
+/* ---- device pointers, whole buffer, asynchronous on `hip_stream` (a hipStream_t; NULL = default) -- */
+int32_t dxtlt_transform_bc1_with_settings_device(const void *d_input, void *d_output, size_t len,
+                                                 uint8_t decorrelation_mode, bool split_colour_endpoints,
+                                                 void *hip_stream);
+int32_t dxtlt_untransform_bc1_with_settings_device(const void *d_input, void *d_output, size_t len,
+                                                   uint8_t decorrelation_mode, bool split_colour_endpoints,
+                                                   void *hip_stream);
+int32_t dxtlt_transform_bc2_with_settings_device(const void *d_input, void *d_output, size_t len,
+                                                 uint8_t decorrelation_mode, bool split_colour_endpoints,
+                                                 void *hip_stream);
+int32_t dxtlt_untransform_bc2_with_settings_device(const void *d_input, void *d_output, size_t len,
+                                                   uint8_t decorrelation_mode, bool split_colour_endpoints,
+                                                   void *hip_stream);
+int32_t dxtlt_transform_bc3_with_settings_device(const void *d_input, void *d_output, size_t len,
+                                                 uint8_t decorrelation_mode, bool split_alpha_endpoints,
+                                                 bool split_colour_endpoints, void *hip_stream);
+int32_t dxtlt_untransform_bc3_with_settings_device(const void *d_input, void *d_output, size_t len,
+                                                   uint8_t decorrelation_mode, bool split_alpha_endpoints,
+                                                   bool split_colour_endpoints, void *hip_stream);
+
+/* ---- device pointers, one block range of a larger array -----------------------------------------
+ * format: 1, 2, 3 = BC1, BC2, BC3.  inverse: false = transform, true = untransform.
+ * The array has `total_blocks` blocks; this call handles blocks [first_block, first_block+num_blocks).
+ *   d_aos    points at the AoS bytes of block `first_block` (the range's own slice of the block array)
+ *   d_soa    points at byte 0 of the WHOLE transformed buffer (total_blocks * block_size bytes); the call
+ *            touches only this range's slice of every stream.
+ * Forward reads d_aos and writes d_soa; inverse reads d_soa and writes d_aos.
+ * With first_block = 0 and num_blocks = total_blocks this is the whole-buffer call. */
+int32_t dxtlt_transform_range_device(int32_t format, bool inverse, const void *d_src, void *d_dst,
+                                     uint64_t total_blocks, uint64_t first_block, uint64_t num_blocks,
+                                     uint8_t decorrelation_mode, bool split_alpha_endpoints,
+                                     bool split_colour_endpoints, void *hip_stream);
+
+/* ---- single-process multi-GPU: shard [0, N) by contiguous block range over `num_devices` GPUs -----
+ * Host pointers.  Each device receives its slice of the input, runs the range kernel, and its slice of
+ * every output stream is copied straight to its final place in `output_ptr` (no collective; see
+ * DESIGN.md "Multi-GPU").  num_devices <= 0 means all visible devices. */
+int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t *input_ptr, uint8_t *output_ptr,
+                                size_t len, uint8_t decorrelation_mode, bool split_alpha_endpoints,
+                                bool split_colour_endpoints, int32_t num_devices);
+
+/* ---- plumbing ---------------------------------------------------------------------------------- */
+/* Deterministic synthetic blocks on the device: qword i = splitmix64(seed, first_qword + i). */
+int32_t dxtlt_fill_splitmix64_device(void *d_dst, size_t len_bytes, uint64_t seed, uint64_t first_qword,
+                                     void *hip_stream);
+/* Text of the last failure on the calling thread ("" if none). */
+const char *dxtlt_last_error(void);
+/* Number of visible HIP devices (0 if the runtime cannot initialise). */
+int32_t dxtlt_device_count(void);
+/* Tuning knobs for experiments (persistent grid size = CUs * wgs_per_cu; force the element-granular
+ * kernel).  Process-wide; 0 restores the default. */
+void dxtlt_set_tuning(int32_t wgs_per_cu, int32_t force_generic);
+/* "dxtlt-gfx950 <version>" */
+const char *dxtlt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,106 @@
+/*
+ * dxtlt_oracle.h -- CPU oracle for the BCn block transform hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
+ * scalar ("portable32" / "generic") loops.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product library
+ * (libdxtlt_gfx950.so) never links, loads or calls anything in oracle/.
+ *
+ * Parity pin status: the reference (Rust, /root/reference) cannot be built in
+ * this image (no cargo/rustc) and holds NO golden vector of transformed bytes
+ * for any BC1/BC2/BC3 mode.  What it does hold, and what this oracle is checked
+ * against in tests/test_oracle.py:
+ *   - the three test-data generator known-answer vectors
+ *     (bc1 test_prelude.rs:107-119, bc2 :586-606, bc3 :1058-1078),
+ *   - the split_565_color_endpoints 3-pair vector (common .../tests.rs:140-152),
+ *   - the round-trip-for-every-n harness (bc1 test_prelude.rs:154-317 and twins),
+ *   - the YCoCg-R 13/16-colour round-trip sets (decorrelate.rs:413-446, avx2.rs:194-266),
+ *   - the real-texture round trips on assets/tests/r2-256-bc{1,2,3}.dds.
+ * Forward-byte parity therefore rests on the code-defined layout plus an
+ * independently written numpy restatement (oracle/oracle_np.py) agreeing with
+ * this file on every case; see DESIGN.md "Oracle".
+ *
+ * All reference paths below are relative to /root/reference/src/core/.
+ */
+#ifndef DXTLT_ORACLE_H
+#define DXTLT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* YCoCgVariant, core numbering:
+ * dxt-lossless-transform-common/src/color_565/decorrelate.rs:72-84 */
+enum {
+    ORACLE_YCOCG_NONE = 0,
+    ORACLE_YCOCG_VAR1 = 1,
+    ORACLE_YCOCG_VAR2 = 2,
+    ORACLE_YCOCG_VAR3 = 3
+};
+
+/* BcNValidationError (safe wrappers), e.g.
+ * dxt-lossless-transform-bc1/src/transform/safe/transform_with_settings.rs:18-31 */
+enum {
+    ORACLE_OK = 0,
+    ORACLE_INVALID_LENGTH = 1,
+    ORACLE_OUTPUT_TOO_SMALL = 2
+};
+
+/* Color565::{decorrelate,recorrelate}_ycocg_r(variant), decorrelate.rs:364,391 */
+uint16_t oracle_decorrelate_565(uint16_t v, int variant);
+uint16_t oracle_recorrelate_565(uint16_t v, int variant);
+
+/* transform_bcN_with_settings / untransform_bcN_with_settings (unsafe ptr API).
+ * len is in bytes and must be a multiple of the block size. */
+void oracle_transform_bc1(const uint8_t *in, uint8_t *out, size_t len, int variant, int split_colour);
+void oracle_untransform_bc1(const uint8_t *in, uint8_t *out, size_t len, int variant, int split_colour);
+void oracle_transform_bc2(const uint8_t *in, uint8_t *out, size_t len, int variant, int split_colour);
+void oracle_untransform_bc2(const uint8_t *in, uint8_t *out, size_t len, int variant, int split_colour);
+void oracle_transform_bc3(const uint8_t *in, uint8_t *out, size_t len, int variant, int split_alpha,
+                          int split_colour);
+void oracle_untransform_bc3(const uint8_t *in, uint8_t *out, size_t len, int variant, int split_alpha,
+                            int split_colour);
+
+/* *_safe wrappers: length / size validation then the call above. */
+int oracle_transform_bc1_safe(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int variant,
+                              int split_colour);
+int oracle_untransform_bc1_safe(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int variant,
+                                int split_colour);
+int oracle_transform_bc2_safe(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int variant,
+                              int split_colour);
+int oracle_untransform_bc2_safe(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int variant,
+                                int split_colour);
+int oracle_transform_bc3_safe(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int variant,
+                              int split_alpha, int split_colour);
+int oracle_untransform_bc3_safe(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int variant,
+                                int split_alpha, int split_colour);
+
+/* The reference's deterministic test-data generators (test_prelude.rs). */
+void oracle_generate_bc1_test_data(size_t num_blocks, uint8_t *out);
+void oracle_generate_bc2_test_data(size_t num_blocks, uint8_t *out);
+void oracle_generate_bc3_test_data(size_t num_blocks, uint8_t *out);
+
+/* split_color_endpoints reference implementation
+ * (common/src/transforms/split_565_color_endpoints/mod.rs:110): pairs -> all c0 then all c1. */
+void oracle_split_565_color_endpoints(const uint8_t *in, uint8_t *out, size_t len_bytes);
+
+/* Synthetic workload generator shared with the GPU fill kernel:
+ * qword i of the buffer = splitmix64_mix(seed + (first_qword + i + 1) * GOLDEN), little-endian. */
+void oracle_fill_splitmix64(uint8_t *out, size_t len_bytes, uint64_t seed, uint64_t first_qword);
+
+/* 64-bit wrapping sum of the buffer read as little-endian u64 words (tail bytes zero-extended):
+ * a cheap order-insensitive checksum computable on both sides. */
+uint64_t oracle_sum_u64(const uint8_t *data, size_t len_bytes);
+
+/* Multi-threaded (pthread) range split of the scalar loops above; used only by bench.py's
+ * cpu_baseline leg.  kind: 1/2/3 = BC1/BC2/BC3; inverse != 0 runs the untransform. */
+void oracle_run_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t len, int variant,
+                   int split_alpha, int split_colour, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

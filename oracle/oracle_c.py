@@ -1,0 +1,156 @@
+"""ctypes binding of the C oracle (oracle/dxtlt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of bench.py.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdxtlt_oracle.so")
+
+NONE, VAR1, VAR2, VAR3 = 0, 1, 2, 3
+OK, INVALID_LENGTH, OUTPUT_TOO_SMALL = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (``make -C oracle``) if the .so is missing or stale."""
+    src = os.path.join(_HERE, "dxtlt_oracle.c")
+    hdr = os.path.join(_HERE, "dxtlt_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_SO)
+        or (os.path.exists(src) and os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libdxtlt_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        l = C.CDLL(build())
+        u8p, sz, i = C.c_void_p, C.c_size_t, C.c_int
+        l.oracle_decorrelate_565.argtypes = [C.c_uint16, i]
+        l.oracle_decorrelate_565.restype = C.c_uint16
+        l.oracle_recorrelate_565.argtypes = [C.c_uint16, i]
+        l.oracle_recorrelate_565.restype = C.c_uint16
+        for n in ("bc1", "bc2"):
+            for d in ("transform", "untransform"):
+                f = getattr(l, f"oracle_{d}_{n}")
+                f.argtypes = [u8p, u8p, sz, i, i]
+                f.restype = None
+                f = getattr(l, f"oracle_{d}_{n}_safe")
+                f.argtypes = [u8p, sz, u8p, sz, i, i]
+                f.restype = i
+        for d in ("transform", "untransform"):
+            f = getattr(l, f"oracle_{d}_bc3")
+            f.argtypes = [u8p, u8p, sz, i, i, i]
+            f.restype = None
+            f = getattr(l, f"oracle_{d}_bc3_safe")
+            f.argtypes = [u8p, sz, u8p, sz, i, i, i]
+            f.restype = i
+        for n in ("bc1", "bc2", "bc3"):
+            f = getattr(l, f"oracle_generate_{n}_test_data")
+            f.argtypes = [sz, u8p]
+            f.restype = None
+        l.oracle_split_565_color_endpoints.argtypes = [u8p, u8p, sz]
+        l.oracle_split_565_color_endpoints.restype = None
+        l.oracle_fill_splitmix64.argtypes = [u8p, sz, C.c_uint64, C.c_uint64]
+        l.oracle_fill_splitmix64.restype = None
+        l.oracle_sum_u64.argtypes = [u8p, sz]
+        l.oracle_sum_u64.restype = C.c_uint64
+        l.oracle_run_mt.argtypes = [i, i, u8p, u8p, sz, i, i, i, i]
+        l.oracle_run_mt.restype = None
+        _lib = l
+    return _lib
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _as_u8(x) -> np.ndarray:
+    a = np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray, memoryview)) else np.asarray(x)
+    assert a.dtype == np.uint8 and a.ndim == 1
+    return a
+
+
+BLOCK = {"bc1": 8, "bc2": 16, "bc3": 16}
+
+
+def transform(fmt: str, data, variant: int = VAR1, split_colour: bool = True, split_alpha: bool = True,
+              inverse: bool = False) -> np.ndarray:
+    """oracle_{un,}transform_bcN on a whole buffer (no validation: len must be a block multiple)."""
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % BLOCK[fmt] == 0
+    out = np.empty_like(a)
+    d = "untransform" if inverse else "transform"
+    f = getattr(lib(), f"oracle_{d}_{fmt}")
+    if fmt == "bc3":
+        f(_ptr(a), _ptr(out), a.size, int(variant), int(split_alpha), int(split_colour))
+    else:
+        f(_ptr(a), _ptr(out), a.size, int(variant), int(split_colour))
+    return out
+
+
+def transform_safe(fmt: str, data, out_len: int, variant: int = VAR1, split_colour: bool = True,
+                   split_alpha: bool = True, inverse: bool = False):
+    """Safe-wrapper semantics: returns (code, out)."""
+    a = np.ascontiguousarray(_as_u8(data))
+    out = np.zeros(max(out_len, 1), dtype=np.uint8)
+    d = "untransform" if inverse else "transform"
+    f = getattr(lib(), f"oracle_{d}_{fmt}_safe")
+    if fmt == "bc3":
+        rc = f(_ptr(a), a.size, _ptr(out), out_len, int(variant), int(split_alpha), int(split_colour))
+    else:
+        rc = f(_ptr(a), a.size, _ptr(out), out_len, int(variant), int(split_colour))
+    return rc, out[:out_len]
+
+
+def generate_test_data(fmt: str, num_blocks: int) -> np.ndarray:
+    out = np.empty(num_blocks * BLOCK[fmt], dtype=np.uint8)
+    getattr(lib(), f"oracle_generate_{fmt}_test_data")(num_blocks, _ptr(out))
+    return out
+
+
+def split_565_color_endpoints(data) -> np.ndarray:
+    a = np.ascontiguousarray(_as_u8(data))
+    out = np.empty_like(a)
+    lib().oracle_split_565_color_endpoints(_ptr(a), _ptr(out), a.size)
+    return out
+
+
+def fill_splitmix64(len_bytes: int, seed: int, first_qword: int = 0) -> np.ndarray:
+    out = np.empty(len_bytes, dtype=np.uint8)
+    lib().oracle_fill_splitmix64(_ptr(out), len_bytes, seed & (2**64 - 1), first_qword)
+    return out
+
+
+def sum_u64(data) -> int:
+    a = np.ascontiguousarray(_as_u8(data))
+    return int(lib().oracle_sum_u64(_ptr(a), a.size))
+
+
+def run_mt(fmt: str, src: np.ndarray, dst: np.ndarray, variant: int, split_colour: bool, split_alpha: bool,
+           inverse: bool, threads: int) -> None:
+    kind = {"bc1": 1, "bc2": 2, "bc3": 3}[fmt]
+    lib().oracle_run_mt(kind, int(inverse), _ptr(src), _ptr(dst), src.size, int(variant), int(split_alpha),
+                        int(split_colour), int(threads))
+
+
+def decorrelate(v: int, variant: int) -> int:
+    return int(lib().oracle_decorrelate_565(v, variant))
+
+
+def recorrelate(v: int, variant: int) -> int:
+    return int(lib().oracle_recorrelate_565(v, variant))

@@ -1,0 +1,180 @@
+"""Second, independently written restatement of the BCn transform in numpy.
+
+TEST INFRASTRUCTURE ONLY (see oracle/dxtlt_oracle.h).  Where the C oracle walks one block at a
+time like the reference's scalar loops, this file states the *format*: it views the block array as
+a structured table and writes each output stream as one slice.  The two are written separately on
+purpose; tests/test_oracle.py requires them to agree byte-for-byte, and
+tests/golden/make_golden.py uses this file to emit the committed fixtures.
+
+Format statement (N = number of blocks, little-endian fields):
+  BC1  block {c0:u16, c1:u16, idx:u32}
+       out = [colours 4N][idx 4N]; colours = N x (c0',c1') pairs, or all c0' then all c1' when split
+       (reference: dxt-lossless-transform-bc1/src/transform/transform_with_settings.rs:39-71)
+  BC2  block {alpha:u64, c0, c1, idx}
+       out = [alpha 8N][colours 4N][idx 4N]            (bc2 .../transform_with_settings.rs:30-73)
+  BC3  block {a0:u8, a1:u8, aidx:6B, c0, c1, idx}
+       out = [alpha endpoints 2N][aidx 6N][colours 4N][idx 4N]; alpha endpoints = (a0,a1) pairs, or
+       all a0 then all a1 when split                   (bc3 .../transform_with_settings.rs:32-142)
+  c' = YCoCg-R(c) in 5-bit modular arithmetic (common/src/color_565/decorrelate.rs:101-344).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NONE, VAR1, VAR2, VAR3 = 0, 1, 2, 3
+
+BC1 = np.dtype([("c0", "<u2"), ("c1", "<u2"), ("idx", "<u4")])
+BC2 = np.dtype([("alpha", "<u8"), ("c0", "<u2"), ("c1", "<u2"), ("idx", "<u4")])
+BC3 = np.dtype([("a0", "u1"), ("a1", "u1"), ("aidx", "u1", (6,)), ("c0", "<u2"), ("c1", "<u2"), ("idx", "<u4")])
+assert BC1.itemsize == 8 and BC2.itemsize == 16 and BC3.itemsize == 16
+
+
+def decorrelate(c: np.ndarray, variant: int) -> np.ndarray:
+    """Vectorised Color565::decorrelate_ycocg_r on a u16 array."""
+    if variant == NONE:
+        return c.astype(np.uint16)
+    v = c.astype(np.int32)
+    r, g, gl, b = (v >> 11) & 31, (v >> 6) & 31, (v >> 5) & 1, v & 31
+    co = (r - b) % 32
+    t = (b + co // 2) % 32
+    cg = (g - t) % 32
+    y = (t + cg // 2) % 32
+    if variant == VAR1:
+        o = (y << 11) | (co << 6) | (gl << 5) | cg
+    elif variant == VAR2:
+        o = (gl << 15) | (y << 10) | (co << 5) | cg
+    elif variant == VAR3:
+        o = (y << 11) | (co << 6) | (cg << 1) | gl
+    else:
+        raise ValueError(variant)
+    return o.astype(np.uint16)
+
+
+def recorrelate(c: np.ndarray, variant: int) -> np.ndarray:
+    if variant == NONE:
+        return c.astype(np.uint16)
+    v = c.astype(np.int32)
+    if variant == VAR1:
+        y, co, gl, cg = (v >> 11) & 31, (v >> 6) & 31, (v >> 5) & 1, v & 31
+    elif variant == VAR2:
+        gl, y, co, cg = (v >> 15) & 1, (v >> 10) & 31, (v >> 5) & 31, v & 31
+    elif variant == VAR3:
+        y, co, cg, gl = (v >> 11) & 31, (v >> 6) & 31, (v >> 1) & 31, v & 1
+    else:
+        raise ValueError(variant)
+    t = (y - cg // 2) % 32
+    g = (cg + t) % 32
+    b = (t - co // 2) % 32
+    r = (b + co) % 32
+    return ((r << 11) | (g << 6) | (gl << 5) | b).astype(np.uint16)
+
+
+def _u8(x) -> np.ndarray:
+    a = np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray, memoryview)) else np.asarray(x)
+    assert a.dtype == np.uint8 and a.ndim == 1
+    return np.ascontiguousarray(a)
+
+
+def _colour_section(c0: np.ndarray, c1: np.ndarray, split: bool) -> np.ndarray:
+    if split:
+        return np.concatenate([c0.astype("<u2").view(np.uint8), c1.astype("<u2").view(np.uint8)])
+    pairs = np.empty((c0.size, 2), dtype="<u2")
+    pairs[:, 0], pairs[:, 1] = c0, c1
+    return pairs.reshape(-1).view(np.uint8)
+
+
+def _colour_unsection(sec: np.ndarray, n: int, split: bool):
+    w = sec.view("<u2")
+    if split:
+        return w[:n].copy(), w[n:].copy()
+    p = w.reshape(n, 2)
+    return p[:, 0].copy(), p[:, 1].copy()
+
+
+def transform_bc1(data, variant=VAR1, split_colour=True) -> np.ndarray:
+    blk = _u8(data).view(BC1)
+    c0, c1 = decorrelate(blk["c0"], variant), decorrelate(blk["c1"], variant)
+    return np.concatenate([_colour_section(c0, c1, split_colour), blk["idx"].astype("<u4").view(np.uint8)])
+
+
+def untransform_bc1(data, variant=VAR1, split_colour=True) -> np.ndarray:
+    a = _u8(data)
+    n = a.size // 8
+    out = np.empty(n, dtype=BC1)
+    c0, c1 = _colour_unsection(a[: 4 * n], n, split_colour)
+    out["c0"], out["c1"] = recorrelate(c0, variant), recorrelate(c1, variant)
+    out["idx"] = a[4 * n:].view("<u4")
+    return out.view(np.uint8)
+
+
+def transform_bc2(data, variant=VAR1, split_colour=True) -> np.ndarray:
+    blk = _u8(data).view(BC2)
+    c0, c1 = decorrelate(blk["c0"], variant), decorrelate(blk["c1"], variant)
+    return np.concatenate([
+        blk["alpha"].astype("<u8").view(np.uint8),
+        _colour_section(c0, c1, split_colour),
+        blk["idx"].astype("<u4").view(np.uint8),
+    ])
+
+
+def untransform_bc2(data, variant=VAR1, split_colour=True) -> np.ndarray:
+    a = _u8(data)
+    n = a.size // 16
+    out = np.empty(n, dtype=BC2)
+    out["alpha"] = a[: 8 * n].view("<u8")
+    c0, c1 = _colour_unsection(a[8 * n: 12 * n], n, split_colour)
+    out["c0"], out["c1"] = recorrelate(c0, variant), recorrelate(c1, variant)
+    out["idx"] = a[12 * n:].view("<u4")
+    return out.view(np.uint8)
+
+
+def transform_bc3(data, variant=VAR1, split_alpha=True, split_colour=True) -> np.ndarray:
+    blk = _u8(data).view(BC3)
+    if split_alpha:
+        alpha = np.concatenate([blk["a0"], blk["a1"]])
+    else:
+        alpha = np.stack([blk["a0"], blk["a1"]], axis=1).reshape(-1)
+    c0, c1 = decorrelate(blk["c0"], variant), decorrelate(blk["c1"], variant)
+    return np.concatenate([
+        np.ascontiguousarray(alpha),
+        np.ascontiguousarray(blk["aidx"]).reshape(-1),
+        _colour_section(c0, c1, split_colour),
+        blk["idx"].astype("<u4").view(np.uint8),
+    ])
+
+
+def untransform_bc3(data, variant=VAR1, split_alpha=True, split_colour=True) -> np.ndarray:
+    a = _u8(data)
+    n = a.size // 16
+    out = np.empty(n, dtype=BC3)
+    if split_alpha:
+        out["a0"], out["a1"] = a[:n], a[n: 2 * n]
+    else:
+        p = a[: 2 * n].reshape(n, 2)
+        out["a0"], out["a1"] = p[:, 0], p[:, 1]
+    out["aidx"] = a[2 * n: 8 * n].reshape(n, 6)
+    c0, c1 = _colour_unsection(a[8 * n: 12 * n], n, split_colour)
+    out["c0"], out["c1"] = recorrelate(c0, variant), recorrelate(c1, variant)
+    out["idx"] = a[12 * n:].view("<u4")
+    return out.view(np.uint8)
+
+
+def transform(fmt: str, data, variant=VAR1, split_colour=True, split_alpha=True, inverse=False) -> np.ndarray:
+    if fmt == "bc1":
+        return (untransform_bc1 if inverse else transform_bc1)(data, variant, split_colour)
+    if fmt == "bc2":
+        return (untransform_bc2 if inverse else transform_bc2)(data, variant, split_colour)
+    if fmt == "bc3":
+        return (untransform_bc3 if inverse else transform_bc3)(data, variant, split_alpha, split_colour)
+    raise ValueError(fmt)
+
+
+def splitmix64(seed: int, first_qword: int, count: int) -> np.ndarray:
+    """qword i = mix(seed + (first_qword + i + 1) * GOLDEN) -- same stream as oracle_fill_splitmix64."""
+    m = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        idx = np.arange(first_qword + 1, first_qword + 1 + count, dtype=np.uint64)
+        z = (np.uint64(seed & int(m)) + idx * np.uint64(0x9E3779B97F4A7C15)) & m
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & m
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & m
+        return z ^ (z >> np.uint64(31))

@@ -1,0 +1,103 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every symbol the headers declare, and
+its argument validation (which runs before any device work) behaves like the reference's."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"\b((?:dxtlt|dltbc\d(?:core)?)_\w+)\s*\(", text):
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_headers_declare_something():
+    syms = declared_symbols()
+    assert "dxtlt_transform_bc1_with_settings" in syms
+    assert len(syms) >= 19
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = C.CDLL(pkg._lib.lib_path())
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+
+
+def test_version_and_last_error(pkg):
+    l = pkg.load()
+    assert l.dxtlt_version().decode().startswith("dxtlt-gfx950")
+    assert isinstance(pkg._lib.last_error(), str)
+
+
+def test_validation_precedes_device_work(pkg):
+    """Length / argument errors are reported without touching a device (so they work on a CPU-only box)."""
+    l = pkg.load()
+    buf = np.zeros(64, dtype=np.uint8)
+    out = np.zeros(64, dtype=np.uint8)
+    assert l.dxtlt_transform_bc1_with_settings(buf.ctypes.data, out.ctypes.data, 12, 1, True) == 1  # INVALID_LENGTH
+    assert l.dxtlt_transform_bc3_with_settings(buf.ctypes.data, out.ctypes.data, 24, 1, True, True) == 1
+    assert l.dxtlt_transform_bc1_with_settings(buf.ctypes.data, out.ctypes.data, 16, 9, True) == 2  # bad mode
+    assert l.dxtlt_transform_bc1_with_settings(None, out.ctypes.data, 16, 1, True) == 2  # NULL
+    assert "dxtlt" in pkg._lib.last_error()
+    # zero blocks is a no-op and needs no device
+    assert l.dxtlt_transform_bc2_with_settings(buf.ctypes.data, out.ctypes.data, 0, 1, True) == 0
+    assert l.dxtlt_transform_range_device(1, False, None, None, 10, 8, 4, 1, False, True, None) == 2  # bad range
+
+
+def test_python_wrapper_validation(pkg):
+    x = np.zeros(24, dtype=np.uint8)
+    with pytest.raises(pkg.InvalidLength):
+        pkg.transform_bc1_with_settings(x[:12], np.zeros(12, dtype=np.uint8))
+    with pytest.raises(pkg.OutputBufferTooSmall) as e:
+        pkg.transform_bc1_with_settings(x, np.zeros(16, dtype=np.uint8))
+    assert (e.value.needed, e.value.actual) == (24, 16)
+    # length is checked before size (bc1 safe/transform_with_settings.rs:93-105)
+    with pytest.raises(pkg.InvalidLength):
+        pkg.transform_bc3_with_settings(x, np.zeros(1, dtype=np.uint8))
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    """On a box without a GPU a real transform must fail loudly, never silently compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    x = np.zeros(16, dtype=np.uint8)
+    with pytest.raises(pkg.DeviceError) as e:
+        pkg.transform_bc1_with_settings(x, np.zeros(16, dtype=np.uint8))
+    assert e.value.code in (3, 4)
+
+
+def test_settings_defaults_and_combinations(pkg):
+    # bc1 settings.rs:35-43, bc3 settings.rs:39-48
+    assert pkg.Bc1TransformSettings() == pkg.Bc1TransformSettings(pkg.YCoCgVariant.Variant1, True)
+    assert pkg.Bc3TransformSettings() == pkg.Bc3TransformSettings(pkg.YCoCgVariant.Variant1, True, True)
+    assert len(set(pkg.Bc1TransformSettings.all_combinations())) == 8
+    assert len(set(pkg.Bc2TransformSettings.all_combinations())) == 8
+    assert len(set(pkg.Bc3TransformSettings.all_combinations())) == 16
+    assert [int(v) for v in pkg.YCoCgVariant] == [0, 1, 2, 3]
+
+
+def test_stream_table_and_shard_plan(pkg):
+    assert pkg.stream_table("bc1", pkg.Bc1TransformSettings()) == [(0, 2), (2, 2), (4, 4)]
+    assert pkg.stream_table("bc1", pkg.Bc1TransformSettings(pkg.YCoCgVariant.NONE, False)) == [(0, 4), (4, 4)]
+    assert pkg.stream_table("bc2", pkg.Bc2TransformSettings()) == [(0, 8), (8, 2), (10, 2), (12, 4)]
+    assert pkg.stream_table("bc3", pkg.Bc3TransformSettings()) == [(0, 1), (1, 1), (2, 6), (8, 2), (10, 2), (12, 4)]
+    assert pkg.stream_table("bc3", pkg.Bc3TransformSettings(pkg.YCoCgVariant.NONE, False, False)) == \
+        [(0, 2), (2, 6), (8, 4), (12, 4)]
+    plan = pkg.plan_shards(10_000_019, 8)
+    assert plan[0][0] == 0 and sum(n for _, n in plan) == 10_000_019
+    assert all(a + n == b for (a, n), (b, _) in zip(plan, plan[1:]))
+    assert all(first % 2048 == 0 for first, _ in plan)
+    assert pkg.plan_shards(5, 8)[-1] == (0, 5)

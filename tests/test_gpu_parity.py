@@ -1,0 +1,317 @@
+"""Parity of the HIP path (through the C ABI of libdxtlt_gfx950.so) against the CPU oracle.  Needs an MI355X.
+
+Bar: bit-exact.  Small and medium sizes are compared byte-for-byte with the oracle and with the committed golden
+fixtures; BASELINE.json's full sizes (8 GiB BC1 / BC3) use the size-independent properties of the domain: exact
+round trip, exact comparison of sampled block windows (the transform is block-independent, so a window of the
+output streams is a pure function of the same window of blocks), and per-stream 64-bit sums."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import BLOCK, FORMATS, all_settings, golden_digests, golden_vectors, payload, pkg_settings, settings_id
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TILE = {"bc1": 2048, "bc2": 1024, "bc3": 1024}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def run_device(pkg, fmt, x_host, s, dev, inverse=False):
+    x = torch.from_numpy(np.ascontiguousarray(x_host)).to(dev)
+    y = torch.full_like(x, 0xA5)
+    name = ("untransform" if inverse else "transform") + f"_{fmt}_with_settings"
+    getattr(pkg, name)(x, y, pkg_settings(pkg, fmt, s))
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def fwd_oracle(oracle, fmt, x, s, inverse=False):
+    v, sa, sc = s
+    return oracle.transform(fmt, x, v, sc, sa, inverse=inverse)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# every settings combination x sizes around the tile boundaries (reference: run_*_roundtrip_test for every n
+# in 1..=max_blocks with max_blocks = 2 x kernel width, bc1 test_prelude.rs:154-317)
+# ------------------------------------------------------------------------------------------------------------
+def sizes_for(fmt):
+    t = TILE[fmt]
+    return [1, 2, 3, 15, 16, 17, 63, 64, 65, t - 16, t - 1, t, t + 1, t + 16, 2 * t, 2 * t + 1, 3 * t + 16 * 7,
+            5 * t + 37]
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_all_settings_all_sizes(pkg, oracle, dev, fmt):
+    for n in sizes_for(fmt):
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0xC0FFEE00 + n)
+        for s in all_settings(fmt):
+            want = fwd_oracle(oracle, fmt, x, s)
+            got = run_device(pkg, fmt, x, s, dev)
+            assert np.array_equal(got, want), (fmt, n, settings_id(s), "forward")
+            back = run_device(pkg, fmt, want, s, dev, inverse=True)
+            assert np.array_equal(back, x), (fmt, n, settings_id(s), "inverse")
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_every_n_up_to_two_tiles_default_settings(pkg, oracle, dev, fmt):
+    """Every block count 0..=130 (head/exact/tail of the element kernel) plus every n in a window around two
+    tiles; default settings."""
+    s = {"bc1": (1, 0, 1), "bc2": (1, 0, 1), "bc3": (1, 1, 1)}[fmt]
+    t = TILE[fmt]
+    for n in list(range(0, 131)) + list(range(2 * t - 20, 2 * t + 21)):
+        x = oracle.generate_test_data(fmt, n)
+        got = run_device(pkg, fmt, x, s, dev) if n else np.zeros(0, dtype=np.uint8)
+        assert np.array_equal(got, fwd_oracle(oracle, fmt, x, s)), (fmt, n)
+
+
+def test_zero_blocks_is_a_noop(pkg, dev):
+    x = torch.empty(0, dtype=torch.uint8, device=dev)
+    y = torch.empty(0, dtype=torch.uint8, device=dev)
+    pkg.transform_bc1_with_settings(x, y)
+    pkg.untransform_bc3_with_settings(x, y)
+    pkg.transform_bc2_with_settings(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# pointer alignment (reference: run_*_untransform_unaligned_test offsets both pointers by one byte,
+# bc1 test_prelude.rs:364-373)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("shift", [1, 2, 4, 8])
+def test_misaligned_device_pointers(pkg, oracle, dev, fmt, shift):
+    n = 3 * TILE[fmt] + 11
+    x = oracle.fill_splitmix64(n * BLOCK[fmt], 0xA11A + shift)
+    for s in all_settings(fmt):
+        xs = torch.zeros(x.size + shift, dtype=torch.uint8, device=dev)
+        xs[shift:] = torch.from_numpy(x).to(dev)
+        ys = torch.zeros(x.size + shift, dtype=torch.uint8, device=dev)
+        st = pkg_settings(pkg, fmt, s)
+        getattr(pkg, f"transform_{fmt}_with_settings")(xs[shift:], ys[shift:], st)
+        torch.cuda.synchronize()
+        want = fwd_oracle(oracle, fmt, x, s)
+        assert np.array_equal(ys[shift:].cpu().numpy(), want), (fmt, shift, settings_id(s))
+        assert int(ys[:shift].sum()) == 0, "wrote before the output pointer"
+        zs = torch.zeros(x.size + shift, dtype=torch.uint8, device=dev)
+        getattr(pkg, f"untransform_{fmt}_with_settings")(ys[shift:], zs[shift:], st)
+        torch.cuda.synchronize()
+        assert np.array_equal(zs[shift:].cpu().numpy(), x), (fmt, shift, settings_id(s), "inverse")
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_element_kernel_equals_tiled_kernel(pkg, oracle, dev, fmt):
+    n = 4 * TILE[fmt]
+    x = oracle.fill_splitmix64(n * BLOCK[fmt], 0xE1E)
+    for s in all_settings(fmt):
+        tiled = run_device(pkg, fmt, x, s, dev)
+        try:
+            pkg.set_tuning(0, True)
+            generic = run_device(pkg, fmt, x, s, dev)
+            back = run_device(pkg, fmt, generic, s, dev, inverse=True)
+        finally:
+            pkg.set_tuning(0, False)
+        assert np.array_equal(tiled, generic), (fmt, settings_id(s))
+        assert np.array_equal(back, x)
+
+
+def test_no_write_past_the_end(pkg, oracle, dev):
+    """Stream sections are adjacent in one buffer: a wide store of one stream must never spill into the next
+    (SURVEY.md 2, AVX-512 crib) nor past the end of the output."""
+    for fmt in FORMATS:
+        n = 2 * TILE[fmt] + 5
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x5A5A)
+        xd = torch.from_numpy(x).to(dev)
+        yd = torch.full((x.size + 4096,), 0x77, dtype=torch.uint8, device=dev)
+        s = (1, 1, 1)
+        getattr(pkg, f"transform_{fmt}_with_settings")(xd, yd[: x.size], pkg_settings(pkg, fmt, s))
+        torch.cuda.synchronize()
+        assert np.array_equal(yd[: x.size].cpu().numpy(), fwd_oracle(oracle, fmt, x, s))
+        assert bool((yd[x.size:] == 0x77).all())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# committed fixtures through the GPU
+# ------------------------------------------------------------------------------------------------------------
+def test_golden_vectors_on_gpu(pkg, dev):
+    for e in golden_vectors()["vectors"]:
+        x = np.frombuffer(bytes.fromhex(e["input"]), dtype=np.uint8)
+        s = (e["variant"], e["split_alpha"], e["split_colour"])
+        assert run_device(pkg, e["fmt"], x, s, dev).tobytes().hex() == e["output"], e
+        y = np.frombuffer(bytes.fromhex(e["output"]), dtype=np.uint8)
+        assert run_device(pkg, e["fmt"], y, s, dev, inverse=True).tobytes().hex() == e["input"], e
+
+
+def test_golden_digests_on_gpu(pkg, oracle, dev):
+    cache = {}
+    for e in golden_digests():
+        key = (e["fmt"], e["source"], e.get("seed"), e["blocks"])
+        if key not in cache:
+            if e["source"] == "splitmix64":
+                t = torch.empty(e["blocks"] * BLOCK[e["fmt"]], dtype=torch.uint8, device=dev)
+                pkg.fill_splitmix64(t, e["seed"])
+                cache = {key: t}
+            else:
+                cache = {key: torch.from_numpy(payload(e["fmt"])).to(dev)}
+        x = cache[key]
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+        st = pkg_settings(pkg, e["fmt"], (e["variant"], e["split_alpha"], e["split_colour"]))
+        getattr(pkg, f"transform_{e['fmt']}_with_settings")(x, y, st)
+        getattr(pkg, f"untransform_{e['fmt']}_with_settings")(y, z, st)
+        torch.cuda.synchronize()
+        assert hashlib.sha256(x.cpu().numpy()).hexdigest() == e["input_sha256"], "fill kernel differs"
+        assert hashlib.sha256(y.cpu().numpy()).hexdigest() == e["output_sha256"], e
+        assert torch.equal(z, x)
+
+
+def test_fill_kernel_matches_oracle_fill(pkg, oracle, dev):
+    for nbytes, first in ((8 * 1000, 0), (8 * 1000 + 5, 17), (3, 2), (1 << 20, 1 << 33)):
+        t = torch.zeros(nbytes + 8, dtype=torch.uint8, device=dev)
+        pkg.fill_splitmix64(t[:nbytes], 0x0BC10002, first)
+        torch.cuda.synchronize()
+        assert np.array_equal(t[:nbytes].cpu().numpy(), oracle.fill_splitmix64(nbytes, 0x0BC10002, first))
+        assert int(t[nbytes:].sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# block ranges (multi-GPU shards / chunked staging) and the host-pointer entry points
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_range_calls_compose_to_the_whole_buffer(pkg, oracle, dev, fmt):
+    total = 7 * TILE[fmt] + 16 * 3 + 5
+    x = oracle.fill_splitmix64(total * BLOCK[fmt], 0x5AAD)
+    xd = torch.from_numpy(x).to(dev)
+    cuts = [0, 2 * TILE[fmt], 2 * TILE[fmt] + 16, 5 * TILE[fmt] + 7, total]  # aligned and unaligned shard starts
+    for s in [(1, 1, 1), (0, 0, 0), (2, 1, 0), (3, 0, 1)]:
+        st = pkg_settings(pkg, fmt, s)
+        yd = torch.zeros_like(xd)
+        for a, b in zip(cuts, cuts[1:]):
+            pkg.transform_range(fmt, False, xd[a * BLOCK[fmt]:], yd, total, a, b - a, st)
+        torch.cuda.synchronize()
+        want = fwd_oracle(oracle, fmt, x, s)
+        assert np.array_equal(yd.cpu().numpy(), want), (fmt, settings_id(s))
+        zd = torch.zeros_like(xd)
+        for a, b in zip(cuts, cuts[1:]):
+            pkg.transform_range(fmt, True, yd, zd[a * BLOCK[fmt]:], total, a, b - a, st)
+        torch.cuda.synchronize()
+        assert torch.equal(zd, xd)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_host_pointer_entry_points(pkg, oracle, dev, fmt):
+    for n in (1, 37, TILE[fmt] * 3 + 9):
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x4057 + n)
+        for s in all_settings(fmt):
+            st = pkg_settings(pkg, fmt, s)
+            # +1-byte offset views: the reference's unaligned tests
+            src = np.zeros(x.size + 1, dtype=np.uint8)
+            src[1:] = x
+            dst = np.zeros(x.size + 1, dtype=np.uint8)
+            getattr(pkg, f"transform_{fmt}_with_settings")(src[1:], dst[1:], st)
+            want = fwd_oracle(oracle, fmt, x, s)
+            assert np.array_equal(dst[1:], want) and dst[0] == 0
+            back = np.zeros_like(x)
+            getattr(pkg, f"untransform_{fmt}_with_settings")(dst[1:], back, st)
+            assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
+    n = 9 * 2048 + 123
+    x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x5AAD0 + n)
+    s = (1, 1, 1)
+    st = pkg_settings(pkg, fmt, s)
+    y = np.zeros_like(x)
+    pkg.transform_sharded(fmt, False, x, y, st, 0)
+    assert np.array_equal(y, fwd_oracle(oracle, fmt, x, s))
+    z = np.zeros_like(x)
+    pkg.transform_sharded(fmt, True, y, z, st, 0)
+    assert np.array_equal(z, x)
+
+
+def test_real_textures(pkg, oracle, dev):
+    """assets/tests/r2-256-bc{1,2,3}.dds payloads: every settings combination, forward bytes and round trip
+    (reference: debug_bcN roundtrip commands)."""
+    for fmt in FORMATS:
+        p = payload(fmt)
+        for s in all_settings(fmt):
+            got = run_device(pkg, fmt, p, s, dev)
+            assert np.array_equal(got, fwd_oracle(oracle, fmt, p, s)), (fmt, settings_id(s))
+            assert np.array_equal(run_device(pkg, fmt, got, s, dev, inverse=True), p)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# medium size: exact against the oracle, whole buffer
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_one_gib_exact(pkg, oracle, dev, fmt):
+    nbytes = 1 << 30
+    s = (1, 1, 1)
+    st = pkg_settings(pkg, fmt, s)
+    x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, 0x0BC10002)
+    y = torch.empty_like(x)
+    getattr(pkg, f"transform_{fmt}_with_settings")(x, y, st)
+    torch.cuda.synchronize()
+    host_x = oracle.fill_splitmix64(nbytes, 0x0BC10002)
+    want = np.empty_like(host_x)
+    oracle.run_mt(fmt, host_x, want, s[0], bool(s[2]), bool(s[1]), False, 8)
+    assert np.array_equal(y.cpu().numpy(), want)
+    z = torch.empty_like(x)
+    getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, st)
+    torch.cuda.synchronize()
+    assert torch.equal(z, x)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: configs[1] (BC1, 8 GiB) and configs[2] (BC3, 8 GiB)
+# ------------------------------------------------------------------------------------------------------------
+def _window_check(pkg, oracle, fmt, s, x, y, total_blocks, first, count):
+    """Exact check of blocks [first, first+count): gather the window's slice of every stream from the device
+    output and compare with the oracle run on the window alone."""
+    B = BLOCK[fmt]
+    st = pkg_settings(pkg, fmt, s)
+    xin = x[first * B:(first + count) * B].cpu().numpy()
+    want = fwd_oracle(oracle, fmt, xin, s)
+    got = np.empty_like(want)
+    for off, w in pkg.stream_table(fmt, st):
+        sl = y[off * total_blocks + w * first: off * total_blocks + w * (first + count)].cpu().numpy()
+        got[off * count: off * count + w * count] = sl
+    assert np.array_equal(got, want), (fmt, first, count)
+
+
+@pytest.mark.parametrize("fmt,seed", [("bc1", 0x0BC10002), ("bc3", 0x0BC30003)])
+def test_eight_gib_properties(pkg, oracle, dev, fmt, seed):
+    nbytes = 8 << 30
+    B = BLOCK[fmt]
+    total = nbytes // B
+    s = (1, 1, 1)
+    st = pkg_settings(pkg, fmt, s)
+    x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, seed)
+    y = torch.empty_like(x)
+    getattr(pkg, f"transform_{fmt}_with_settings")(x, y, st)
+    torch.cuda.synchronize()
+    # sampled windows, including both ends and a 2^32-byte-offset crossing
+    win = 64 * 1024
+    firsts = [0, total - win, (1 << 32) // B - win // 2, total // 2 + 12345, total // 3, 7 * (total // 8) + 1]
+    for f in firsts:
+        _window_check(pkg, oracle, fmt, s, x, y, total, f, win)
+    # index streams are copied verbatim: their 64-bit sum equals the sum of the index fields of the input
+    xi = x.view(torch.int32).view(-1, B // 4)
+    idx_sum_in = int(xi[:, -1].to(torch.int64).sum())
+    idx_sum_out = int(y[(B - 4) * total:].view(torch.int32).to(torch.int64).sum())
+    assert idx_sum_in == idx_sum_out
+    del xi
+    # exact round trip at full size
+    z = torch.empty_like(x)
+    getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, st)
+    torch.cuda.synchronize()
+    assert torch.equal(z, x)
