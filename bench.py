@@ -42,7 +42,7 @@ def parse_args():
     p.add_argument("--format", default="bc1", choices=["bc1", "bc2", "bc3"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
-    p.add_argument("--wgs-per-cu", type=int, default=0, help="tuning experiment: persistent grid = CUs * this")
+    p.add_argument("--tile-threads", type=int, default=0, help="tuning experiment: tile workgroup size 256 (default) or 512")
     return p.parse_args()
 
 
@@ -102,8 +102,8 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     pkg.load()
-    if args.wgs_per_cu:
-        pkg.set_tuning(args.wgs_per_cu, False)
+    if args.tile_threads:
+        pkg.set_tuning(args.tile_threads, False)
     fmt = args.format
     block = pkg.BLOCK_BYTES[fmt]
     settings = {"bc1": pkg.Bc1TransformSettings(), "bc2": pkg.Bc2TransformSettings(),

@@ -128,8 +128,8 @@ def load():
     return _lib.load()
 
 
-def set_tuning(wgs_per_cu: int = 0, force_generic: bool = False) -> None:
-    load().dxtlt_set_tuning(int(wgs_per_cu), int(bool(force_generic)))
+def set_tuning(tile_threads: int = 0, force_generic: bool = False) -> None:
+    load().dxtlt_set_tuning(int(tile_threads), int(bool(force_generic)))
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -10,19 +10,22 @@
 //
 // How it is mapped to the machine (this is NOT how the reference does it; the reference is x86 SIMD):
 //   * HBM-bound byte shuffling: 2 bytes of traffic per byte of input, ~20 integer ops per colour pair.
-//     No MFMA.  The only thing that matters is that every HBM access is a full-width, fully coalesced
-//     16 B/lane vector access and that enough of them are in flight.
-//   * One 256-thread workgroup owns a contiguous 16 KiB tile of blocks (2048 BC1 / 1024 BC2,BC3 blocks).
-//     Forward: 4 x global_load_dwordx4 per lane (1 KiB contiguous per wave-instruction) -> YCoCg-R in
-//     registers -> each field is written to its place in an LDS image that is laid out exactly like the
-//     output (stream after stream) -> barrier -> the image is read back linearly with ds_read_b128 and
-//     every stream slice leaves with global_store_dwordx4, again 1 KiB contiguous per wave-instruction.
-//     Inverse: the mirror (linear 16-B stream loads -> LDS image -> per-block gather -> AoS dwordx4 stores).
-//   * Stream slices of a tile are multiples of 1 KiB, so one wave-instruction never straddles two
-//     streams and the stream of a store is wave-uniform (selected on SGPRs).
-//   * Persistent grid (CUs x 8 workgroups), grid-stride over tiles; the next tile's loads are issued
-//     before the current tile's store phase so HBM reads stay in flight across the barrier.
-//   * Non-temporal loads/stores: every byte is touched exactly once.
+//     No MFMA.  What matters is that every HBM access is a full-width, fully coalesced 16 B/lane vector
+//     access and that the memory system always has many independent workgroups to pull from.
+//   * One workgroup owns ONE contiguous tile of blocks: THREADS x 16 bytes (256 threads: 4 KiB = 512 BC1 or
+//     256 BC2/BC3 blocks).  Forward: one global_load_dwordx4 per lane (1 KiB contiguous per wave
+//     instruction) -> YCoCg-R in registers -> each field is written to its place in an LDS image that is
+//     laid out exactly like the output (stream after stream) -> barrier -> the image is read back linearly
+//     with ds_read_b128 and leaves with one global_store_dwordx4 per lane; every stream slice of the tile
+//     is a contiguous run of >= 256 bytes.  Inverse: the mirror (linear 16-B stream loads -> LDS image ->
+//     per-block gather + inverse YCoCg-R -> AoS dwordx4 store).
+//   * One tile per workgroup, grid = number of tiles (2^21 workgroups for 8 GiB).  Measured on MI355X
+//     (profiles/r01_b_*, r01_c_*): a persistent grid-stride loop with 4 vectors per lane and software
+//     prefetch reached 0.58-0.60 of the 8 TB/s peak, the same structure as one small tile per workgroup
+//     0.79-0.80, against 0.81-0.83 for a plain dwordx4 copy launched the same way.  The hardware
+//     dispatcher is the better scheduler for a pure stream: short-lived workgroups de-synchronise reads
+//     and writes and keep every channel busy.
+//   * Non-temporal loads/stores (every byte is touched exactly once): +2-3 % over default policy.
 //   * 64-bit block indices and byte offsets everywhere (8 GiB of BC1 = 2^30 blocks).
 //   * Anything the tiled path cannot take (tail blocks, stream bases or pointers that are not 16-byte
 //     aligned) goes to an element-granular kernel: one lane per block, natural-width or byte accesses.
@@ -36,9 +39,7 @@ namespace dxtlt {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kThreads = 256;        // 4 waves
-constexpr int kTileBytes = 16384;    // LDS image == one tile of input == one tile of output
-constexpr int kVecs = kTileBytes / 16 / kThreads;  // 16-byte vectors per lane per tile (4)
+constexpr int kThreads = 256;        // element-granular / fill kernels; default tile workgroup (4 waves)
 
 #ifndef DXTLT_NONTEMPORAL
 #define DXTLT_NONTEMPORAL 1
@@ -63,22 +64,23 @@ __device__ __forceinline__ void gstore16(void* p, u32x4 v)
 }
 
 __host__ __device__ constexpr int fmt_block(int fmt) { return fmt == kBc1 ? 8 : 16; }
-__host__ __device__ constexpr int fmt_tile_blocks(int fmt) { return kTileBytes / fmt_block(fmt); }
+// one 16-byte vector per lane: a THREADS-wide workgroup owns THREADS*16 bytes of blocks
+__host__ __device__ constexpr int tile_blocks(int fmt, int threads) { return threads * 16 / fmt_block(fmt); }
 
-// Byte offset, inside the whole transformed buffer, of the 1 KiB LDS-image chunk that starts at image
-// byte `chunk_byte` (wave-uniform), for the tile whose first block is `blk0` (global block index).
-template <int FMT, bool SA, bool SC>
-__device__ __forceinline__ uint64_t soa_offset_of_chunk(int chunk_byte, uint64_t total_blocks, uint64_t blk0)
+// Byte offset, inside the whole transformed buffer, of LDS-image byte `o` (a lane's 16-byte segment) for
+// the tile whose first block is `blk0` (global block index).  Stream boundaries inside the image are
+// multiples of 256 bytes, so a 16-byte segment never straddles two streams.
+template <int FMT, bool SA, bool SC, int T>
+__device__ __forceinline__ uint64_t soa_offset_of_image_byte(int o, uint64_t total_blocks, uint64_t blk0)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = fmt_tile_blocks(FMT);
     uint64_t r = 0;
 #pragma unroll
     for (int s = 0; s < S.n; ++s) {
         const int lo = S.off[s] * T;
         const int hi = lo + S.width[s] * T;
-        if (chunk_byte >= lo && chunk_byte < hi)
-            r = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 + (uint64_t)(chunk_byte - lo);
+        if (o >= lo && o < hi)
+            r = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 + (uint64_t)(o - lo);
     }
     return r;
 }
@@ -93,10 +95,9 @@ __device__ __forceinline__ T& lds_at(uint8_t* lds, int byte_off)
     return *reinterpret_cast<T*>(lds + byte_off);
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int T>
 __device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
 {
-    constexpr int T = fmt_tile_blocks(FMT);
     if constexpr (FMT == kBc1) {
         // q = { colours A, indices A, colours B, indices B }
         const uint32_t ca = decorrelate2<VARIANT>(q.x);
@@ -142,10 +143,9 @@ __device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
     }
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int T>
 __device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
 {
-    constexpr int T = fmt_tile_blocks(FMT);
     u32x4 q;
     if constexpr (FMT == kBc1) {
         uint32_t ca, cb;
@@ -198,111 +198,42 @@ __device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled kernels.  `aos` points at the range's first block, `soa` at byte 0 of the whole transformed
-// buffer.  Preconditions (checked on the host): both pointers 16-byte aligned; every stream base
-// off*total_blocks + width*first_block is a multiple of 16; the range starts with `num_tiles` full tiles.
+// Tiled kernels: one tile per workgroup.  `aos` points at the range's first block, `soa` at byte 0 of the
+// whole transformed buffer.  Preconditions (checked on the host): both pointers 16-byte aligned; every
+// stream base off*total_blocks + width*first_block is a multiple of 16; gridDim.x == number of FULL tiles
+// at the start of the range.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int VARIANT, bool SA, bool SC>
-__global__ void __launch_bounds__(kThreads)
-fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks,
-          uint64_t first_block, uint64_t num_tiles)
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kTileBytes];
-    constexpr int T = fmt_tile_blocks(FMT);
+    constexpr int T = tile_blocks(FMT, THREADS);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
     const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lane = t & 63;
+    const uint64_t tile = blockIdx.x;
 
-    uint64_t tile = blockIdx.x;
-    if (tile >= num_tiles)
-        return;
-
-    u32x4 q[kVecs];
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j)
-        q[j] = gload16(aos + tile * kTileBytes + (uint64_t)(t + kThreads * j) * 16);
-
-    for (;;) {
-#pragma unroll
-        for (int j = 0; j < kVecs; ++j)
-            scatter_to_image<FMT, VARIANT, SA, SC>(lds, t + kThreads * j, q[j]);
-        __syncthreads();
-
-        const uint64_t next = tile + gridDim.x;
-        const bool has_next = next < num_tiles;
-        if (has_next) {
-#pragma unroll
-            for (int j = 0; j < kVecs; ++j)
-                q[j] = gload16(aos + next * kTileBytes + (uint64_t)(t + kThreads * j) * 16);
-        }
-
-        const uint64_t blk0 = first_block + tile * T;
-#pragma unroll
-        for (int k = 0; k < kVecs; ++k) {
-            const int chunk_byte = (wave + 4 * k) * 1024;  // SGPR
-            const u32x4 v = lds_at<u32x4>(lds, chunk_byte + lane * 16);
-            const uint64_t o = soa_offset_of_chunk<FMT, SA, SC>(chunk_byte, total_blocks, blk0);
-            gstore16(soa + o + lane * 16, v);
-        }
-        if (!has_next)
-            break;
-        __syncthreads();
-        tile = next;
-    }
+    const u32x4 q = gload16(aos + tile * (THREADS * 16) + t * 16);
+    scatter_to_image<FMT, VARIANT, SA, SC, T>(lds, t, q);
+    __syncthreads();
+    const u32x4 v = lds_at<u32x4>(lds, t * 16);
+    const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
+    gstore16(soa + o, v);
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
-__global__ void __launch_bounds__(kThreads)
-inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks,
-          uint64_t first_block, uint64_t num_tiles)
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kTileBytes];
-    constexpr int T = fmt_tile_blocks(FMT);
+    constexpr int T = tile_blocks(FMT, THREADS);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
     const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lane = t & 63;
+    const uint64_t tile = blockIdx.x;
 
-    uint64_t tile = blockIdx.x;
-    if (tile >= num_tiles)
-        return;
-
-    u32x4 v[kVecs];
-#pragma unroll
-    for (int k = 0; k < kVecs; ++k) {
-        const int chunk_byte = (wave + 4 * k) * 1024;
-        const uint64_t o = soa_offset_of_chunk<FMT, SA, SC>(chunk_byte, total_blocks, first_block + tile * T);
-        v[k] = gload16(soa + o + lane * 16);
-    }
-
-    for (;;) {
-#pragma unroll
-        for (int k = 0; k < kVecs; ++k)
-            lds_at<u32x4>(lds, (wave + 4 * k) * 1024 + lane * 16) = v[k];
-        __syncthreads();
-
-        const uint64_t next = tile + gridDim.x;
-        const bool has_next = next < num_tiles;
-        if (has_next) {
-#pragma unroll
-            for (int k = 0; k < kVecs; ++k) {
-                const int chunk_byte = (wave + 4 * k) * 1024;
-                const uint64_t o =
-                    soa_offset_of_chunk<FMT, SA, SC>(chunk_byte, total_blocks, first_block + next * T);
-                v[k] = gload16(soa + o + lane * 16);
-            }
-        }
-
-#pragma unroll
-        for (int j = 0; j < kVecs; ++j) {
-            const int u = t + kThreads * j;
-            const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC>(lds, u);
-            gstore16(aos + tile * kTileBytes + (uint64_t)u * 16, q);
-        }
-        if (!has_next)
-            break;
-        __syncthreads();
-        tile = next;
-    }
+    const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
+    lds_at<u32x4>(lds, t * 16) = gload16(soa + o);
+    __syncthreads();
+    const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC, T>(lds, t);
+    gstore16(aos + tile * (THREADS * 16) + t * 16, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,11 +436,12 @@ fill_splitmix64_kernel(uint8_t* __restrict__ dst, uint64_t len_bytes, uint64_t s
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t);
+using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t);
 using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
 
 struct KernelSet {
-    TiledFn tiled;
+    TiledFn tiled256;
+    TiledFn tiled512;
     GenericFn generic;
 };
 
@@ -517,8 +449,10 @@ template <int FMT, int VARIANT, bool SA, bool SC>
 KernelSet kernels_for(bool inverse)
 {
     if (inverse)
-        return {inv_tiled<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, true>};
-    return {fwd_tiled<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, false>};
+        return {inv_tiled<FMT, VARIANT, SA, SC, 256>, inv_tiled<FMT, VARIANT, SA, SC, 512>,
+                generic_kernel<FMT, VARIANT, SA, SC, true>};
+    return {fwd_tiled<FMT, VARIANT, SA, SC, 256>, fwd_tiled<FMT, VARIANT, SA, SC, 512>,
+            generic_kernel<FMT, VARIANT, SA, SC, false>};
 }
 
 template <int FMT, int VARIANT>
@@ -592,15 +526,14 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (tuning && tuning->force_generic)
         tiled_ok = false;
 
-    const uint64_t T = (uint64_t)fmt_tile_blocks(fmt);
+    const int threads = (tuning && tuning->tile_threads == 512) ? 512 : 256;
+    const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
     const uint64_t num_tiles = tiled_ok ? r.num_blocks / T : 0;
     if (num_tiles > 0) {
-        int per_cu = (tuning && tuning->wgs_per_cu > 0) ? tuning->wgs_per_cu : 8;
-        uint64_t grid = (uint64_t)cached_cu_count() * (uint64_t)per_cu;
-        if (grid > num_tiles)
-            grid = num_tiles;
-        hipLaunchKernelGGL(ks.tiled, dim3((unsigned)grid), dim3(kThreads), 0, stream, src8, dst8, r.total_blocks,
-                           r.first_block, num_tiles);
+        if (num_tiles > 0x7FFFFFFFull)
+            return hipErrorInvalidValue;  // > 8 TiB in one call
+        hipLaunchKernelGGL(threads == 512 ? ks.tiled512 : ks.tiled256, dim3((unsigned)num_tiles), dim3(threads), 0,
+                           stream, src8, dst8, r.total_blocks, r.first_block);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;

@@ -24,7 +24,7 @@ struct Range {
 };
 
 struct LaunchTuning {
-    int wgs_per_cu;   // persistent grid = CUs * wgs_per_cu (0 = default)
+    int tile_threads;   // 0/256 = default tile workgroup, 512 = experiment
     int force_generic;  // 1 = always take the element-granular kernel (testing)
 };
 

@@ -21,7 +21,7 @@ using dxtlt::Range;
 using dxtlt::Settings;
 
 thread_local std::string g_last_error;
-std::atomic<int> g_wgs_per_cu{0};
+std::atomic<int> g_tile_threads{0};
 std::atomic<int> g_force_generic{0};
 
 int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess)
@@ -45,7 +45,7 @@ int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess)
 dxtlt::LaunchTuning current_tuning()
 {
     dxtlt::LaunchTuning t;
-    t.wgs_per_cu = g_wgs_per_cu.load(std::memory_order_relaxed);
+    t.tile_threads = g_tile_threads.load(std::memory_order_relaxed);
     t.force_generic = g_force_generic.load(std::memory_order_relaxed);
     return t;
 }
@@ -387,9 +387,9 @@ int32_t dxtlt_device_count(void)
     return count;
 }
 
-void dxtlt_set_tuning(int32_t wgs_per_cu, int32_t force_generic)
+void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 {
-    g_wgs_per_cu.store(wgs_per_cu);
+    g_tile_threads.store(tile_threads);
     g_force_generic.store(force_generic);
 }
 

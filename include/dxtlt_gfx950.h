@@ -119,9 +119,9 @@ int32_t dxtlt_fill_splitmix64_device(void *d_dst, size_t len_bytes, uint64_t see
 const char *dxtlt_last_error(void);
 /* Number of visible HIP devices (0 if the runtime cannot initialise). */
 int32_t dxtlt_device_count(void);
-/* Tuning knobs for experiments (persistent grid size = CUs * wgs_per_cu; force the element-granular
+/* Tuning knobs for experiments (tile workgroup size 256 or 512 threads; force the element-granular
  * kernel).  Process-wide; 0 restores the default. */
-void dxtlt_set_tuning(int32_t wgs_per_cu, int32_t force_generic);
+void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic);
 /* "dxtlt-gfx950 <version>" */
 const char *dxtlt_version(void);
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-TILE = {"bc1": 2048, "bc2": 1024, "bc3": 1024}
+TILE = {"bc1": 512, "bc2": 256, "bc3": 256}  # blocks per 256-thread tile (one 16-byte vector per lane)
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +45,7 @@ def fwd_oracle(oracle, fmt, x, s, inverse=False):
 def sizes_for(fmt):
     t = TILE[fmt]
     return [1, 2, 3, 15, 16, 17, 63, 64, 65, t - 16, t - 1, t, t + 1, t + 16, 2 * t, 2 * t + 1, 3 * t + 16 * 7,
-            5 * t + 37]
+            5 * t + 37, 16 * t, 33 * t + 16]
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
@@ -118,6 +118,22 @@ def test_element_kernel_equals_tiled_kernel(pkg, oracle, dev, fmt):
         finally:
             pkg.set_tuning(0, False)
         assert np.array_equal(tiled, generic), (fmt, settings_id(s))
+        assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_512_thread_tiles_equal_256_thread_tiles(pkg, oracle, dev, fmt):
+    n = 9 * TILE[fmt] + 16 * 3 + 1
+    x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x512)
+    for s in all_settings(fmt):
+        want = fwd_oracle(oracle, fmt, x, s)
+        try:
+            pkg.set_tuning(512, False)
+            got = run_device(pkg, fmt, x, s, dev)
+            back = run_device(pkg, fmt, got, s, dev, inverse=True)
+        finally:
+            pkg.set_tuning(0, False)
+        assert np.array_equal(got, want), (fmt, settings_id(s))
         assert np.array_equal(back, x)
 
 
