@@ -1,0 +1,226 @@
+// auto_transform.cpp -- transform_bcN_auto behind the C ABI: brute-force choice of transform settings with a
+// caller-supplied size estimator.
+//
+// Reference behaviour kept exactly (paths under /root/reference/src/core/):
+//   BC1  dxt-lossless-transform-bc1/src/transform/transform_auto.rs:200-270, test orders settings.rs:81-98
+//   BC2  dxt-lossless-transform-bc2/src/transform/transform_auto.rs:196-,   test orders settings.rs:81-98
+//   BC3  dxt-lossless-transform-bc3/src/transform/transform_auto.rs:196-294, test orders settings.rs:91-121
+//   * one max_compressed_size query up front (len/2 for BC1, len/4 for BC2 and BC3), scratch allocated once;
+//   * candidates are tried in the reference's order; each is a FULL transform followed by the estimator on the
+//     endpoint section(s) only: BC1 [0, len/2); BC2 [len/2, len/2+len/4); BC3 alpha endpoints [0, 2N) plus
+//     colour endpoints [len/2, len/2+4N), sizes added;
+//   * strict `<` against the running best (first best wins), defaults as the initial best;
+//   * if the best candidate was not the last one tried, the data is transformed once more with it.
+//
+// GPU shape: the input is uploaded once; every candidate is one kernel launch on the resident copy (2.6 ms per
+// 8 GiB); only the section(s) the estimator looks at travel back per candidate (half or a quarter of the buffer);
+// the full result is downloaded once at the end.  The estimator itself stays on the CPU behind the callback
+// (zstd ~1 GB/s, LTU ~2.5 GB/s in the reference's own numbers), so it, not the transform, bounds this path.
+#include <cstdlib>
+
+#include "../../include/dxtlt_gfx950.h"
+#include "bcn_launch.h"
+#include "host_common.h"
+
+namespace {
+
+struct Candidate {
+    uint8_t mode;
+    bool split_alpha;
+    bool split_colour;
+};
+
+// bc1/bc2 settings.rs:81-86 and :89-98
+const Candidate kFast12[] = {{0, false, false}, {0, false, true}, {1, false, false}, {1, false, true}};
+const Candidate kAll12[] = {{2, false, false}, {0, false, false}, {0, false, true}, {3, false, false},
+                            {3, false, true},  {2, false, true},  {1, false, false}, {1, false, true}};
+// bc3 settings.rs:91-100 and :104-121  (variant, split_alphas, split_colours)
+const Candidate kFast3[] = {{1, true, false}, {1, true, true},  {0, true, false},  {0, false, true},
+                            {0, true, true},  {1, false, true}, {0, false, false}, {1, false, false}};
+const Candidate kAll3[] = {{2, true, false},  {2, true, true},  {3, true, true},   {3, true, false},
+                           {1, true, false},  {3, false, true}, {1, true, true},   {2, false, true},
+                           {2, false, false}, {3, false, false}, {0, true, false}, {0, false, true},
+                           {0, true, true},   {1, false, true}, {0, false, false}, {1, false, false}};
+
+bool same(const Candidate& a, const Candidate& b)
+{
+    return a.mode == b.mode && a.split_alpha == b.split_alpha && a.split_colour == b.split_colour;
+}
+
+#define HIP_TRY_AUTO(expr, what)                                        \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) {                                         \
+            std::free(scratch);                                         \
+            return dxtlt_host::fail(dxtlt_host::kDevice, what, e_);     \
+        }                                                               \
+    } while (0)
+
+}  // namespace
+
+int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* out, size_t len,
+                                   const DltSizeEstimator* est, bool use_all, AutoChoice* choice)
+{
+    if (format < 1 || format > 3)
+        return fail(kInvalidArgument, "format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
+    const size_t block = format == 1 ? 8 : 16;
+    if (len % block != 0)
+        return fail(kInvalidLength, "len is not a multiple of the block size");
+    if (est == nullptr || est->MaxCompressedSize == nullptr || est->EstimateCompressedSize == nullptr || choice == nullptr)
+        return fail(kInvalidArgument, "NULL estimator / choice");
+    if (len > 0 && (in == nullptr || out == nullptr))
+        return fail(kInvalidArgument, "NULL buffer with len > 0");
+
+    const uint64_t blocks = len / block;
+    // defaults: Bc1/Bc2 {Variant1, split}, Bc3 {Variant1, split alphas, split colours}
+    Candidate best{1, format == 3, true};
+    Candidate last = best;
+    size_t best_size = SIZE_MAX;
+    choice->estimator_error = 0;
+
+    // the section(s) the estimator sees
+    const size_t colour_off = format == 1 ? 0 : len / 2;
+    const size_t colour_len = format == 1 ? len / 2 : len / 4;
+    const size_t alpha_len = format == 3 ? (size_t)blocks * 2 : 0;
+
+    size_t max_comp = 0;
+    uint32_t rc_est = est->MaxCompressedSize(est->Context, format == 1 ? len / 2 : len / 4, &max_comp);
+    if (rc_est != 0) {
+        choice->estimator_error = rc_est;
+        return fail(kEstimator, "size estimator: max_compressed_size failed");
+    }
+    uint8_t* scratch = nullptr;
+    if (max_comp != 0) {
+        scratch = static_cast<uint8_t*>(std::aligned_alloc(64, (max_comp + 63) / 64 * 64));
+        if (scratch == nullptr)
+            return fail(kAllocation, "estimator scratch allocation failed");
+    }
+
+    void *d_in = nullptr, *d_out = nullptr;
+    hipStream_t st = nullptr;
+    if (len > 0) {
+        int32_t rc = acquire_staging(len, &d_in, &d_out, &st);
+        if (rc != kOk) {
+            std::free(scratch);
+            return rc;
+        }
+        HIP_TRY_AUTO(hipMemcpyAsync(d_in, in, len, hipMemcpyHostToDevice, st), "H2D copy");
+    }
+
+    const Candidate* order;
+    int count;
+    if (format == 3) {
+        order = use_all ? kAll3 : kFast3;
+        count = use_all ? 16 : 8;
+    } else {
+        order = use_all ? kAll12 : kFast12;
+        count = use_all ? 8 : 4;
+    }
+
+    for (int i = 0; i < count; ++i) {
+        const Candidate c = order[i];
+        if (len > 0) {
+            int32_t rc = enqueue(format, false, d_in, d_out, blocks, c.mode, c.split_alpha, c.split_colour, st);
+            if (rc != kOk) {
+                std::free(scratch);
+                return rc;
+            }
+            if (alpha_len)
+                HIP_TRY_AUTO(hipMemcpyAsync(out, d_out, alpha_len, hipMemcpyDeviceToHost, st), "D2H alpha endpoints");
+            HIP_TRY_AUTO(hipMemcpyAsync(out + colour_off, (const uint8_t*)d_out + colour_off, colour_len,
+                                        hipMemcpyDeviceToHost, st),
+                         "D2H colour endpoints");
+            HIP_TRY_AUTO(hipStreamSynchronize(st), "stream synchronize");
+        }
+        last = c;
+
+        size_t total = 0, part = 0;
+        if (format == 3) {
+            rc_est = est->EstimateCompressedSize(est->Context, out, alpha_len, scratch, max_comp, &part);
+            if (rc_est == 0) {
+                total = part;
+                part = 0;
+                rc_est = est->EstimateCompressedSize(est->Context, out + colour_off, colour_len, scratch, max_comp, &part);
+                total += part;
+            }
+        } else {
+            rc_est = est->EstimateCompressedSize(est->Context, out + colour_off, colour_len, scratch, max_comp, &total);
+        }
+        if (rc_est != 0) {
+            std::free(scratch);
+            choice->estimator_error = rc_est;
+            return fail(kEstimator, "size estimator: estimate_compressed_size failed");
+        }
+        if (total < best_size) {
+            best_size = total;
+            best = c;
+        }
+    }
+
+    if (len > 0) {
+        if (!same(best, last)) {
+            int32_t rc = enqueue(format, false, d_in, d_out, blocks, best.mode, best.split_alpha, best.split_colour, st);
+            if (rc != kOk) {
+                std::free(scratch);
+                return rc;
+            }
+        }
+        HIP_TRY_AUTO(hipMemcpyAsync(out, d_out, len, hipMemcpyDeviceToHost, st), "D2H result");
+        HIP_TRY_AUTO(hipStreamSynchronize(st), "stream synchronize");
+    }
+    std::free(scratch);
+    choice->mode = best.mode;
+    choice->split_alpha = best.split_alpha;
+    choice->split_colour = best.split_colour;
+    return kOk;
+}
+
+extern "C" {
+
+int32_t dxtlt_transform_bc1_auto(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len,
+                                 const DltSizeEstimator* estimator, bool use_all_decorrelation_modes,
+                                 uint8_t* out_decorrelation_mode, bool* out_split_colour_endpoints,
+                                 uint32_t* out_estimator_error)
+{
+    dxtlt_host::AutoChoice c{};
+    int32_t rc = dxtlt_host::transform_auto(1, input_ptr, output_ptr, len, estimator, use_all_decorrelation_modes, &c);
+    if (out_estimator_error) *out_estimator_error = c.estimator_error;
+    if (rc == DXTLT_OK) {
+        if (out_decorrelation_mode) *out_decorrelation_mode = c.mode;
+        if (out_split_colour_endpoints) *out_split_colour_endpoints = c.split_colour;
+    }
+    return rc;
+}
+
+int32_t dxtlt_transform_bc2_auto(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len,
+                                 const DltSizeEstimator* estimator, bool use_all_decorrelation_modes,
+                                 uint8_t* out_decorrelation_mode, bool* out_split_colour_endpoints,
+                                 uint32_t* out_estimator_error)
+{
+    dxtlt_host::AutoChoice c{};
+    int32_t rc = dxtlt_host::transform_auto(2, input_ptr, output_ptr, len, estimator, use_all_decorrelation_modes, &c);
+    if (out_estimator_error) *out_estimator_error = c.estimator_error;
+    if (rc == DXTLT_OK) {
+        if (out_decorrelation_mode) *out_decorrelation_mode = c.mode;
+        if (out_split_colour_endpoints) *out_split_colour_endpoints = c.split_colour;
+    }
+    return rc;
+}
+
+int32_t dxtlt_transform_bc3_auto(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len,
+                                 const DltSizeEstimator* estimator, bool use_all_decorrelation_modes,
+                                 uint8_t* out_decorrelation_mode, bool* out_split_alpha_endpoints,
+                                 bool* out_split_colour_endpoints, uint32_t* out_estimator_error)
+{
+    dxtlt_host::AutoChoice c{};
+    int32_t rc = dxtlt_host::transform_auto(3, input_ptr, output_ptr, len, estimator, use_all_decorrelation_modes, &c);
+    if (out_estimator_error) *out_estimator_error = c.estimator_error;
+    if (rc == DXTLT_OK) {
+        if (out_decorrelation_mode) *out_decorrelation_mode = c.mode;
+        if (out_split_alpha_endpoints) *out_split_alpha_endpoints = c.split_alpha;
+        if (out_split_colour_endpoints) *out_split_colour_endpoints = c.split_colour;
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bcn_launch.h"
+#include "host_common.h"
 
 namespace {
 
@@ -24,7 +25,9 @@ thread_local std::string g_last_error;
 std::atomic<int> g_tile_threads{0};
 std::atomic<int> g_force_generic{0};
 
-int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess)
+}  // namespace
+
+int32_t dxtlt_host::fail(int32_t code, const char* what, hipError_t e)
 {
     char buf[256];
     if (e != hipSuccess)
@@ -34,6 +37,9 @@ int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess)
     g_last_error = buf;
     return code;
 }
+
+namespace {
+using dxtlt_host::fail;
 
 #define HIP_TRY(expr, what)                                \
     do {                                                   \
@@ -145,8 +151,28 @@ struct HostCtx {
 
 thread_local HostCtx g_host_ctx;
 
-int32_t host_call(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode, bool sa,
-                  bool sc)
+}  // namespace
+
+int32_t dxtlt_host::acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream)
+{
+    HostCtx& c = g_host_ctx;
+    int32_t rc = c.prepare(bytes);
+    if (rc != DXTLT_OK)
+        return rc;
+    *d_in = c.d_in;
+    *d_out = c.d_out;
+    *stream = c.stream;
+    return DXTLT_OK;
+}
+
+int32_t dxtlt_host::enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
+                            bool sa, bool sc, hipStream_t stream)
+{
+    return device_range(format, inverse, d_src, d_dst, blocks, 0, blocks, mode, sa, sc, stream);
+}
+
+int32_t dxtlt_host::transform(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode,
+                              bool sa, bool sc)
 {
     int32_t rc = check_common(format, len, mode, in, out);
     if (rc != DXTLT_OK)
@@ -165,6 +191,14 @@ int32_t host_call(int32_t format, bool inverse, const uint8_t* in, uint8_t* out,
     HIP_TRY(hipMemcpyAsync(out, c.d_out, len, hipMemcpyDeviceToHost, c.stream), "D2H copy");
     HIP_TRY(hipStreamSynchronize(c.stream), "stream synchronize");
     return DXTLT_OK;
+}
+
+namespace {
+using dxtlt_host::transform;
+inline int32_t host_call(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode,
+                         bool sa, bool sc)
+{
+    return transform(format, inverse, in, out, len, mode, sa, sc);
 }
 
 // ---------------------------------------------------------------------------------------------------

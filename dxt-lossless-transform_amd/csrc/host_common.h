@@ -1,0 +1,48 @@
+// host_common.h -- internal interface between the C ABI translation units (dxtlt_api.cpp, auto_transform.cpp,
+// c_api_core.cpp, c_api_stable.cpp).  Not installed.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dlt_size_estimator.h"
+
+namespace dxtlt_host {
+
+// status codes == DXTLT_* in include/dxtlt_gfx950.h
+enum : int32_t {
+    kOk = 0,
+    kInvalidLength = 1,
+    kInvalidArgument = 2,
+    kNoDevice = 3,
+    kDevice = 4,
+    kEstimator = 5,
+    kAllocation = 6,
+};
+
+// Records the failure text for dxtlt_last_error() on this thread and returns `code`.
+int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess);
+
+// Host pointers in/out, whole buffer, synchronous (H2D + kernel + D2H on the current device).
+int32_t transform(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode,
+                  bool split_alpha, bool split_colour);
+
+// This thread's staging context on the current device: two device buffers of at least `bytes` and a stream.
+int32_t acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream);
+
+// Enqueue one whole-buffer transform on device pointers.
+int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
+                bool split_alpha, bool split_colour, hipStream_t stream);
+
+struct AutoChoice {
+    uint8_t mode;  // core numbering
+    bool split_alpha;
+    bool split_colour;
+    uint32_t estimator_error;  // the callback's non-zero return when the status is kEstimator
+};
+
+// transform_bcN_auto on host pointers (see auto_transform.cpp).
+int32_t transform_auto(int32_t format, const uint8_t* in, uint8_t* out, size_t len, const DltSizeEstimator* estimator,
+                       bool use_all_decorrelation_modes, AutoChoice* choice);
+
+}  // namespace dxtlt_host

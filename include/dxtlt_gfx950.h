@@ -37,6 +37,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "dlt_size_estimator.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -47,6 +49,8 @@ extern "C" {
 #define DXTLT_E_INVALID_ARGUMENT 2 /* bad decorrelation mode, NULL pointer with len > 0, bad range */
 #define DXTLT_E_NO_DEVICE 3        /* no usable HIP device */
 #define DXTLT_E_DEVICE 4           /* HIP runtime error (allocation, copy, launch) */
+#define DXTLT_E_ESTIMATOR 5        /* a size-estimator callback returned non-zero (auto transform) */
+#define DXTLT_E_ALLOCATION 6       /* host allocation of the estimator scratch buffer failed */
 
 /* YCoCgVariant, core numbering */
 #define DXTLT_YCOCG_NONE 0
@@ -69,6 +73,28 @@ int32_t dxtlt_transform_bc3_with_settings(const uint8_t *input_ptr, uint8_t *out
 int32_t dxtlt_untransform_bc3_with_settings(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
                                             uint8_t decorrelation_mode, bool split_alpha_endpoints,
                                             bool split_colour_endpoints);
+
+/* ---- host pointers: transform_bcN_auto ------------------------------------------------------------
+ * Replaces the bodies of (paths under /root/reference/src/core/):
+ *   transform_bc1_auto   dxt-lossless-transform-bc1/src/transform/transform_auto.rs:200
+ *   transform_bc2_auto   dxt-lossless-transform-bc2/src/transform/transform_auto.rs:196
+ *   transform_bc3_auto   dxt-lossless-transform-bc3/src/transform/transform_auto.rs:196
+ * `estimator` is the C vtable of the crate's SizeEstimationOperations (a Rust shim wraps any T in one).
+ * Candidate order, estimated sections, strict `<` tie-break and the final re-transform follow the reference;
+ * on DXTLT_OK the out_* settings (core numbering) describe the data left in output_ptr.  On DXTLT_E_ESTIMATOR
+ * *out_estimator_error (may be NULL) receives the callback's error code. */
+int32_t dxtlt_transform_bc1_auto(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                 const DltSizeEstimator *estimator, bool use_all_decorrelation_modes,
+                                 uint8_t *out_decorrelation_mode, bool *out_split_colour_endpoints,
+                                 uint32_t *out_estimator_error);
+int32_t dxtlt_transform_bc2_auto(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                 const DltSizeEstimator *estimator, bool use_all_decorrelation_modes,
+                                 uint8_t *out_decorrelation_mode, bool *out_split_colour_endpoints,
+                                 uint32_t *out_estimator_error);
+int32_t dxtlt_transform_bc3_auto(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len,
+                                 const DltSizeEstimator *estimator, bool use_all_decorrelation_modes,
+                                 uint8_t *out_decorrelation_mode, bool *out_split_alpha_endpoints,
+                                 bool *out_split_colour_endpoints, uint32_t *out_estimator_error);
 
 /* ---- device pointers, whole buffer, asynchronous on `hip_stream` (a hipStream_t; NULL = default) -- */
 int32_t dxtlt_transform_bc1_with_settings_device(const void *d_input, void *d_output, size_t len,

@@ -1,0 +1,98 @@
+"""ctypes view of the reference-shaped C APIs (include/dltbc{1,2,3}core.h, include/dltbc{1,2}.h,
+include/dlt_size_estimator.h) for the tests."""
+from __future__ import annotations
+
+import ctypes as C
+import zlib
+
+MAXFN = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t))
+ESTFN = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t))
+
+
+class DltSizeEstimator(C.Structure):
+    _fields_ = [("Context", C.c_void_p), ("MaxCompressedSize", MAXFN), ("EstimateCompressedSize", ESTFN)]
+
+
+class CoreSettings2(C.Structure):  # Dltbc1/2TransformSettings, core layout
+    _fields_ = [("SplitColourEndpoints", C.c_bool), ("DecorrelationMode", C.c_uint8)]
+
+
+class CoreSettings3(C.Structure):
+    _fields_ = [("SplitAlphaEndpoints", C.c_bool), ("SplitColourEndpoints", C.c_bool), ("DecorrelationMode", C.c_uint8)]
+
+
+class AutoSettings(C.Structure):
+    _fields_ = [("UseAllModes", C.c_bool)]
+
+
+class Result(C.Structure):
+    _fields_ = [("ErrorCode", C.c_int32)]
+
+
+def bind(lib):
+    vp, sz = C.c_void_p, C.c_size_t
+    for n, S in ((1, CoreSettings2), (2, CoreSettings2), (3, CoreSettings3)):
+        for d in ("transform", "untransform"):
+            f = getattr(lib, f"dltbc{n}core_{d}")
+            f.argtypes, f.restype = [vp, sz, vp, sz, S], Result
+        f = getattr(lib, f"dltbc{n}core_transform_auto")
+        f.argtypes, f.restype = [vp, sz, vp, sz, C.POINTER(DltSizeEstimator), AutoSettings, C.POINTER(S)], Result
+    for n in (1, 2):
+        p = f"dltbc{n}_"
+        getattr(lib, p + "new_ManualTransformBuilder").argtypes = []
+        getattr(lib, p + "new_ManualTransformBuilder").restype = vp
+        getattr(lib, p + "free_ManualTransformBuilder").argtypes = [vp]
+        getattr(lib, p + "free_ManualTransformBuilder").restype = None
+        getattr(lib, p + "clone_ManualTransformBuilder").argtypes = [vp]
+        getattr(lib, p + "clone_ManualTransformBuilder").restype = vp
+        getattr(lib, p + "ManualTransformBuilder_SetDecorrelationMode").argtypes = [vp, C.c_uint8]
+        getattr(lib, p + "ManualTransformBuilder_SetDecorrelationMode").restype = None
+        getattr(lib, p + "ManualTransformBuilder_SetSplitColourEndpoints").argtypes = [vp, C.c_bool]
+        getattr(lib, p + "ManualTransformBuilder_SetSplitColourEndpoints").restype = None
+        getattr(lib, p + "ManualTransformBuilder_ResetToDefaults").argtypes = [vp]
+        getattr(lib, p + "ManualTransformBuilder_ResetToDefaults").restype = None
+        for d in ("Transform", "Untransform"):
+            f = getattr(lib, p + "ManualTransformBuilder_" + d)
+            f.argtypes, f.restype = [vp, sz, vp, sz, vp], Result
+        getattr(lib, p + "new_AutoTransformBuilder").argtypes = [C.POINTER(DltSizeEstimator)]
+        getattr(lib, p + "new_AutoTransformBuilder").restype = vp
+        getattr(lib, p + "free_AutoTransformBuilder").argtypes = [vp]
+        getattr(lib, p + "free_AutoTransformBuilder").restype = None
+        f = getattr(lib, p + "AutoTransformBuilder_SetUseAllDecorrelationModes")
+        f.argtypes, f.restype = [vp, C.c_bool], Result
+        f = getattr(lib, p + "AutoTransformBuilder_Transform")
+        f.argtypes, f.restype = [vp, vp, sz, vp, sz, C.POINTER(vp)], Result
+        f = getattr(lib, p + "error_message")
+        f.argtypes, f.restype = [C.c_int32], C.c_char_p
+    return lib
+
+
+def make_estimator(kind: str, log=None):
+    """kind: 'dummy' (size = len, like the reference's C dummy estimator, bc1 c_api/transform_auto.rs:200-231),
+    'zlib' (zlib level 1 size), 'fail_max' / 'fail_est' (callback errors)."""
+
+    def py_estimate(buf: bytes) -> int:
+        if kind == "zlib":
+            return len(zlib.compress(buf, 1))
+        return len(buf)
+
+    @MAXFN
+    def max_fn(ctx, n, out):
+        if kind == "fail_max":
+            return 41
+        out[0] = n + 64 if kind == "zlib" else (0 if kind == "dummy0" else n)
+        return 0
+
+    @ESTFN
+    def est_fn(ctx, inp, n, scratch, scratch_len, out):
+        if kind == "fail_est":
+            return 42
+        data = C.string_at(inp, n) if n else b""
+        if log is not None:
+            log.append(n)
+        out[0] = py_estimate(data)
+        return 0
+
+    est = DltSizeEstimator(None, max_fn, est_fn)
+    est._keep = (max_fn, est_fn)
+    return est, py_estimate

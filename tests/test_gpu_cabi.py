@@ -1,0 +1,148 @@
+"""The reference-shaped C APIs (core dltbcNcore_*, stable dltbcN_*) end to end on the GPU, against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cabi
+from helpers import BLOCK, all_settings, payload
+from oracle import oracle_auto
+
+pytestmark = pytest.mark.gpu
+
+CORE_S = {1: cabi.CoreSettings2, 2: cabi.CoreSettings2, 3: cabi.CoreSettings3}
+FMT = {1: "bc1", 2: "bc2", 3: "bc3"}
+STABLE_OF_CORE = {1: 0, 2: 1, 3: 2, 0: 3}  # api-common reexports/color_565.rs:65-91
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    import torch
+
+    assert torch.cuda.is_available()
+    return cabi.bind(C.CDLL(pkg._lib.lib_path()))
+
+
+def core_settings(n, s):
+    v, sa, sc = s
+    st = CORE_S[n]()
+    st.DecorrelationMode = v
+    st.SplitColourEndpoints = bool(sc)
+    if n == 3:
+        st.SplitAlphaEndpoints = bool(sa)
+    return st
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_core_transform_untransform(lib, oracle, n):
+    fmt = FMT[n]
+    for blocks in (2, 777, 5000):
+        x = oracle.generate_test_data(fmt, blocks) if blocks < 1000 else oracle.fill_splitmix64(blocks * BLOCK[fmt], 5)
+        for s in all_settings(fmt):
+            st = core_settings(n, s)
+            y = np.zeros(x.size + 3, dtype=np.uint8)  # output may be larger than the input
+            r = getattr(lib, f"dltbc{n}core_transform")(x.ctypes.data, x.size, y.ctypes.data, y.size, st)
+            assert r.ErrorCode == 0
+            want = oracle.transform(fmt, x, s[0], s[2], s[1])
+            assert np.array_equal(y[: x.size], want) and not y[x.size:].any()
+            z = np.zeros_like(x)
+            r = getattr(lib, f"dltbc{n}core_untransform")(y.ctypes.data, x.size, z.ctypes.data, z.size, st)
+            assert r.ErrorCode == 0 and np.array_equal(z, x)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_stable_manual_builder(lib, oracle, n):
+    fmt = FMT[n]
+    p = f"dltbc{n}_"
+    x = oracle.fill_splitmix64(3001 * BLOCK[fmt], 77)
+    b = getattr(lib, p + "new_ManualTransformBuilder")()
+    y = np.zeros_like(x)
+    # defaults: Variant1 + split (bc1-api manual_transform_builder.rs:24-36)
+    assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, x.size, y.ctypes.data, y.size, b).ErrorCode == 0
+    assert np.array_equal(y, oracle.transform(fmt, x, 1, True))
+    for v, _, sc in all_settings(fmt):
+        getattr(lib, p + "ManualTransformBuilder_SetDecorrelationMode")(b, STABLE_OF_CORE[v])
+        getattr(lib, p + "ManualTransformBuilder_SetSplitColourEndpoints")(b, bool(sc))
+        c = getattr(lib, p + "clone_ManualTransformBuilder")(b)
+        assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, x.size, y.ctypes.data, y.size, b).ErrorCode == 0
+        assert np.array_equal(y, oracle.transform(fmt, x, v, sc)), (v, sc)
+        z = np.zeros_like(x)
+        assert getattr(lib, p + "ManualTransformBuilder_Untransform")(y.ctypes.data, y.size, z.ctypes.data, z.size, c).ErrorCode == 0
+        assert np.array_equal(z, x)
+        getattr(lib, p + "free_ManualTransformBuilder")(c)
+    getattr(lib, p + "ManualTransformBuilder_ResetToDefaults")(b)
+    assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, x.size, y.ctypes.data, y.size, b).ErrorCode == 0
+    assert np.array_equal(y, oracle.transform(fmt, x, 1, True))
+    getattr(lib, p + "free_ManualTransformBuilder")(b)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("use_all", [False, True])
+def test_core_auto_matches_reference_algorithm(lib, oracle, n, use_all):
+    fmt = FMT[n]
+    x = payload(fmt)
+    for kind in ("dummy", "dummy0", "zlib"):
+        log = []
+        est, py_est = cabi.make_estimator(kind, log)
+        want_choice, want_out, want_calls = oracle_auto.transform_auto(fmt, x, lambda b: py_est(bytes(b)), use_all)
+        y = np.zeros_like(x)
+        out = CORE_S[n]()
+        r = getattr(lib, f"dltbc{n}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                         cabi.AutoSettings(use_all), C.byref(out))
+        assert r.ErrorCode == 0
+        got = (out.DecorrelationMode, int(out.SplitAlphaEndpoints) if n == 3 else 0, int(out.SplitColourEndpoints))
+        assert got == want_choice, (kind, got, want_choice)
+        assert np.array_equal(y, want_out)
+        assert log == [ln for _, ln in want_calls]  # same sections, same order
+        z = np.zeros_like(x)
+        assert getattr(lib, f"dltbc{n}core_untransform")(y.ctypes.data, y.size, z.ctypes.data, z.size, out).ErrorCode == 0
+        assert np.array_equal(z, x)
+    if not use_all and n != 3:
+        # with a constant estimator the strict `<` keeps the FIRST candidate: None / NoSplit (settings.rs:81-86)
+        assert oracle_auto.transform_auto(fmt, x, len, False)[0] == (0, 0, 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_core_auto_estimator_failures(lib, n):
+    fmt = FMT[n]
+    x = payload(fmt)
+    y = np.zeros_like(x)
+    out = CORE_S[n]()
+    for kind in ("fail_max", "fail_est"):
+        est, _ = cabi.make_estimator(kind)
+        r = getattr(lib, f"dltbc{n}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                         cabi.AutoSettings(False), C.byref(out))
+        assert r.ErrorCode == 7  # SizeEstimationError
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_stable_auto_builder(lib, oracle, n):
+    fmt = FMT[n]
+    p = f"dltbc{n}_"
+    x = payload(fmt)
+    for use_all in (False, True):
+        est, py_est = cabi.make_estimator("zlib")
+        want_choice, want_out, _ = oracle_auto.transform_auto(fmt, x, lambda b: py_est(bytes(b)), use_all)
+        ab = getattr(lib, p + "new_AutoTransformBuilder")(C.byref(est))
+        assert getattr(lib, p + "AutoTransformBuilder_SetUseAllDecorrelationModes")(ab, use_all).ErrorCode == 0
+        y = np.zeros_like(x)
+        mb = C.c_void_p()
+        r = getattr(lib, p + "AutoTransformBuilder_Transform")(ab, x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(mb))
+        assert r.ErrorCode == 0 and mb.value
+        assert np.array_equal(y, want_out)
+        # the returned manual builder carries the chosen settings: it untransforms the result...
+        z = np.zeros_like(x)
+        assert getattr(lib, p + "ManualTransformBuilder_Untransform")(y.ctypes.data, y.size, z.ctypes.data, z.size, mb).ErrorCode == 0
+        assert np.array_equal(z, x)
+        # ...and transforming again with it reproduces the auto output
+        y2 = np.zeros_like(x)
+        assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, x.size, y2.ctypes.data, y2.size, mb).ErrorCode == 0
+        assert np.array_equal(y2, y)
+        getattr(lib, p + "free_ManualTransformBuilder")(mb)
+        getattr(lib, p + "free_AutoTransformBuilder")(ab)
+    est, _ = cabi.make_estimator("fail_est")
+    ab = getattr(lib, p + "new_AutoTransformBuilder")(C.byref(est))
+    mb = C.c_void_p(1)
+    r = getattr(lib, p + "AutoTransformBuilder_Transform")(ab, x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(mb))
+    assert r.ErrorCode == 4 and mb.value is None  # SizeEstimationFailed, output builder NULL
+    getattr(lib, p + "free_AutoTransformBuilder")(ab)
