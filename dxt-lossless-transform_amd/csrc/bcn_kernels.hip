@@ -39,7 +39,16 @@ namespace dxtlt {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kThreads = 256;        // element-granular / fill kernels; default tile workgroup (4 waves)
+constexpr int kThreads = 256;        // element-granular / fill kernels
+// Default tile workgroup size (tile = threads * 16 bytes) per format and direction, chosen by measurement on the
+// 8 GiB workloads (profiles/r01_g_tile_threads_sweep.txt, two runs): fraction of peak, fwd / inv
+//   BC1  64: .79-.81/.82-.84   128: .83/.83   256: .82-.83/.79-.80   512: .80/.75-.76
+//   BC2  64: .78/.81-.82       128: .81/.76   256: .81-.82/.79-.80   512: .81/.77-.78
+//   BC3  64: .72/.72-.75       128: .77/.72-.73   256: .79/.78-.80   512: .78/.77-.79
+constexpr int default_tile_threads(int fmt, bool inverse)
+{
+    return fmt == kBc1 ? (inverse ? 64 : 128) : fmt == kBc2 ? (inverse ? 64 : 256) : 256;
+}
 
 #ifndef DXTLT_NONTEMPORAL
 #define DXTLT_NONTEMPORAL 1
@@ -440,18 +449,21 @@ using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t);
 using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
 
 struct KernelSet {
-    TiledFn tiled256;
-    TiledFn tiled512;
+    TiledFn tiled[4];  // 64, 128, 256, 512 threads
     GenericFn generic;
 };
+
+inline int threads_slot(int threads) { return threads == 64 ? 0 : threads == 128 ? 1 : threads == 512 ? 3 : 2; }
 
 template <int FMT, int VARIANT, bool SA, bool SC>
 KernelSet kernels_for(bool inverse)
 {
     if (inverse)
-        return {inv_tiled<FMT, VARIANT, SA, SC, 256>, inv_tiled<FMT, VARIANT, SA, SC, 512>,
+        return {{inv_tiled<FMT, VARIANT, SA, SC, 64>, inv_tiled<FMT, VARIANT, SA, SC, 128>,
+                 inv_tiled<FMT, VARIANT, SA, SC, 256>, inv_tiled<FMT, VARIANT, SA, SC, 512>},
                 generic_kernel<FMT, VARIANT, SA, SC, true>};
-    return {fwd_tiled<FMT, VARIANT, SA, SC, 256>, fwd_tiled<FMT, VARIANT, SA, SC, 512>,
+    return {{fwd_tiled<FMT, VARIANT, SA, SC, 64>, fwd_tiled<FMT, VARIANT, SA, SC, 128>,
+             fwd_tiled<FMT, VARIANT, SA, SC, 256>, fwd_tiled<FMT, VARIANT, SA, SC, 512>},
             generic_kernel<FMT, VARIANT, SA, SC, false>};
 }
 
@@ -526,14 +538,17 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (tuning && tuning->force_generic)
         tiled_ok = false;
 
-    const int threads = (tuning && tuning->tile_threads == 512) ? 512 : 256;
+    int threads = default_tile_threads(fmt, inverse);
+    if (tuning && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
+                   tuning->tile_threads == 512))
+        threads = tuning->tile_threads;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
     const uint64_t num_tiles = tiled_ok ? r.num_blocks / T : 0;
     if (num_tiles > 0) {
         if (num_tiles > 0x7FFFFFFFull)
             return hipErrorInvalidValue;  // > 8 TiB in one call
-        hipLaunchKernelGGL(threads == 512 ? ks.tiled512 : ks.tiled256, dim3((unsigned)num_tiles), dim3(threads), 0,
-                           stream, src8, dst8, r.total_blocks, r.first_block);
+        hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream, src8,
+                           dst8, r.total_blocks, r.first_block);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;

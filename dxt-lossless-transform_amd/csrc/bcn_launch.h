@@ -24,7 +24,7 @@ struct Range {
 };
 
 struct LaunchTuning {
-    int tile_threads;   // 0/256 = default tile workgroup, 512 = experiment
+    int tile_threads;   // 0 = per-direction default; 64, 128, 256, 512 = experiment
     int force_generic;  // 1 = always take the element-granular kernel (testing)
 };
 

@@ -122,13 +122,14 @@ def test_element_kernel_equals_tiled_kernel(pkg, oracle, dev, fmt):
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
-def test_512_thread_tiles_equal_256_thread_tiles(pkg, oracle, dev, fmt):
+@pytest.mark.parametrize("threads", [64, 128, 256, 512])
+def test_every_tile_workgroup_size(pkg, oracle, dev, fmt, threads):
     n = 9 * TILE[fmt] + 16 * 3 + 1
     x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x512)
     for s in all_settings(fmt):
         want = fwd_oracle(oracle, fmt, x, s)
         try:
-            pkg.set_tuning(512, False)
+            pkg.set_tuning(threads, False)
             got = run_device(pkg, fmt, x, s, dev)
             back = run_device(pkg, fmt, got, s, dev, inverse=True)
         finally:
