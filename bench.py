@@ -42,6 +42,11 @@ def parse_args():
     p.add_argument("--format", default="bc1", choices=["bc1", "bc2", "bc3"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
+    p.add_argument("--settings", default="", help="variant,split_alpha,split_colour (e.g. 0,0,1) instead of the "
+                   "format's default settings; a sweep knob, the headline run uses the defaults")
+    p.add_argument("--drop-blocks", type=int, default=0, help="experiment: shorten the buffer by this many blocks "
+                   "(an odd count exercises the shifted-tile kernels)")
+    p.add_argument("--force-path", type=int, default=0, help="experiment: 1 = element-granular kernel, 2 = shifted tiles")
     p.add_argument("--tile-threads", type=int, default=0, help="tuning experiment: tile workgroup size 256 (default) or 512")
     return p.parse_args()
 
@@ -102,17 +107,23 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     pkg.load()
-    if args.tile_threads:
-        pkg.set_tuning(args.tile_threads, False)
+    if args.tile_threads or args.force_path:
+        pkg.set_tuning(args.tile_threads, args.force_path)
     fmt = args.format
     block = pkg.BLOCK_BYTES[fmt]
     settings = {"bc1": pkg.Bc1TransformSettings(), "bc2": pkg.Bc2TransformSettings(),
                 "bc3": pkg.Bc3TransformSettings()}[fmt]
+    if args.settings:
+        v, sa, sc = (int(t) for t in args.settings.split(","))
+        settings = {"bc1": lambda: pkg.Bc1TransformSettings(pkg.YCoCgVariant(v), bool(sc)),
+                    "bc2": lambda: pkg.Bc2TransformSettings(pkg.YCoCgVariant(v), bool(sc)),
+                    "bc3": lambda: pkg.Bc3TransformSettings(pkg.YCoCgVariant(v), bool(sa), bool(sc))}[fmt]()
     fwd = getattr(pkg, f"transform_{fmt}_with_settings")
     inv = getattr(pkg, f"untransform_{fmt}_with_settings")
 
     nbytes = int(args.size_gib * (1 << 30))
     nbytes -= nbytes % (block * 2048)
+    nbytes -= args.drop_blocks * block
     blocks = nbytes // block
     seed = {"bc1": 0x0BC10002, "bc2": 0x0BC20002, "bc3": 0x0BC30003}[fmt]
 
@@ -212,9 +223,10 @@ def main() -> None:
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"{fmt.upper()} forward+inverse, default settings "
-                        f"({'YCoCg Variant1, split colour endpoints' if fmt != 'bc3' else 'YCoCg Variant1, split alpha + colour endpoints'}), "
-                        f"{nbytes / 2**30:g} GiB random block buffer per GPU (BASELINE.json configs[1])",
+            "workload": f"{fmt.upper()} forward+inverse, "
+                        + (f"settings {args.settings} (variant,split_alpha,split_colour), " if args.settings else
+                           f"default settings ({'YCoCg Variant1, split colour endpoints' if fmt != 'bc3' else 'YCoCg Variant1, split alpha + colour endpoints'}), ")
+                        + f"{nbytes / 2**30:g} GiB random block buffer per GPU (BASELINE.json configs[1])",
             "format": fmt, "blocks_per_gpu": blocks, "bytes_per_gpu": nbytes, "seed": hex(seed),
             "sharding": "contiguous block range per rank, no collective",
             "bit_exact_roundtrip_and_oracle_window": bit_exact,

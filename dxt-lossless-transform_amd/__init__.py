@@ -128,8 +128,10 @@ def load():
     return _lib.load()
 
 
-def set_tuning(tile_threads: int = 0, force_generic: bool = False) -> None:
-    load().dxtlt_set_tuning(int(tile_threads), int(bool(force_generic)))
+def set_tuning(tile_threads: int = 0, force_path: int = 0) -> None:
+    """Experiments/tests: tile workgroup size (0 = per-format default) and kernel path (0 = automatic,
+    1 = element-granular kernel, 2 = shifted-tile kernel)."""
+    load().dxtlt_set_tuning(int(tile_threads), int(force_path))
 
 
 # ------------------------------------------------------------------------------------------------------

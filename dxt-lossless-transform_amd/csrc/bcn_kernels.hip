@@ -246,6 +246,331 @@ inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shifted tiles: the tiled structure for transformed buffers whose stream bases are NOT 16-byte aligned
+// (odd block counts -- e.g. a DDS payload with a full mip chain -- or ranges that start at an odd block).
+// Stream s lands at global address G_s = soa + off_s*N + w_s*first_block with misalignment d_s = G_s & 15.
+// Its slice of the LDS image is stored d_s bytes further in (each stream gets 16 bytes of padding), so an
+// LDS byte and the global byte it maps to have the same address modulo 16: the body of every slice still
+// leaves (arrives) as aligned 16-byte vectors, and only the first and last 16-byte segment of a slice are
+// partial; those are moved with 1/2/4/8-byte accesses that touch exactly the slice's own bytes, so the
+// neighbouring tile (which owns the rest of that 16-byte segment) never races with it.
+// Precondition: the AoS pointer is 16-byte aligned.  256-thread tiles.
+// ------------------------------------------------------------------------------------------------
+struct Shifts {
+    int d[6];
+    int xcd_remap;  // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group; observed, used for speed
+// only).  This bijective remap hands each group one contiguous eighth of the tiles, so two neighbouring tiles --
+// which share a 128-byte line whenever a stream base is misaligned -- meet in the same XCD's L2 and leave (arrive)
+// as one full line instead of two partial ones.
+__device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t nwg)
+{
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const uint64_t start = xcd < r ? (uint64_t)xcd * (q + 1) : (uint64_t)r * (q + 1) + (uint64_t)(xcd - r) * q;
+    return start + (orig >> 3);
+}
+
+template <int W>
+__device__ __forceinline__ void lds_put(uint8_t* lds, int addr, uint64_t v)
+{
+    if constexpr (W == 1) {
+        lds[addr] = (uint8_t)v;
+    } else if ((addr & (W - 1)) == 0) {
+        if constexpr (W == 2) lds_at<uint16_t>(lds, addr) = (uint16_t)v;
+        if constexpr (W == 4) lds_at<uint32_t>(lds, addr) = (uint32_t)v;
+        if constexpr (W == 8) lds_at<u32x2>(lds, addr) = u32x2{(uint32_t)v, (uint32_t)(v >> 32)};
+    } else if (W == 8 && (addr & 3) == 0) {
+        lds_at<uint32_t>(lds, addr) = (uint32_t)v;
+        lds_at<uint32_t>(lds, addr + 4) = (uint32_t)(v >> 32);
+    } else if ((addr & 1) == 0) {
+#pragma unroll
+        for (int i = 0; i < W / 2; ++i)
+            lds_at<uint16_t>(lds, addr + 2 * i) = (uint16_t)(v >> (16 * i));
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            lds[addr + i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
+template <int W>
+__device__ __forceinline__ uint64_t lds_get(uint8_t* lds, int addr)
+{
+    if constexpr (W == 1) {
+        return lds[addr];
+    } else if ((addr & (W - 1)) == 0) {
+        if constexpr (W == 2) return lds_at<uint16_t>(lds, addr);
+        if constexpr (W == 4) return lds_at<uint32_t>(lds, addr);
+        if constexpr (W == 8) {
+            const u32x2 p = lds_at<u32x2>(lds, addr);
+            return (uint64_t)p.x | ((uint64_t)p.y << 32);
+        }
+    } else if (W == 8 && (addr & 3) == 0) {
+        return (uint64_t)lds_at<uint32_t>(lds, addr) | ((uint64_t)lds_at<uint32_t>(lds, addr + 4) << 32);
+    } else if ((addr & 1) == 0) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < W / 2; ++i)
+            v |= (uint64_t)lds_at<uint16_t>(lds, addr + 2 * i) << (16 * i);
+        return v;
+    }
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+        v |= (uint64_t)lds[addr + i] << (8 * i);
+    return v;
+}
+
+// stream indices of the fields (make_streams order)
+template <int FMT, bool SA, bool SC>
+struct FieldStreams {
+    static constexpr int alpha = 0;                                       // BC2 alpha, BC3 a0 or (a0,a1)
+    static constexpr int a1 = 1;                                          // BC3 split alphas
+    static constexpr int aidx = SA ? 2 : 1;                               // BC3
+    static constexpr int col = FMT == kBc1 ? 0 : FMT == kBc2 ? 1 : (SA ? 3 : 2);  // c0 or (c0,c1)
+    static constexpr int c1 = col + 1;                                    // split colours
+    static constexpr int idx = col + (SC ? 2 : 1);
+};
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__device__ __forceinline__ void scatter_shifted(uint8_t* lds, int u, u32x4 q, const int (&base)[6])
+{
+    using F = FieldStreams<FMT, SA, SC>;
+    if constexpr (FMT == kBc1) {
+        const uint32_t ca = decorrelate2<VARIANT>(q.x);
+        const uint32_t cb = decorrelate2<VARIANT>(q.z);
+        if constexpr (SC) {
+            lds_put<4>(lds, base[F::col] + 4 * u, (ca & 0xFFFFu) | (cb << 16));
+            lds_put<4>(lds, base[F::c1] + 4 * u, (ca >> 16) | (cb & 0xFFFF0000u));
+        } else {
+            lds_put<8>(lds, base[F::col] + 8 * u, (uint64_t)ca | ((uint64_t)cb << 32));
+        }
+        lds_put<8>(lds, base[F::idx] + 8 * u, (uint64_t)q.y | ((uint64_t)q.w << 32));
+    } else {
+        const uint32_t c = decorrelate2<VARIANT>(q.z);
+        if constexpr (FMT == kBc2) {
+            lds_put<8>(lds, base[F::alpha] + 8 * u, (uint64_t)q.x | ((uint64_t)q.y << 32));
+        } else {
+            if constexpr (SA) {
+                lds_put<1>(lds, base[F::alpha] + u, q.x & 0xFF);
+                lds_put<1>(lds, base[F::a1] + u, (q.x >> 8) & 0xFF);
+            } else {
+                lds_put<2>(lds, base[F::alpha] + 2 * u, q.x & 0xFFFF);
+            }
+            lds_put<2>(lds, base[F::aidx] + 6 * u + 0, q.x >> 16);
+            lds_put<2>(lds, base[F::aidx] + 6 * u + 2, q.y & 0xFFFF);
+            lds_put<2>(lds, base[F::aidx] + 6 * u + 4, q.y >> 16);
+        }
+        if constexpr (SC) {
+            lds_put<2>(lds, base[F::col] + 2 * u, c & 0xFFFF);
+            lds_put<2>(lds, base[F::c1] + 2 * u, c >> 16);
+        } else {
+            lds_put<4>(lds, base[F::col] + 4 * u, c);
+        }
+        lds_put<4>(lds, base[F::idx] + 4 * u, q.w);
+    }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__device__ __forceinline__ u32x4 gather_shifted(uint8_t* lds, int u, const int (&base)[6])
+{
+    using F = FieldStreams<FMT, SA, SC>;
+    u32x4 q;
+    if constexpr (FMT == kBc1) {
+        uint32_t ca, cb;
+        if constexpr (SC) {
+            const uint32_t c0 = (uint32_t)lds_get<4>(lds, base[F::col] + 4 * u);
+            const uint32_t c1 = (uint32_t)lds_get<4>(lds, base[F::c1] + 4 * u);
+            ca = (c0 & 0xFFFFu) | (c1 << 16);
+            cb = (c0 >> 16) | (c1 & 0xFFFF0000u);
+        } else {
+            const uint64_t p = lds_get<8>(lds, base[F::col] + 8 * u);
+            ca = (uint32_t)p;
+            cb = (uint32_t)(p >> 32);
+        }
+        const uint64_t idx = lds_get<8>(lds, base[F::idx] + 8 * u);
+        q.x = recorrelate2<VARIANT>(ca);
+        q.y = (uint32_t)idx;
+        q.z = recorrelate2<VARIANT>(cb);
+        q.w = (uint32_t)(idx >> 32);
+    } else {
+        if constexpr (FMT == kBc2) {
+            const uint64_t a = lds_get<8>(lds, base[F::alpha] + 8 * u);
+            q.x = (uint32_t)a;
+            q.y = (uint32_t)(a >> 32);
+        } else {
+            uint32_t a01;
+            if constexpr (SA)
+                a01 = (uint32_t)lds_get<1>(lds, base[F::alpha] + u) | ((uint32_t)lds_get<1>(lds, base[F::a1] + u) << 8);
+            else
+                a01 = (uint32_t)lds_get<2>(lds, base[F::alpha] + 2 * u);
+            const uint32_t i01 = (uint32_t)lds_get<2>(lds, base[F::aidx] + 6 * u + 0);
+            const uint32_t i23 = (uint32_t)lds_get<2>(lds, base[F::aidx] + 6 * u + 2);
+            const uint32_t i45 = (uint32_t)lds_get<2>(lds, base[F::aidx] + 6 * u + 4);
+            q.x = a01 | (i01 << 16);
+            q.y = i23 | (i45 << 16);
+        }
+        uint32_t c;
+        if constexpr (SC)
+            c = (uint32_t)lds_get<2>(lds, base[F::col] + 2 * u) | ((uint32_t)lds_get<2>(lds, base[F::c1] + 2 * u) << 16);
+        else
+            c = (uint32_t)lds_get<4>(lds, base[F::col] + 4 * u);
+        q.z = recorrelate2<VARIANT>(c);
+        q.w = (uint32_t)lds_get<4>(lds, base[F::idx] + 4 * u);
+    }
+    return q;
+}
+
+// Copy bytes [lo, hi) of one 16-byte segment between two pointers that are both 16-byte aligned at byte 0 of
+// the segment; either lo == 0 (a slice's tail) or hi == 16 (a slice's head).  Typed 1/2/4/8-byte moves.
+template <bool TO_GLOBAL>
+__device__ __forceinline__ void copy_partial_segment(uint8_t* dst, const uint8_t* src, int lo, int hi)
+{
+    auto mv = [&](int p, int w) {
+        if (w == 1) dst[p] = src[p];
+        if (w == 2) *reinterpret_cast<uint16_t*>(dst + p) = *reinterpret_cast<const uint16_t*>(src + p);
+        if (w == 4) *reinterpret_cast<uint32_t*>(dst + p) = *reinterpret_cast<const uint32_t*>(src + p);
+        if (w == 8) *reinterpret_cast<u32x2*>(dst + p) = *reinterpret_cast<const u32x2*>(src + p);
+    };
+    if (hi == 16) {  // head: [lo, 16)
+        int p = lo;
+        if (p & 1) { mv(p, 1); p += 1; }
+        if (p & 2) { mv(p, 2); p += 2; }
+        if (p & 4) { mv(p, 4); p += 4; }
+        if (p & 8) { mv(p, 8); }
+    } else {  // tail: [0, hi)
+        int p = 0;
+        if (hi & 8) { mv(p, 8); p += 8; }
+        if (hi & 4) { mv(p, 4); p += 4; }
+        if (hi & 2) { mv(p, 2); p += 2; }
+        if (hi & 1) { mv(p, 1); }
+    }
+}
+
+// For image byte o (a multiple of 16): stream index, LDS address of the segment, global offset of the segment
+// (aligned), and the stream's shift.
+template <int FMT, bool SA, bool SC, int T>
+__device__ __forceinline__ void shifted_segment(int o, uint64_t total_blocks, uint64_t blk0, const Shifts& sh, int& s_out,
+                                                int& k_out, int& lds_addr, uint64_t& g_off, int& shift)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    s_out = 0; k_out = 0; lds_addr = 0; g_off = 0; shift = 0;
+#pragma unroll
+    for (int s = 0; s < S.n; ++s) {
+        const int lo = S.off[s] * T;
+        const int hi = lo + S.width[s] * T;
+        if (o >= lo && o < hi) {
+            s_out = s;
+            k_out = (o - lo) >> 4;
+            lds_addr = lo + 16 * s + (o - lo);
+            g_off = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 - (uint64_t)sh.d[s] + (uint64_t)(o - lo);
+            shift = sh.d[s];
+        }
+    }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__global__ void __launch_bounds__(256)
+fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
+                Shifts sh)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int T = tile_blocks(FMT, 256);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * 16 + 16 * 6];
+    const int t = threadIdx.x;
+    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    const uint64_t blk0 = first_block + tile * T;
+    int base[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+        base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
+
+    const u32x4 q = gload16(aos + tile * 4096 + t * 16);
+    scatter_shifted<FMT, VARIANT, SA, SC>(lds, t, q, base);
+    __syncthreads();
+
+    int s, k, la, shift;
+    uint64_t g;
+    shifted_segment<FMT, SA, SC, T>(t * 16, total_blocks, blk0, sh, s, k, la, g, shift);
+    if (k == 0 && shift > 0)
+        copy_partial_segment<true>(soa + g, lds + la, shift, 16);
+    else
+        gstore16(soa + g, lds_at<u32x4>(lds, la));
+    if (t < S.n) {  // the extra, partial last segment of stream t
+#pragma unroll
+        for (int ss = 0; ss < S.n; ++ss) {
+            if (ss == t && sh.d[ss] > 0) {
+                const int bytes = S.width[ss] * T;
+                const uint64_t gt = (uint64_t)S.off[ss] * total_blocks + (uint64_t)S.width[ss] * blk0 - (uint64_t)sh.d[ss] + bytes;
+                copy_partial_segment<true>(soa + gt, lds + S.off[ss] * T + 16 * ss + bytes, 0, sh.d[ss]);
+            }
+        }
+    }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+__global__ void __launch_bounds__(256)
+inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
+                Shifts sh)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int T = tile_blocks(FMT, 256);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * 16 + 16 * 6];
+    const int t = threadIdx.x;
+    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    const uint64_t blk0 = first_block + tile * T;
+    int base[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+        base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
+
+    // Loads may fetch the whole aligned 16-byte segment even when only part of it belongs to this tile's slice: the
+    // other bytes land in the stream's LDS padding.  Only a segment that pokes outside the transformed buffer
+    // itself (first tile of the first stream, last tile of the last stream) is fetched piecewise.  All loads of the
+    // tile are issued before the first wait.
+    const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
+    int s, k, la, shift;
+    uint64_t g;
+    shifted_segment<FMT, SA, SC, T>(t * 16, total_blocks, blk0, sh, s, k, la, g, shift);
+    // the extra, partial last segment of stream t (lanes 0..n-1), selected by data, not by control flow
+    int la_t = 0, shift_t = 0;
+    uint64_t g_t = 0;
+#pragma unroll
+    for (int ss = 0; ss < S.n; ++ss) {
+        if (ss == t) {
+            const int bytes = S.width[ss] * T;
+            la_t = S.off[ss] * T + 16 * ss + bytes;
+            shift_t = sh.d[ss];
+            g_t = (uint64_t)S.off[ss] * total_blocks + (uint64_t)S.width[ss] * blk0 - (uint64_t)sh.d[ss] + bytes;
+        }
+    }
+    const bool has_tail = t < S.n && shift_t > 0;
+    // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
+    const bool main_inside = g + 16 <= total_bytes;
+    const bool tail_inside = g_t + 16 <= total_bytes;
+    u32x4 v_main = {0, 0, 0, 0}, v_tail = {0, 0, 0, 0};
+    if (main_inside)
+        v_main = gload16(soa + g);
+    if (has_tail && tail_inside)
+        v_tail = gload16(soa + g_t);
+    if (main_inside)
+        lds_at<u32x4>(lds, la) = v_main;
+    else
+        copy_partial_segment<false>(lds + la, soa + g, (k == 0) ? shift : 0, (k == 0) ? 16 : shift);
+    if (has_tail) {
+        if (tail_inside)
+            lds_at<u32x4>(lds, la_t) = v_tail;
+        else
+            copy_partial_segment<false>(lds + la_t, soa + g_t, 0, shift_t);
+    }
+    __syncthreads();
+    const u32x4 q = gather_shifted<FMT, VARIANT, SA, SC>(lds, t, base);
+    gstore16(aos + tile * 4096 + t * 16, q);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Element-granular kernels: one lane per block, any alignment, any block count.  Used for the tail of a
 // tiled range and for buffers whose pointers / stream bases are not 16-byte aligned.
 // ------------------------------------------------------------------------------------------------
@@ -447,9 +772,11 @@ namespace {
 
 using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t);
 using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
+using ShiftFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, Shifts);
 
 struct KernelSet {
     TiledFn tiled[4];  // 64, 128, 256, 512 threads
+    ShiftFn shifted;   // 256 threads, misaligned stream bases
     GenericFn generic;
 };
 
@@ -461,10 +788,10 @@ KernelSet kernels_for(bool inverse)
     if (inverse)
         return {{inv_tiled<FMT, VARIANT, SA, SC, 64>, inv_tiled<FMT, VARIANT, SA, SC, 128>,
                  inv_tiled<FMT, VARIANT, SA, SC, 256>, inv_tiled<FMT, VARIANT, SA, SC, 512>},
-                generic_kernel<FMT, VARIANT, SA, SC, true>};
+                inv_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, true>};
     return {{fwd_tiled<FMT, VARIANT, SA, SC, 64>, fwd_tiled<FMT, VARIANT, SA, SC, 128>,
              fwd_tiled<FMT, VARIANT, SA, SC, 256>, fwd_tiled<FMT, VARIANT, SA, SC, 512>},
-            generic_kernel<FMT, VARIANT, SA, SC, false>};
+            fwd_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, false>};
 }
 
 template <int FMT, int VARIANT>
@@ -530,25 +857,42 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     const void* aos = inverse ? (const void*)dst : src;
     const void* soa = inverse ? src : (const void*)dst;
 
-    // Can the tiled path take the range?  Both pointers and every stream base must be 16-byte aligned.
+    // Which path can take the range?
+    //   aligned tiles: both pointers and every stream base 16-byte aligned
+    //   shifted tiles: AoS pointer 16-byte aligned, stream bases anywhere
+    //   element kernel: everything else, and the tail that does not fill a tile
     const Streams S = make_streams(fmt, sa, sc);
-    bool tiled_ok = ((reinterpret_cast<uintptr_t>(aos) | reinterpret_cast<uintptr_t>(soa)) & 15) == 0;
-    for (int i = 0; i < S.n && tiled_ok; ++i)
-        tiled_ok = (((uint64_t)S.off[i] * r.total_blocks + (uint64_t)S.width[i] * r.first_block) & 15) == 0;
-    if (tuning && tuning->force_generic)
-        tiled_ok = false;
+    const bool aos_ok = (reinterpret_cast<uintptr_t>(aos) & 15) == 0;
+    Shifts sh{};
+    bool any_shift = false;
+    for (int i = 0; i < S.n; ++i) {
+        const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
+                              (uint64_t)S.width[i] * r.first_block;
+        sh.d[i] = (int)(base & 15);
+        any_shift = any_shift || sh.d[i] != 0;
+    }
+    sh.xcd_remap = (tuning && tuning->xcd_remap >= 0) ? tuning->xcd_remap : 1;
+    const int force = tuning ? tuning->force_generic : 0;  // 1 = element kernel, 2 = shifted tiles
+    const bool use_tiles = aos_ok && force != 1;
+    const bool use_shift = use_tiles && (any_shift || force == 2);
 
     int threads = default_tile_threads(fmt, inverse);
     if (tuning && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
                    tuning->tile_threads == 512))
         threads = tuning->tile_threads;
+    if (use_shift)
+        threads = 256;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
-    const uint64_t num_tiles = tiled_ok ? r.num_blocks / T : 0;
+    const uint64_t num_tiles = use_tiles ? r.num_blocks / T : 0;
     if (num_tiles > 0) {
         if (num_tiles > 0x7FFFFFFFull)
             return hipErrorInvalidValue;  // > 8 TiB in one call
-        hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream, src8,
-                           dst8, r.total_blocks, r.first_block);
+        if (use_shift)
+            hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
+                               r.first_block, sh);
+        else
+            hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream,
+                               src8, dst8, r.total_blocks, r.first_block);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;

@@ -25,7 +25,8 @@ struct Range {
 
 struct LaunchTuning {
     int tile_threads;   // 0 = per-direction default; 64, 128, 256, 512 = experiment
-    int force_generic;  // 1 = always take the element-granular kernel (testing)
+    int force_generic;  // testing: 1 = always the element-granular kernel, 2 = always the shifted-tile kernel
+    int xcd_remap;      // shifted tiles: -1 = default, 0 = off, 1 = XCD-contiguous tile order
 };
 
 // Forward: aos (input) -> soa (output).  Inverse: soa (input) -> aos (output).

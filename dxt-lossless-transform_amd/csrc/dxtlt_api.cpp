@@ -24,6 +24,7 @@ using dxtlt::Settings;
 thread_local std::string g_last_error;
 std::atomic<int> g_tile_threads{0};
 std::atomic<int> g_force_generic{0};
+std::atomic<int> g_xcd_remap{-1};
 
 }  // namespace
 
@@ -52,7 +53,8 @@ dxtlt::LaunchTuning current_tuning()
 {
     dxtlt::LaunchTuning t;
     t.tile_threads = g_tile_threads.load(std::memory_order_relaxed);
-    t.force_generic = g_force_generic.load(std::memory_order_relaxed);
+    t.force_generic = g_force_generic.load(std::memory_order_relaxed) & 0xFF;
+    t.xcd_remap = g_xcd_remap.load(std::memory_order_relaxed);
     return t;
 }
 
@@ -424,7 +426,9 @@ int32_t dxtlt_device_count(void)
 void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 {
     g_tile_threads.store(tile_threads);
-    g_force_generic.store(force_generic);
+    // bits 8..9 of force_path carry the XCD-remap experiment switch: 0x100 = off, 0x200 = on, 0 = default
+    g_force_generic.store(force_generic & 0xFF);
+    g_xcd_remap.store((force_generic & 0x100) ? 0 : (force_generic & 0x200) ? 1 : -1);
 }
 
 const char* dxtlt_version(void) { return "dxtlt-gfx950 0.1.0"; }

@@ -145,9 +145,10 @@ int32_t dxtlt_fill_splitmix64_device(void *d_dst, size_t len_bytes, uint64_t see
 const char *dxtlt_last_error(void);
 /* Number of visible HIP devices (0 if the runtime cannot initialise). */
 int32_t dxtlt_device_count(void);
-/* Tuning knobs for experiments (tile workgroup size 256 or 512 threads; force the element-granular
- * kernel).  Process-wide; 0 restores the default. */
-void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic);
+/* Knobs for experiments and tests.  tile_threads: 64/128/256/512 (0 = per-format default).
+ * force_path: 0 = automatic, 1 = always the element-granular kernel, 2 = always the shifted-tile kernel.
+ * Process-wide. */
+void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path);
 /* "dxtlt-gfx950 <version>" */
 const char *dxtlt_version(void);
 

@@ -112,11 +112,11 @@ def test_element_kernel_equals_tiled_kernel(pkg, oracle, dev, fmt):
     for s in all_settings(fmt):
         tiled = run_device(pkg, fmt, x, s, dev)
         try:
-            pkg.set_tuning(0, True)
+            pkg.set_tuning(0, 1)
             generic = run_device(pkg, fmt, x, s, dev)
             back = run_device(pkg, fmt, generic, s, dev, inverse=True)
         finally:
-            pkg.set_tuning(0, False)
+            pkg.set_tuning(0, 0)
         assert np.array_equal(tiled, generic), (fmt, settings_id(s))
         assert np.array_equal(back, x)
 
@@ -129,12 +129,47 @@ def test_every_tile_workgroup_size(pkg, oracle, dev, fmt, threads):
     for s in all_settings(fmt):
         want = fwd_oracle(oracle, fmt, x, s)
         try:
-            pkg.set_tuning(threads, False)
+            pkg.set_tuning(threads, 0)
             got = run_device(pkg, fmt, x, s, dev)
             back = run_device(pkg, fmt, got, s, dev, inverse=True)
         finally:
-            pkg.set_tuning(0, False)
+            pkg.set_tuning(0, 0)
         assert np.array_equal(got, want), (fmt, settings_id(s))
+        assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_shifted_tiles(pkg, oracle, dev, fmt):
+    """Odd block counts put the stream bases off 16-byte alignment: the shifted-tile kernels take the body.  Every
+    residue of N modulo 16 (BC3 split alphas: a1 starts at byte N), all settings; and the shifted kernels forced on
+    aligned data must equal the aligned kernels."""
+    t = TILE[fmt]
+    for n in [3 * t + r for r in range(1, 17)] + [7 * t + 5, 100 * t + 33]:
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x5111F7 + n)
+        for s in all_settings(fmt):
+            want = fwd_oracle(oracle, fmt, x, s)
+            xd = torch.from_numpy(x).to(dev)
+            yd = torch.full((x.size + 64,), 0x3C, dtype=torch.uint8, device=dev)
+            st = pkg_settings(pkg, fmt, s)
+            getattr(pkg, f"transform_{fmt}_with_settings")(xd, yd[: x.size], st)
+            torch.cuda.synchronize()
+            assert np.array_equal(yd[: x.size].cpu().numpy(), want), (fmt, n, settings_id(s))
+            assert bool((yd[x.size:] == 0x3C).all()), "wrote past the end"
+            zd = torch.full((x.size + 64,), 0x3C, dtype=torch.uint8, device=dev)
+            getattr(pkg, f"untransform_{fmt}_with_settings")(yd[: x.size], zd[: x.size], st)
+            torch.cuda.synchronize()
+            assert np.array_equal(zd[: x.size].cpu().numpy(), x), (fmt, n, settings_id(s), "inverse")
+            assert bool((zd[x.size:] == 0x3C).all())
+    n = 6 * t
+    x = oracle.fill_splitmix64(n * BLOCK[fmt], 0xF02CE)
+    for s in all_settings(fmt):
+        try:
+            pkg.set_tuning(0, 2)
+            got = run_device(pkg, fmt, x, s, dev)
+            back = run_device(pkg, fmt, got, s, dev, inverse=True)
+        finally:
+            pkg.set_tuning(0, 0)
+        assert np.array_equal(got, fwd_oracle(oracle, fmt, x, s)), (fmt, settings_id(s))
         assert np.array_equal(back, x)
 
 
