@@ -206,6 +206,17 @@ __device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
     return q;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group; observed, used for speed
+// only).  This bijective remap hands each group one contiguous eighth of the tiles, so two neighbouring tiles --
+// which share a 128-byte line whenever a stream base is misaligned -- meet in the same XCD's L2 and leave (arrive)
+// as one full line instead of two partial ones.
+__device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t nwg)
+{
+    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const uint64_t start = xcd < r ? (uint64_t)xcd * (q + 1) : (uint64_t)r * (q + 1) + (uint64_t)(xcd - r) * q;
+    return start + (orig >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tiled kernels: one tile per workgroup.  `aos` points at the range's first block, `soa` at byte 0 of the
 // whole transformed buffer.  Preconditions (checked on the host): both pointers 16-byte aligned; every
@@ -214,12 +225,13 @@ __device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
 // ------------------------------------------------------------------------------------------------
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
 __global__ void __launch_bounds__(THREADS)
-fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block)
+fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
+          int xcd_remap)
 {
     constexpr int T = tile_blocks(FMT, THREADS);
     __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
     const int t = threadIdx.x;
-    const uint64_t tile = blockIdx.x;
+    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
 
     const u32x4 q = gload16(aos + tile * (THREADS * 16) + t * 16);
     scatter_to_image<FMT, VARIANT, SA, SC, T>(lds, t, q);
@@ -231,12 +243,13 @@ fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t t
 
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
 __global__ void __launch_bounds__(THREADS)
-inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block)
+inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
+          int xcd_remap)
 {
     constexpr int T = tile_blocks(FMT, THREADS);
     __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
     const int t = threadIdx.x;
-    const uint64_t tile = blockIdx.x;
+    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
 
     const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
     lds_at<u32x4>(lds, t * 16) = gload16(soa + o);
@@ -261,16 +274,6 @@ struct Shifts {
     int xcd_remap;  // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
 };
 
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group; observed, used for speed
-// only).  This bijective remap hands each group one contiguous eighth of the tiles, so two neighbouring tiles --
-// which share a 128-byte line whenever a stream base is misaligned -- meet in the same XCD's L2 and leave (arrive)
-// as one full line instead of two partial ones.
-__device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t nwg)
-{
-    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const uint64_t start = xcd < r ? (uint64_t)xcd * (q + 1) : (uint64_t)r * (q + 1) + (uint64_t)(xcd - r) * q;
-    return start + (orig >> 3);
-}
 
 template <int W>
 __device__ __forceinline__ void lds_put(uint8_t* lds, int addr, uint64_t v)
@@ -770,7 +773,7 @@ fill_splitmix64_kernel(uint8_t* __restrict__ dst, uint64_t len_bytes, uint64_t s
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t);
+using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int);
 using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
 using ShiftFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, Shifts);
 
@@ -871,7 +874,11 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         sh.d[i] = (int)(base & 15);
         any_shift = any_shift || sh.d[i] != 0;
     }
-    sh.xcd_remap = (tuning && tuning->xcd_remap >= 0) ? tuning->xcd_remap : 1;
+    // XCD-contiguous tile order: measured +2..+9 % on shifted tiles (neighbouring tiles share 128-byte lines), -1..-3 %
+    // on aligned tiles (profiles/r01_i_*) -- so on for the former, off for the latter unless an experiment says so
+    const int remap_override = tuning ? tuning->xcd_remap : -1;
+    sh.xcd_remap = remap_override >= 0 ? remap_override : 1;
+    const int aligned_remap = remap_override >= 0 ? remap_override : 0;
     const int force = tuning ? tuning->force_generic : 0;  // 1 = element kernel, 2 = shifted tiles
     const bool use_tiles = aos_ok && force != 1;
     const bool use_shift = use_tiles && (any_shift || force == 2);
@@ -892,7 +899,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
                                r.first_block, sh);
         else
             hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream,
-                               src8, dst8, r.total_blocks, r.first_block);
+                               src8, dst8, r.total_blocks, r.first_block, aligned_remap);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
