@@ -5,7 +5,10 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -153,6 +156,124 @@ struct HostCtx {
 
 thread_local HostCtx g_host_ctx;
 
+// ---------------------------------------------------------------------------------------------------
+// Chunked host path: H2D of chunk k+1, the kernel of chunk k and D2H of chunk k-1 overlap.
+// Copies from/to pageable host memory block the calling thread while the runtime stages them, so the two
+// directions are driven by two host threads: the caller uploads and launches (stream `up`), a helper thread
+// downloads (stream `down`) as soon as the chunk's event has fired.  PCIe is full duplex; the kernel time is
+// negligible next to either copy.  A chunk is a block range of the whole array (dxtlt_transform_range_device
+// semantics), so on the SoA side every chunk moves one slice per stream.
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t kPipelineMinBytes = 32u << 20;   // below this one H2D + kernel + D2H is as fast
+constexpr uint64_t kPipelineChunkBytes = 32u << 20;
+std::atomic<int> g_host_pipeline{1};
+
+struct PipeShared {
+    std::mutex m;
+    std::condition_variable cv;
+    int launched = 0;     // chunks whose kernel (and event) have been enqueued
+    bool failed = false;  // uploader gave up
+};
+
+int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint8_t* in, uint8_t* out, uint64_t blocks,
+                            uint8_t mode, bool sa, bool sc)
+{
+    const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
+    const dxtlt::Streams S = dxtlt::make_streams(format, format == 3 && sa, sc);
+    uint64_t chunk_blocks = kPipelineChunkBytes / B;  // a multiple of every tile size
+    const int nchunks = (int)((blocks + chunk_blocks - 1) / chunk_blocks);
+    const int dev = c.device;
+
+    hipStream_t down = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking), "hipStreamCreate(download)");
+    std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
+    for (auto& e : ev) {
+        hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            for (auto& e2 : ev) if (e2) (void)hipEventDestroy(e2);
+            (void)hipStreamDestroy(down);
+            return fail(DXTLT_E_DEVICE, "hipEventCreate", err);
+        }
+    }
+
+    PipeShared sh;
+    hipError_t down_err = hipSuccess;
+    std::thread downloader([&] {
+        hipError_t e = hipSetDevice(dev);
+        for (int k = 0; k < nchunks && e == hipSuccess; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(sh.m);
+                sh.cv.wait(lk, [&] { return sh.launched > k || sh.failed; });
+                if (sh.launched <= k)
+                    break;  // uploader failed before this chunk
+            }
+            const uint64_t first = (uint64_t)k * chunk_blocks;
+            const uint64_t count = std::min<uint64_t>(chunk_blocks, blocks - first);
+            e = hipStreamWaitEvent(down, ev[(size_t)k], 0);
+            if (!inverse) {
+                for (int s = 0; s < S.n && e == hipSuccess; ++s) {
+                    const uint64_t o = (uint64_t)S.off[s] * blocks + (uint64_t)S.width[s] * first;
+                    e = hipMemcpyAsync(out + o, (const uint8_t*)c.d_out + o, (size_t)(S.width[s] * count),
+                                       hipMemcpyDeviceToHost, down);
+                }
+            } else if (e == hipSuccess) {
+                e = hipMemcpyAsync(out + first * B, (const uint8_t*)c.d_out + first * B, (size_t)(count * B),
+                                   hipMemcpyDeviceToHost, down);
+            }
+        }
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(down);
+        down_err = e;
+    });
+
+    hipError_t up_err = hipSuccess;
+    int32_t rc = DXTLT_OK;
+    for (int k = 0; k < nchunks; ++k) {
+        const uint64_t first = (uint64_t)k * chunk_blocks;
+        const uint64_t count = std::min<uint64_t>(chunk_blocks, blocks - first);
+        if (!inverse) {
+            up_err = hipMemcpyAsync((uint8_t*)c.d_in + first * B, in + first * B, (size_t)(count * B),
+                                    hipMemcpyHostToDevice, c.stream);
+            if (up_err == hipSuccess)
+                rc = device_range(format, false, (const uint8_t*)c.d_in + first * B, c.d_out, blocks, first, count, mode,
+                                  sa, sc, c.stream);
+        } else {
+            for (int s = 0; s < S.n && up_err == hipSuccess; ++s) {
+                const uint64_t o = (uint64_t)S.off[s] * blocks + (uint64_t)S.width[s] * first;
+                up_err = hipMemcpyAsync((uint8_t*)c.d_in + o, in + o, (size_t)(S.width[s] * count), hipMemcpyHostToDevice,
+                                        c.stream);
+            }
+            if (up_err == hipSuccess)
+                rc = device_range(format, true, c.d_in, (uint8_t*)c.d_out + first * B, blocks, first, count, mode, sa, sc,
+                                  c.stream);
+        }
+        if (up_err == hipSuccess && rc == DXTLT_OK)
+            up_err = hipEventRecord(ev[(size_t)k], c.stream);
+        {
+            std::lock_guard<std::mutex> lk(sh.m);
+            if (up_err == hipSuccess && rc == DXTLT_OK)
+                sh.launched = k + 1;
+            else
+                sh.failed = true;
+        }
+        sh.cv.notify_all();
+        if (up_err != hipSuccess || rc != DXTLT_OK)
+            break;
+    }
+    downloader.join();
+    if (up_err == hipSuccess && rc == DXTLT_OK)
+        up_err = hipStreamSynchronize(c.stream);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(down);
+    if (rc != DXTLT_OK)
+        return rc;
+    if (up_err != hipSuccess)
+        return fail(DXTLT_E_DEVICE, "pipelined upload/launch", up_err);
+    if (down_err != hipSuccess)
+        return fail(DXTLT_E_DEVICE, "pipelined download", down_err);
+    return DXTLT_OK;
+}
+
 }  // namespace
 
 int32_t dxtlt_host::acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream)
@@ -186,6 +307,8 @@ int32_t dxtlt_host::transform(int32_t format, bool inverse, const uint8_t* in, u
     if (rc != DXTLT_OK)
         return rc;
     const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
+    if (len >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0)
+        return pipelined_transform(c, format, inverse, in, out, blocks, mode, sa, sc);
     HIP_TRY(hipMemcpyAsync(c.d_in, in, len, hipMemcpyHostToDevice, c.stream), "H2D copy");
     rc = device_range(format, inverse, c.d_in, c.d_out, blocks, 0, blocks, mode, sa, sc, c.stream);
     if (rc != DXTLT_OK)

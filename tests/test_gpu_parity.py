@@ -275,6 +275,25 @@ def test_host_pointer_entry_points(pkg, oracle, dev, fmt):
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
+def test_host_pointer_chunked_pipeline(pkg, oracle, dev, fmt):
+    """Buffers of 32 MiB and more take the chunked upload / kernel / download pipeline (two host threads, block-range
+    kernels): several chunks, a ragged last chunk, an odd block count."""
+    for nbytes_target in ((32 << 20), (100 << 20) + 48 * BLOCK[fmt] + BLOCK[fmt]):
+        n = nbytes_target // BLOCK[fmt]
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x919E + n)
+        for s in [(1, 1, 1), (0, 0, 0), (3, 0, 1)]:
+            st = pkg_settings(pkg, fmt, s)
+            y = np.zeros_like(x)
+            getattr(pkg, f"transform_{fmt}_with_settings")(x, y, st)
+            want = np.empty_like(x)
+            oracle.run_mt(fmt, x, want, s[0], bool(s[2]), bool(s[1]), False, 8)
+            assert np.array_equal(y, want), (fmt, n, settings_id(s))
+            z = np.zeros_like(x)
+            getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, st)
+            assert np.array_equal(z, x), (fmt, n, settings_id(s), "inverse")
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
 def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
     n = 9 * 2048 + 123
     x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x5AAD0 + n)
