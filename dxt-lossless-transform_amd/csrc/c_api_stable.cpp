@@ -1,5 +1,6 @@
-// c_api_stable.cpp -- the reference's STABLE C API for BC1 and BC2 (dltbc1_*, dltbc2_*: 13 symbols each), served by
-// the gfx950 path.  Declarations and reference citations: include/dltbc1.h, include/dltbc2.h.
+// c_api_stable.cpp -- the reference's STABLE C API for BC1 and BC2 (dltbc1_*, dltbc2_*: 13 symbols each) and an additive
+// BC3 twin (dltbc3_*, 14 symbols), served by the gfx950 path.  Declarations and reference citations:
+// include/dltbc1.h, include/dltbc2.h, include/dltbc3.h.
 //
 // Builders are plain heap objects holding settings in CORE numbering; the stable YCoCgVariant numbering
 // (Variant1=0, Variant2=1, Variant3=2, None=3; api-common/src/reexports/color_565.rs:65-91) is converted at the
@@ -38,6 +39,7 @@ struct StableResult {
 struct ManualBuilder {
     uint8_t mode_core = 1;
     bool split_colour = true;
+    bool split_alpha = true;  // BC3 only (Bc3TransformSettings default, bc3 settings.rs:39-48)
 };
 
 struct AutoBuilder {
@@ -80,8 +82,8 @@ StableResult manual_run(int32_t format, bool inverse, const uint8_t* input, size
         return {kInvalidLength};
     if (output_len < input_len)
         return {kOutputBufferTooSmall};
-    return {map_status(dxtlt_host::transform(format, inverse, input, output, input_len, b->mode_core, false,
-                                             b->split_colour))};
+    return {map_status(dxtlt_host::transform(format, inverse, input, output, input_len, b->mode_core,
+                                             format == 3 && b->split_alpha, b->split_colour))};
 }
 
 StableResult auto_run(int32_t format, AutoBuilder* b, const uint8_t* data, size_t data_len, uint8_t* output,
@@ -111,6 +113,7 @@ StableResult auto_run(int32_t format, AutoBuilder* b, const uint8_t* data, size_
         return {kAllocationFailed};
     m->mode_core = c.mode;
     m->split_colour = c.split_colour;
+    m->split_alpha = c.split_alpha;
     *out_manual = m;
     return {kSuccess};
 }
@@ -192,6 +195,12 @@ extern "C" {
 
 DLT_STABLE_API(1, 1)
 DLT_STABLE_API(2, 2)
+DLT_STABLE_API(3, 3)  // additive: the reference's bc3-api crate is empty (include/dltbc3.h)
+
+void dltbc3_ManualTransformBuilder_SetSplitAlphaEndpoints(ManualBuilder* b, bool split)
+{
+    if (b) b->split_alpha = split;
+}
 
 // error.rs:131-175 (bc1) -- static strings
 const char* dltbc1_error_message(int32_t code)
@@ -200,6 +209,14 @@ const char* dltbc1_error_message(int32_t code)
                    "Null pointer provided for Dltbc1TransformSettings parameter",
                    "Null pointer provided for Dltbc1ManualTransformBuilder parameter",
                    "Null pointer provided for Dltbc1EstimateSettingsBuilder parameter");
+}
+
+const char* dltbc3_error_message(int32_t code)
+{
+    return message(code, "Invalid input length: Length must be divisible by 16 (BC3 block size)",
+                   "Null pointer provided for Dltbc3TransformSettings parameter",
+                   "Null pointer provided for Dltbc3ManualTransformBuilder parameter",
+                   "Null pointer provided for Dltbc3EstimateSettingsBuilder parameter");
 }
 
 const char* dltbc2_error_message(int32_t code)

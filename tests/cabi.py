@@ -37,7 +37,7 @@ def bind(lib):
             f.argtypes, f.restype = [vp, sz, vp, sz, S], Result
         f = getattr(lib, f"dltbc{n}core_transform_auto")
         f.argtypes, f.restype = [vp, sz, vp, sz, C.POINTER(DltSizeEstimator), AutoSettings, C.POINTER(S)], Result
-    for n in (1, 2):
+    for n in (1, 2, 3):
         p = f"dltbc{n}_"
         getattr(lib, p + "new_ManualTransformBuilder").argtypes = []
         getattr(lib, p + "new_ManualTransformBuilder").restype = vp
@@ -64,6 +64,8 @@ def bind(lib):
         f.argtypes, f.restype = [vp, vp, sz, vp, sz, C.POINTER(vp)], Result
         f = getattr(lib, p + "error_message")
         f.argtypes, f.restype = [C.c_int32], C.c_char_p
+    lib.dltbc3_ManualTransformBuilder_SetSplitAlphaEndpoints.argtypes = [vp, C.c_bool]
+    lib.dltbc3_ManualTransformBuilder_SetSplitAlphaEndpoints.restype = None
     return lib
 
 

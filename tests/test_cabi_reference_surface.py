@@ -55,7 +55,7 @@ def test_core_auto_null_checks(lib, n, S):
     assert f(x.ctypes.data, 32, y.ctypes.data, 16, C.byref(est), a, C.byref(out)).ErrorCode == 6
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_stable_manual_builder_lifecycle_and_checks(lib, n):
     p = f"dltbc{n}_"
     b = getattr(lib, p + "new_ManualTransformBuilder")()
@@ -83,7 +83,7 @@ def test_stable_manual_builder_lifecycle_and_checks(lib, n):
     getattr(lib, p + "free_ManualTransformBuilder")(c)
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_stable_auto_builder_checks(lib, n):
     p = f"dltbc{n}_"
     assert getattr(lib, p + "new_AutoTransformBuilder")(None) is None

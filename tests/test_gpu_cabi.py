@@ -50,22 +50,24 @@ def test_core_transform_untransform(lib, oracle, n):
             assert r.ErrorCode == 0 and np.array_equal(z, x)
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_stable_manual_builder(lib, oracle, n):
     fmt = FMT[n]
     p = f"dltbc{n}_"
     x = oracle.fill_splitmix64(3001 * BLOCK[fmt], 77)
     b = getattr(lib, p + "new_ManualTransformBuilder")()
     y = np.zeros_like(x)
-    # defaults: Variant1 + split (bc1-api manual_transform_builder.rs:24-36)
+    # defaults: Variant1 + split (bc1-api manual_transform_builder.rs:24-36; BC3: + split alphas)
     assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, x.size, y.ctypes.data, y.size, b).ErrorCode == 0
     assert np.array_equal(y, oracle.transform(fmt, x, 1, True))
-    for v, _, sc in all_settings(fmt):
+    for v, sa, sc in all_settings(fmt):
         getattr(lib, p + "ManualTransformBuilder_SetDecorrelationMode")(b, STABLE_OF_CORE[v])
         getattr(lib, p + "ManualTransformBuilder_SetSplitColourEndpoints")(b, bool(sc))
+        if n == 3:
+            lib.dltbc3_ManualTransformBuilder_SetSplitAlphaEndpoints(b, bool(sa))
         c = getattr(lib, p + "clone_ManualTransformBuilder")(b)
         assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, x.size, y.ctypes.data, y.size, b).ErrorCode == 0
-        assert np.array_equal(y, oracle.transform(fmt, x, v, sc)), (v, sc)
+        assert np.array_equal(y, oracle.transform(fmt, x, v, sc, sa if n == 3 else True)), (v, sa, sc)
         z = np.zeros_like(x)
         assert getattr(lib, p + "ManualTransformBuilder_Untransform")(y.ctypes.data, y.size, z.ctypes.data, z.size, c).ErrorCode == 0
         assert np.array_equal(z, x)
@@ -115,7 +117,7 @@ def test_core_auto_estimator_failures(lib, n):
         assert r.ErrorCode == 7  # SizeEstimationError
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_stable_auto_builder(lib, oracle, n):
     fmt = FMT[n]
     p = f"dltbc{n}_"
