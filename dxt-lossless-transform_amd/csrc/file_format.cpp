@@ -1,0 +1,332 @@
+// file_format.cpp -- TransformHeader embed/unembed and the DDS container handler (include/dxtlt_file_formats.h).
+// Host-side byte bookkeeping; the texture payload goes through the gfx950 path (host_common.h).
+// Reference citations for every rule are in the header.
+#include "../../include/dxtlt_file_formats.h"
+
+#include <cstring>
+
+#include "host_common.h"
+
+namespace {
+
+inline uint32_t rd32(const uint8_t* p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+inline void wr32(uint8_t* p, uint32_t v)
+{
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+// embed/formats/bc1.rs: Variant1=0, Variant2=1, Variant3=2, None=3 in the header; core numbering is None=0, 1, 2, 3
+inline uint32_t core_to_header_variant(uint8_t core) { return core == 0 ? 3u : (uint32_t)(core - 1); }
+inline uint8_t header_to_core_variant(uint32_t v) { return v == 3 ? 0 : (uint8_t)(v + 1); }
+
+// dds/constants.rs
+constexpr uint32_t kDdsMagic = 0x20534444;
+constexpr size_t kDdsHeaderSize = 0x80, kDx10HeaderSize = 20;
+constexpr size_t kFlagsOff = 0x08, kHeightOff = 0x0C, kWidthOff = 0x10, kMipOff = 0x1C, kPfFlagsOff = 0x50,
+                 kFourccOff = 0x54, kBitCountOff = 0x58, kRMaskOff = 0x5C, kGMaskOff = 0x60, kBMaskOff = 0x64,
+                 kAMaskOff = 0x68, kDx10FormatOff = 0x80;
+constexpr uint32_t kDdsdMipmapCount = 0x20000;
+constexpr uint32_t kDdpfAlphaPixels = 0x1, kDdpfAlpha = 0x2, kDdpfFourcc = 0x4, kDdpfRgb = 0x40, kDdpfYuv = 0x200,
+                   kDdpfLuminance = 0x20000;
+
+constexpr uint32_t fourcc(char a, char b, char c, char d)
+{
+    return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24);
+}
+
+bool likely_dds(const uint8_t* p, size_t len) { return len >= kDdsHeaderSize && rd32(p) == kDdsMagic; }
+
+// saturating u32 add (the reference uses u32::saturating_add on the running total; the products wrap)
+inline uint32_t sat_add(uint32_t a, uint32_t b) { return a + b < a ? 0xFFFFFFFFu : a + b; }
+
+bool pixel_length(uint32_t w, uint32_t h, uint32_t mips, uint32_t bpp, uint32_t* out)
+{
+    if (bpp == 0)
+        return false;
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < mips; ++i) {
+        total = sat_add(total, w * h * bpp);
+        w = w / 2 > 1 ? w / 2 : 1;
+        h = h / 2 > 1 ? h / 2 : 1;
+    }
+    *out = total;
+    return true;
+}
+
+bool block_length(uint8_t fmt, uint32_t w, uint32_t h, uint32_t mips, uint32_t* out)
+{
+    const uint32_t block = (fmt == BC1 || fmt == BC4) ? 8 : 16;
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < mips; ++i) {
+        const uint32_t bw = w / 4 + (w % 4 != 0), bh = h / 4 + (h % 4 != 0);
+        total = sat_add(total, bw * bh * block);
+        w = w / 2 > 1 ? w / 2 : 1;
+        h = h / 2 > 1 ? h / 2 : 1;
+    }
+    *out = total;
+    return true;
+}
+
+uint8_t detect_uncompressed(const uint8_t* d)
+{
+    const uint32_t flags = rd32(d + kPfFlagsOff), bits = rd32(d + kBitCountOff);
+    const uint32_t r = rd32(d + kRMaskOff), g = rd32(d + kGMaskOff), b = rd32(d + kBMaskOff), a = rd32(d + kAMaskOff);
+    if (bits == 24)
+        return (r == 0x00FF0000 && g == 0x0000FF00 && b == 0x000000FF && a == 0) ? BGR888 : Unknown;
+    if (bits == 32 && (flags & kDdpfAlphaPixels)) {
+        if (r == 0x000000FF && g == 0x0000FF00 && b == 0x00FF0000 && a == 0xFF000000)
+            return RGBA8888;
+        if (r == 0x00FF0000 && g == 0x0000FF00 && b == 0x000000FF && a == 0xFF000000)
+            return BGRA8888;
+    }
+    return Unknown;
+}
+
+// parse_dds_ignore_magic (parse_dds.rs:79-); returns false for "None"
+bool parse_ignore_magic(const uint8_t* d, size_t len, DdsInfo* info)
+{
+    if (len < kDdsHeaderSize)
+        return false;
+    const uint32_t cc = rd32(d + kFourccOff);
+    uint8_t fmt;
+    size_t off;
+    if (cc == fourcc('D', 'X', '1', '0')) {
+        if (len < kDdsHeaderSize + kDx10HeaderSize)
+            return false;
+        const uint32_t dxgi = rd32(d + kDx10FormatOff);
+        if (dxgi >= 70 && dxgi <= 72) fmt = BC1;
+        else if (dxgi >= 73 && dxgi <= 75) fmt = BC2;
+        else if (dxgi >= 76 && dxgi <= 78) fmt = BC3;
+        else if (dxgi >= 79 && dxgi <= 81) fmt = BC4;
+        else if (dxgi >= 82 && dxgi <= 84) fmt = BC5;
+        else if (dxgi >= 94 && dxgi <= 96) fmt = BC6H;
+        else if (dxgi >= 97 && dxgi <= 99) fmt = BC7;
+        else if (dxgi >= 27 && dxgi <= 32) fmt = RGBA8888;
+        else if (dxgi == 87 || dxgi == 90 || dxgi == 91) fmt = BGRA8888;
+        else fmt = Unknown;
+        off = kDdsHeaderSize + kDx10HeaderSize;
+    } else {
+        const uint32_t pf = rd32(d + kPfFlagsOff);
+        if (pf & kDdpfFourcc) {
+            if (cc == fourcc('D', 'X', 'T', '1')) fmt = BC1;
+            else if (cc == fourcc('D', 'X', 'T', '2') || cc == fourcc('D', 'X', 'T', '3')) fmt = BC2;
+            else if (cc == fourcc('D', 'X', 'T', '4') || cc == fourcc('D', 'X', 'T', '5')) fmt = BC3;
+            else if (cc == fourcc('B', 'C', '4', 'U') || cc == fourcc('B', 'C', '4', 'S') || cc == fourcc('A', 'T', 'I', '1')) fmt = BC4;
+            else if (cc == fourcc('B', 'C', '5', 'U') || cc == fourcc('B', 'C', '5', 'S') || cc == fourcc('A', 'T', 'I', '2')) fmt = BC5;
+            else fmt = Unknown;
+        } else if (pf & kDdpfRgb) {
+            fmt = detect_uncompressed(d);
+        } else {
+            fmt = Unknown;
+        }
+        off = kDdsHeaderSize;
+    }
+
+    // calculate_data_length (parse_dds.rs:190-)
+    const uint32_t flags = rd32(d + kFlagsOff), height = rd32(d + kHeightOff), width = rd32(d + kWidthOff);
+    const uint32_t raw_mips = rd32(d + kMipOff);
+    const uint32_t mips = (flags & kDdsdMipmapCount) ? (raw_mips > 1 ? raw_mips : 1) : 1;
+    uint32_t length = 0;
+    bool ok = true;
+    switch (fmt) {
+    case BC1: case BC2: case BC3: case BC4: case BC5: case BC6H: case BC7:
+        ok = block_length(fmt, width, height, mips, &length);
+        break;
+    case RGBA8888: case BGRA8888:
+        ok = pixel_length(width, height, mips, 4, &length);
+        break;
+    case BGR888:
+        ok = pixel_length(width, height, mips, 3, &length);
+        break;
+    default: {  // Unknown: try the pixel format (calculate_uncompressed_data_length)
+        const uint32_t pf = rd32(d + kPfFlagsOff), bits = rd32(d + kBitCountOff);
+        if ((pf & (kDdpfRgb | kDdpfLuminance | kDdpfYuv | kDdpfAlpha)) == 0 || bits % 8 != 0)
+            ok = false;
+        else
+            ok = pixel_length(width, height, mips, bits / 8, &length);
+        break;
+    }
+    }
+    info->Format = (DdsFormat)fmt;
+    info->DataOffset = (uint8_t)off;
+    info->DataLength = ok ? length : 0;  // unwrap_or(0)
+    return true;
+}
+
+int32_t map_device_status(int32_t st)
+{
+    if (st == dxtlt_host::kOk) return DXTLT_FF_OK;
+    if (st == dxtlt_host::kInvalidLength) return DXTLT_FF_INVALID_DATA_ALIGNMENT;
+    if (st == dxtlt_host::kEstimator || st == dxtlt_host::kAllocation) return DXTLT_FF_ESTIMATOR_FAILED;
+    return DXTLT_FF_TRANSFORM_FAILED;
+}
+
+// format_conversion.rs: only BC1/BC2 upstream; BC3 additive here
+int dds_to_bcn(uint8_t fmt) { return fmt == BC1 ? 1 : fmt == BC2 ? 2 : fmt == BC3 ? 3 : 0; }
+
+int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len,
+                             const DltSizeEstimator* estimator, bool use_all, uint8_t mode, bool sa, bool sc)
+{
+    if (input == nullptr || output == nullptr)
+        return DXTLT_FF_NULL_POINTER;
+    if (output_len < input_len)
+        return DXTLT_FF_OUTPUT_TOO_SMALL;
+    DdsInfo info;
+    if (!likely_dds(input, input_len) || !parse_ignore_magic(input, input_len, &info))
+        return DXTLT_FF_INVALID_INPUT_HEADER;
+    const size_t off = info.DataOffset, length = info.DataLength;
+    if (input_len < off + length)
+        return DXTLT_FF_INPUT_TOO_SHORT;
+    const int bcn = dds_to_bcn(info.Format);
+    if (bcn == 0)
+        return DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT;
+    if (length % (bcn == 1 ? 8 : 16) != 0)
+        return DXTLT_FF_INVALID_DATA_ALIGNMENT;
+    if (bcn != 3)
+        sa = false;
+
+    std::memcpy(output, input, off);
+    int32_t st;
+    if (estimator != nullptr) {
+        dxtlt_host::AutoChoice c{};
+        st = dxtlt_host::transform_auto(bcn, input + off, output + off, length, estimator, use_all, &c);
+        mode = c.mode;
+        sa = c.split_alpha;
+        sc = c.split_colour;
+    } else {
+        if (mode > 3)
+            return DXTLT_FF_CORRUPTED_EMBEDDED_DATA;
+        st = dxtlt_host::transform(bcn, false, input + off, output + off, length, mode, sa, sc);
+    }
+    if (st != dxtlt_host::kOk)
+        return map_device_status(st);
+    if (input_len > off + length)
+        std::memcpy(output + off + length, input + off + length, input_len - off - length);
+    wr32(output, dxtlt_transform_header_pack(bcn - 1, mode, sa, sc));  // overwrites the 'DDS ' magic
+    return DXTLT_FF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t dxtlt_transform_header_pack(int32_t transform_format, uint8_t mode, bool sa, bool sc)
+{
+    uint32_t data = 0;  // header_version 0 in bits 0-1
+    if (transform_format == DXTLT_TF_BC1 || transform_format == DXTLT_TF_BC2) {
+        data |= (sc ? 1u : 0u) << 2;
+        data |= core_to_header_variant(mode & 3) << 3;
+    } else if (transform_format == DXTLT_TF_BC3) {  // additive layout, see the header file
+        data |= (sa ? 1u : 0u) << 2;
+        data |= (sc ? 1u : 0u) << 3;
+        data |= core_to_header_variant(mode & 3) << 4;
+    }
+    return ((uint32_t)transform_format & 0xF) | (data << 4);
+}
+
+int32_t dxtlt_transform_header_unpack(uint32_t header, int32_t* transform_format, uint8_t* mode, bool* sa, bool* sc)
+{
+    const uint32_t fmt = header & 0xF, data = header >> 4;
+    if ((data & 3) != 0)
+        return DXTLT_FF_CORRUPTED_EMBEDDED_DATA;  // unknown header version
+    uint8_t m = 0;
+    bool a = false, c = false;
+    if (fmt == DXTLT_TF_BC1 || fmt == DXTLT_TF_BC2) {
+        c = (data >> 2) & 1;
+        m = header_to_core_variant((data >> 3) & 3);
+    } else if (fmt == DXTLT_TF_BC3) {
+        a = (data >> 2) & 1;
+        c = (data >> 3) & 1;
+        m = header_to_core_variant((data >> 4) & 3);
+    } else {
+        return DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT;
+    }
+    if (transform_format) *transform_format = (int32_t)fmt;
+    if (mode) *mode = m;
+    if (sa) *sa = a;
+    if (sc) *sc = c;
+    return DXTLT_FF_OK;
+}
+
+bool is_dds(const uint8_t* ptr, size_t len)
+{
+    if (ptr == nullptr || len == 0)
+        return false;
+    return likely_dds(ptr, len);
+}
+
+DdsInfo parse_dds(const uint8_t* ptr, size_t len)
+{
+    DdsInfo none;
+    none.Format = (DdsFormat)NotADds;
+    none.DataOffset = 0;
+    none.DataLength = 0;
+    if (ptr == nullptr || len == 0 || !likely_dds(ptr, len))
+        return none;
+    DdsInfo info = none;
+    if (!parse_ignore_magic(ptr, len, &info))
+        return none;
+    return info;
+}
+
+int32_t dxtlt_dds_transform(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len, uint8_t mode,
+                            bool sa, bool sc)
+{
+    return dds_transform_common(input, input_len, output, output_len, nullptr, false, mode, sa, sc);
+}
+
+int32_t dxtlt_dds_transform_auto(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len,
+                                 const DltSizeEstimator* estimator, bool use_all)
+{
+    if (estimator == nullptr)
+        return DXTLT_FF_NULL_POINTER;
+    return dds_transform_common(input, input_len, output, output_len, estimator, use_all, 0, false, false);
+}
+
+int32_t dxtlt_dds_untransform(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len)
+{
+    if (input == nullptr || output == nullptr)
+        return DXTLT_FF_NULL_POINTER;
+    if (input_len < DXTLT_TRANSFORM_HEADER_SIZE)
+        return DXTLT_FF_INPUT_TOO_SHORT;
+    if (output_len < input_len)
+        return DXTLT_FF_OUTPUT_TOO_SMALL;
+    const uint32_t header = rd32(input);
+    DdsInfo info;
+    if (!parse_ignore_magic(input, input_len, &info))
+        return DXTLT_FF_INVALID_INPUT_HEADER;
+    const size_t off = info.DataOffset, length = info.DataLength;
+    if (input_len < off + length)
+        return DXTLT_FF_INPUT_TOO_SHORT;
+
+    int32_t tf = 0;
+    uint8_t mode = 0;
+    bool sa = false, sc = false;
+    // dispatch_untransform (handlers/dispatch.rs:39-): format first, then the details, then the alignment
+    if ((header & 0xF) > DXTLT_TF_BC3)
+        return DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT;
+    int32_t rc = dxtlt_transform_header_unpack(header, &tf, &mode, &sa, &sc);
+    if (rc != DXTLT_FF_OK)
+        return rc;
+    const int bcn = tf + 1;
+    if (length % (bcn == 1 ? 8 : 16) != 0)
+        return DXTLT_FF_INVALID_DATA_ALIGNMENT;
+
+    wr32(output, kDdsMagic);
+    std::memcpy(output + 4, input + 4, off - 4);
+    int32_t st = dxtlt_host::transform(bcn, true, input + off, output + off, length, mode, sa, sc);
+    if (st != dxtlt_host::kOk)
+        return map_device_status(st);
+    if (input_len > off + length)
+        std::memcpy(output + off + length, input + off + length, input_len - off - length);
+    return DXTLT_FF_OK;
+}
+
+}  // extern "C"

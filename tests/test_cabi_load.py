@@ -17,7 +17,7 @@ def declared_symbols():
         text = open(h).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         text = re.sub(r"//[^\n]*", "", text)
-        for m in re.finditer(r"\b((?:dxtlt|dltbc\d(?:core)?)_\w+)\s*\(", text):
+        for m in re.finditer(r"\b((?:dxtlt|dltbc\d(?:core)?)_\w+|is_dds|parse_dds)\s*\(", text):
             names.add(m.group(1))
     return sorted(names)
 

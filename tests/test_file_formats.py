@@ -1,0 +1,209 @@
+"""File-format layer: TransformHeader bit layout, DDS parsing (CPU only) and the DDS handler
+round trip (GPU).  Mirrors the reference's tests: embed/mod.rs:204-256, embed/formats/bc1.rs tests, dds/parse_dds.rs
+tests, dds/likely_dds.rs tests, handler/file_format_handler.rs tests."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import cabi
+from helpers import GOLDEN, all_settings
+
+
+class DdsInfo(C.Structure):
+    _fields_ = [("Format", C.c_uint8), ("DataOffset", C.c_uint8), ("DataLength", C.c_uint32)]
+
+
+NOT_A_DDS, UNKNOWN, BC1, BC2, BC3, BC6H, BC7, RGBA8888, BGRA8888, BGR888, BC4, BC5 = range(12)
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    l = C.CDLL(pkg._lib.lib_path())
+    vp, sz = C.c_void_p, C.c_size_t
+    l.dxtlt_transform_header_pack.argtypes = [C.c_int32, C.c_uint8, C.c_bool, C.c_bool]
+    l.dxtlt_transform_header_pack.restype = C.c_uint32
+    l.dxtlt_transform_header_unpack.argtypes = [C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                                C.POINTER(C.c_bool), C.POINTER(C.c_bool)]
+    l.dxtlt_transform_header_unpack.restype = C.c_int32
+    l.is_dds.argtypes, l.is_dds.restype = [vp, sz], C.c_bool
+    l.parse_dds.argtypes, l.parse_dds.restype = [vp, sz], DdsInfo
+    l.dxtlt_dds_transform.argtypes = [vp, sz, vp, sz, C.c_uint8, C.c_bool, C.c_bool]
+    l.dxtlt_dds_transform.restype = C.c_int32
+    l.dxtlt_dds_transform_auto.argtypes = [vp, sz, vp, sz, C.POINTER(cabi.DltSizeEstimator), C.c_bool]
+    l.dxtlt_dds_transform_auto.restype = C.c_int32
+    l.dxtlt_dds_untransform.argtypes = [vp, sz, vp, sz]
+    l.dxtlt_dds_untransform.restype = C.c_int32
+    return l
+
+
+def dds_file(fmt: str) -> np.ndarray:
+    h = np.fromfile(os.path.join(GOLDEN, f"r2-256-{fmt}.header.bin"), dtype=np.uint8)
+    p = np.fromfile(os.path.join(GOLDEN, f"r2-256-{fmt}.payload.bin"), dtype=np.uint8)
+    return np.concatenate([h, p])
+
+
+def legacy_header(fourcc: bytes, width: int, height: int, mips: int = 0, pf_flags: int = 0x4) -> bytearray:
+    h = bytearray(128)
+    h[0:4] = b"DDS "
+    struct.pack_into("<I", h, 4, 124)
+    flags = 0x1 | 0x2 | 0x4 | 0x1000 | (0x20000 if mips else 0)
+    struct.pack_into("<III", h, 8, flags, height, width)
+    struct.pack_into("<I", h, 0x1C, mips)
+    struct.pack_into("<II", h, 0x4C, 32, pf_flags)
+    h[0x54:0x58] = fourcc
+    return h
+
+
+# ---- TransformHeader ---------------------------------------------------------------------------------------
+def test_header_bit_layout(lib):
+    # format in bits 0-3, data in bits 4-31 (embed/mod.rs:105-120); BC1 data = version:2 | split:1 | variant:2 with
+    # Variant1=0, Variant2=1, Variant3=2, None=3 (embed/formats/bc1.rs:34-60)
+    assert lib.dxtlt_transform_header_pack(0, 1, False, True) == 0x40           # BC1, Variant1 + split
+    assert lib.dxtlt_transform_header_pack(0, 0, False, False) == (3 << 3) << 4  # BC1, None, no split
+    assert lib.dxtlt_transform_header_pack(1, 2, False, True) == 1 | ((1 << 2 | 1 << 3) << 4)  # BC2, Variant2 + split
+    assert lib.dxtlt_transform_header_pack(0, 3, False, False) == (2 << 3) << 4  # BC1, Variant3
+    for fmt, has_alpha in ((0, False), (1, False), (2, True)):
+        for v in range(4):
+            for sa in ((False, True) if has_alpha else (False,)):
+                for sc in (False, True):
+                    h = lib.dxtlt_transform_header_pack(fmt, v, sa, sc)
+                    assert h & 0xF == fmt and (h >> 4) & 3 == 0  # format code, header version 0
+                    f, m, a, c = C.c_int32(), C.c_uint8(), C.c_bool(), C.c_bool()
+                    assert lib.dxtlt_transform_header_unpack(h, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 0
+                    assert (f.value, m.value, a.value, c.value) == (fmt, v, sa, sc)
+
+
+def test_header_rejects_bad_version_and_format(lib):
+    f, m, a, c = C.c_int32(), C.c_uint8(), C.c_bool(), C.c_bool()
+    bad_version = 0 | (3 << 4)  # bc1.rs test_invalid_header_version: only version 0 is valid
+    assert lib.dxtlt_transform_header_unpack(bad_version, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 5
+    assert lib.dxtlt_transform_header_unpack(0x3, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 4  # BC7
+    assert lib.dxtlt_transform_header_unpack(0xF, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 4
+
+
+# ---- DDS parsing -------------------------------------------------------------------------------------------
+def test_is_dds(lib):
+    # likely_dds.rs tests: magic + at least 128 bytes
+    ok = np.frombuffer(b"DDS " + bytes(124), dtype=np.uint8)
+    assert lib.is_dds(ok.ctypes.data, ok.size)
+    assert not lib.is_dds(ok.ctypes.data, 127)
+    bad = np.frombuffer(b"DDX " + bytes(124), dtype=np.uint8)
+    assert not lib.is_dds(bad.ctypes.data, bad.size)
+    assert not lib.is_dds(None, 128) and not lib.is_dds(ok.ctypes.data, 0)
+
+
+def test_parse_real_textures(lib):
+    for fmt, code, length in (("bc1", BC1, 32768), ("bc2", BC2, 65536), ("bc3", BC3, 65536)):
+        d = dds_file(fmt)
+        info = lib.parse_dds(d.ctypes.data, d.size)
+        assert (info.Format, info.DataOffset, info.DataLength) == (code, 128, length)
+    info = lib.parse_dds(None, 0)
+    assert (info.Format, info.DataOffset, info.DataLength) == (NOT_A_DDS, 0, 0)
+
+
+@pytest.mark.parametrize("fourcc,code", [(b"DXT1", BC1), (b"DXT2", BC2), (b"DXT3", BC2), (b"DXT4", BC3),
+                                         (b"DXT5", BC3), (b"ATI1", BC4), (b"BC4U", BC4), (b"ATI2", BC5),
+                                         (b"BC5S", BC5), (b"ABCD", UNKNOWN)])
+def test_parse_legacy_fourcc(lib, fourcc, code):
+    # parse_dds.rs parse_dds_handles_legacy_formats
+    h = np.frombuffer(bytes(legacy_header(fourcc, 4, 4)) + bytes(16), dtype=np.uint8)
+    info = lib.parse_dds(h.ctypes.data, h.size)
+    assert info.Format == code and info.DataOffset == 128
+
+
+@pytest.mark.parametrize("dxgi,code", [(70, BC1), (71, BC1), (72, BC1), (74, BC2), (77, BC3), (80, BC4), (83, BC5),
+                                       (95, BC6H), (98, BC7), (28, RGBA8888), (87, BGRA8888), (2, UNKNOWN)])
+def test_parse_dx10(lib, dxgi, code):
+    h = legacy_header(b"DX10", 8, 8)
+    ext = bytearray(20)
+    struct.pack_into("<I", ext, 0, dxgi)
+    d = np.frombuffer(bytes(h) + bytes(ext) + bytes(64), dtype=np.uint8)
+    info = lib.parse_dds(d.ctypes.data, d.size)
+    assert info.Format == code and info.DataOffset == 148
+    short = np.frombuffer(bytes(h) + bytes(10), dtype=np.uint8)  # DX10 header cut short -> not parseable
+    assert lib.parse_dds(short.ctypes.data, short.size).Format == NOT_A_DDS
+
+
+@pytest.mark.parametrize("w,h,mips,fourcc,want", [
+    (4, 4, 0, b"DXT1", 8), (256, 256, 0, b"DXT1", 32768), (256, 256, 9, b"DXT1", 43704),
+    (5, 7, 0, b"DXT5", 2 * 2 * 16), (1, 1, 1, b"DXT3", 16), (16, 4, 3, b"DXT1", (4 * 1 + 2 * 1 + 1 * 1) * 8),
+])
+def test_block_data_length(lib, w, h, mips, fourcc, want):
+    # calculate_data_length_for_block_compression: ceil(w/4)*ceil(h/4)*block per level, halving down to 1x1
+    d = np.frombuffer(bytes(legacy_header(fourcc, w, h, mips)) + bytes(16), dtype=np.uint8)
+    assert lib.parse_dds(d.ctypes.data, d.size).DataLength == want
+
+
+def test_uncompressed_formats(lib):
+    def rgb(bits, masks, flags):
+        hd = legacy_header(b"\0\0\0\0", 4, 2, 0, flags)
+        struct.pack_into("<IIIII", hd, 0x58, bits, *masks)
+        return np.frombuffer(bytes(hd) + bytes(64), dtype=np.uint8)
+    d = rgb(32, (0xFF, 0xFF00, 0xFF0000, 0xFF000000), 0x41)
+    i = lib.parse_dds(d.ctypes.data, d.size)
+    assert (i.Format, i.DataLength) == (RGBA8888, 32)
+    d = rgb(32, (0xFF0000, 0xFF00, 0xFF, 0xFF000000), 0x41)
+    assert lib.parse_dds(d.ctypes.data, d.size).Format == BGRA8888
+    d = rgb(24, (0xFF0000, 0xFF00, 0xFF, 0), 0x40)
+    i = lib.parse_dds(d.ctypes.data, d.size)
+    assert (i.Format, i.DataLength) == (BGR888, 24)
+    d = rgb(16, (0xF800, 0x7E0, 0x1F, 0), 0x40)  # RGB565: unknown format, length from the bit count
+    i = lib.parse_dds(d.ctypes.data, d.size)
+    assert (i.Format, i.DataLength) == (UNKNOWN, 16)
+
+
+def test_handler_argument_checks(lib):
+    d = dds_file("bc1")
+    out = np.zeros(d.size, dtype=np.uint8)
+    assert lib.dxtlt_dds_transform(d.ctypes.data, d.size, out.ctypes.data, d.size - 1, 1, False, True) == 1
+    notdds = np.zeros(200, dtype=np.uint8)
+    assert lib.dxtlt_dds_transform(notdds.ctypes.data, 200, out.ctypes.data, out.size, 1, False, True) == 2
+    assert lib.dxtlt_dds_transform(d.ctypes.data, d.size - 100, out.ctypes.data, out.size, 1, False, True) == 3  # truncated
+    bc7 = np.frombuffer(bytes(legacy_header(b"DX10", 4, 4)) + struct.pack("<I", 98) + bytes(16) + bytes(16), dtype=np.uint8)
+    assert lib.dxtlt_dds_transform(bc7.ctypes.data, bc7.size, out.ctypes.data, out.size, 1, False, True) == 4
+    assert lib.dxtlt_dds_untransform(d.ctypes.data, 3, out.ctypes.data, out.size) == 3
+    assert lib.dxtlt_dds_untransform(d.ctypes.data, d.size, out.ctypes.data, 10) == 1
+    assert lib.dxtlt_dds_transform(None, 10, out.ctypes.data, out.size, 1, False, True) == 9
+
+
+# ---- DDS handler end to end ----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["bc1", "bc2", "bc3"])
+def test_dds_roundtrip_all_settings(lib, oracle, fmt):
+    d = np.concatenate([dds_file(fmt), np.arange(37, dtype=np.uint8)])  # trailing bytes are copied verbatim
+    payload = d[128:-37]
+    for v, sa, sc in all_settings(fmt):
+        t = np.zeros_like(d)
+        assert lib.dxtlt_dds_transform(d.ctypes.data, d.size, t.ctypes.data, t.size, v, bool(sa), bool(sc)) == 0
+        # magic replaced by the TransformHeader, the rest of the header and the tail untouched, payload transformed
+        want_header = lib.dxtlt_transform_header_pack({"bc1": 0, "bc2": 1, "bc3": 2}[fmt], v, bool(sa), bool(sc))
+        assert struct.unpack("<I", t[:4].tobytes())[0] == want_header
+        assert np.array_equal(t[4:128], d[4:128]) and np.array_equal(t[-37:], d[-37:])
+        assert np.array_equal(t[128:-37], oracle.transform(fmt, payload, v, sc, sa))
+        assert not lib.is_dds(t.ctypes.data, t.size)
+        r = np.zeros_like(d)
+        assert lib.dxtlt_dds_untransform(t.ctypes.data, t.size, r.ctypes.data, r.size) == 0
+        assert np.array_equal(r, d)
+
+
+@pytest.mark.gpu
+def test_dds_auto_transform(lib, oracle):
+    from oracle import oracle_auto
+
+    for fmt in ("bc1", "bc2", "bc3"):
+        d = dds_file(fmt)
+        est, py_est = cabi.make_estimator("zlib")
+        choice, want, _ = oracle_auto.transform_auto(fmt, d[128:], lambda b: py_est(bytes(b)), False)
+        t = np.zeros_like(d)
+        assert lib.dxtlt_dds_transform_auto(d.ctypes.data, d.size, t.ctypes.data, t.size, C.byref(est), False) == 0
+        assert np.array_equal(t[128:], want)
+        f, m, a, c = C.c_int32(), C.c_uint8(), C.c_bool(), C.c_bool()
+        hdr = struct.unpack("<I", t[:4].tobytes())[0]
+        assert lib.dxtlt_transform_header_unpack(hdr, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 0
+        assert (m.value, int(a.value), int(c.value)) == choice
+        r = np.zeros_like(d)
+        assert lib.dxtlt_dds_untransform(t.ctypes.data, t.size, r.ctypes.data, r.size) == 0
+        assert np.array_equal(r, d)
