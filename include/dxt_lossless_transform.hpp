@@ -1,0 +1,362 @@
+// dxt_lossless_transform.hpp -- C++17 host-side mirror of the reference's Rust API for the BCn transform path,
+// header-only over the C ABI of libdxtlt_gfx950.so (dxtlt_gfx950.h).
+//
+// The reference is a Rust workspace and this image has no Rust toolchain, so the host layer a Rust user would see is
+// restated here in C++ with the same names, argument meaning and error behaviour (paths under /root/reference/src/):
+//
+//   core::YCoCgVariant                 core/dxt-lossless-transform-common/src/color_565/decorrelate.rs:72-84
+//   core::Bc{1,2,3}TransformSettings   core/dxt-lossless-transform-bc{1,2,3}/src/transform/settings.rs:16-48
+//   core::transform_bcN_with_settings  core/.../transform/transform_with_settings.rs:31,92 (bc2 :30,93; bc3 :32,162)
+//   core::*_safe + BcNValidationError  core/.../transform/safe/transform_with_settings.rs:18-31,88,192
+//   core::transform_bcN_auto           core/.../transform/transform_auto.rs:200 (bc2/bc3 :196)
+//   api::YCoCgVariant (renumbered)     api/dxt-lossless-transform-api-common/src/reexports/color_565.rs:65-91
+//   api::Bc{1,2}ManualTransformBuilder api/dxt-lossless-transform-bc1-api/src/transform/manual_transform_builder.rs:18-150
+//   api::Bc{1,2}AutoTransformBuilder   api/dxt-lossless-transform-bc1-api/src/transform/auto_transform_builder.rs:15-130
+//   api::Bc{1,2}Error                  api/dxt-lossless-transform-bc1-api/src/error.rs:11-35
+//
+// Differences forced by the device: the reference's unsafe fns cannot fail; here a device/runtime failure throws
+// dxt_lossless_transform::DeviceError (never a silent CPU fallback -- there is none in this library).
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "dxtlt_gfx950.h"
+
+namespace dxt_lossless_transform {
+
+struct DeviceError : std::runtime_error {
+    int32_t code;
+    DeviceError(int32_t c, const char* what) : std::runtime_error(what), code(c) {}
+};
+
+namespace detail {
+inline void check_device(int32_t rc)
+{
+    if (rc != DXTLT_OK)
+        throw DeviceError(rc, dxtlt_last_error());
+}
+}  // namespace detail
+
+// =====================================================================================================
+// core crates (unstable API)
+// =====================================================================================================
+namespace core {
+
+enum class YCoCgVariant : uint8_t { None = 0, Variant1 = 1, Variant2 = 2, Variant3 = 3 };
+
+struct Bc1TransformSettings {
+    YCoCgVariant decorrelation_mode = YCoCgVariant::Variant1;  // Default: settings.rs:35-43
+    bool split_colour_endpoints = true;
+    bool operator==(const Bc1TransformSettings& o) const
+    {
+        return decorrelation_mode == o.decorrelation_mode && split_colour_endpoints == o.split_colour_endpoints;
+    }
+    bool operator!=(const Bc1TransformSettings& o) const { return !(*this == o); }
+    // settings.rs:68 -- every variant x {true, false}
+    static std::array<Bc1TransformSettings, 8> all_combinations()
+    {
+        std::array<Bc1TransformSettings, 8> a{};
+        int i = 0;
+        for (int v = 0; v < 4; ++v)
+            for (bool s : {true, false})
+                a[i++] = {static_cast<YCoCgVariant>(v), s};
+        return a;
+    }
+};
+using Bc1UntransformSettings = Bc1TransformSettings;  // settings.rs:33
+using Bc2TransformSettings = Bc1TransformSettings;    // same fields and defaults (bc2 settings.rs:16)
+using Bc2UntransformSettings = Bc2TransformSettings;
+
+struct Bc3TransformSettings {
+    YCoCgVariant decorrelation_mode = YCoCgVariant::Variant1;  // Default: bc3 settings.rs:39-48
+    bool split_alpha_endpoints = true;
+    bool split_colour_endpoints = true;
+    bool operator==(const Bc3TransformSettings& o) const
+    {
+        return decorrelation_mode == o.decorrelation_mode && split_alpha_endpoints == o.split_alpha_endpoints &&
+               split_colour_endpoints == o.split_colour_endpoints;
+    }
+    static std::array<Bc3TransformSettings, 16> all_combinations()  // bc3 settings.rs:74
+    {
+        std::array<Bc3TransformSettings, 16> a{};
+        int i = 0;
+        for (int v = 0; v < 4; ++v)
+            for (bool sa : {true, false})
+                for (bool sc : {true, false})
+                    a[i++] = {static_cast<YCoCgVariant>(v), sa, sc};
+        return a;
+    }
+};
+using Bc3UntransformSettings = Bc3TransformSettings;
+
+// ---- unsafe pointer API: len must be a multiple of the block size, buffers must not overlap ----
+inline void transform_bc1_with_settings(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, Bc1TransformSettings s)
+{
+    detail::check_device(dxtlt_transform_bc1_with_settings(input_ptr, output_ptr, len, (uint8_t)s.decorrelation_mode,
+                                                           s.split_colour_endpoints));
+}
+inline void untransform_bc1_with_settings(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, Bc1UntransformSettings s)
+{
+    detail::check_device(dxtlt_untransform_bc1_with_settings(input_ptr, output_ptr, len, (uint8_t)s.decorrelation_mode,
+                                                             s.split_colour_endpoints));
+}
+inline void transform_bc2_with_settings(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, Bc2TransformSettings s)
+{
+    detail::check_device(dxtlt_transform_bc2_with_settings(input_ptr, output_ptr, len, (uint8_t)s.decorrelation_mode,
+                                                           s.split_colour_endpoints));
+}
+inline void untransform_bc2_with_settings(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, Bc2UntransformSettings s)
+{
+    detail::check_device(dxtlt_untransform_bc2_with_settings(input_ptr, output_ptr, len, (uint8_t)s.decorrelation_mode,
+                                                             s.split_colour_endpoints));
+}
+inline void transform_bc3_with_settings(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, Bc3TransformSettings s)
+{
+    detail::check_device(dxtlt_transform_bc3_with_settings(input_ptr, output_ptr, len, (uint8_t)s.decorrelation_mode,
+                                                           s.split_alpha_endpoints, s.split_colour_endpoints));
+}
+inline void untransform_bc3_with_settings(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, Bc3UntransformSettings s)
+{
+    detail::check_device(dxtlt_untransform_bc3_with_settings(input_ptr, output_ptr, len, (uint8_t)s.decorrelation_mode,
+                                                             s.split_alpha_endpoints, s.split_colour_endpoints));
+}
+
+// ---- safe slice API: Result<(), BcNValidationError> ----
+struct ValidationError {  // Bc1ValidationError / Bc2ValidationError / Bc3ValidationError
+    enum Kind { Ok, InvalidLength, OutputBufferTooSmall } kind = Ok;
+    size_t length = 0;  // InvalidLength(len)
+    size_t needed = 0;  // OutputBufferTooSmall { needed, actual }
+    size_t actual = 0;
+    bool is_ok() const { return kind == Ok; }
+    bool is_err() const { return kind != Ok; }
+};
+
+namespace detail_safe {
+inline ValidationError validate(size_t in_len, size_t out_len, size_t block)
+{
+    // order of safe/transform_with_settings.rs:93-105: length first, then output size
+    ValidationError e;
+    if (in_len % block != 0) {
+        e.kind = ValidationError::InvalidLength;
+        e.length = in_len;
+    } else if (out_len < in_len) {
+        e.kind = ValidationError::OutputBufferTooSmall;
+        e.needed = in_len;
+        e.actual = out_len;
+    }
+    return e;
+}
+}  // namespace detail_safe
+
+#define DXTLT_SAFE_PAIR(N, BLOCK, SETTINGS)                                                                           \
+    inline ValidationError transform_bc##N##_with_settings_safe(const uint8_t* input, size_t input_len, uint8_t* output, \
+                                                                size_t output_len, SETTINGS s)                       \
+    {                                                                                                                \
+        ValidationError e = detail_safe::validate(input_len, output_len, BLOCK);                                     \
+        if (e.is_ok()) transform_bc##N##_with_settings(input, output, input_len, s);                                 \
+        return e;                                                                                                    \
+    }                                                                                                                \
+    inline ValidationError untransform_bc##N##_with_settings_safe(const uint8_t* input, size_t input_len,            \
+                                                                  uint8_t* output, size_t output_len, SETTINGS s)    \
+    {                                                                                                                \
+        ValidationError e = detail_safe::validate(input_len, output_len, BLOCK);                                     \
+        if (e.is_ok()) untransform_bc##N##_with_settings(input, output, input_len, s);                               \
+        return e;                                                                                                    \
+    }
+DXTLT_SAFE_PAIR(1, 8, Bc1TransformSettings)
+DXTLT_SAFE_PAIR(2, 16, Bc2TransformSettings)
+DXTLT_SAFE_PAIR(3, 16, Bc3TransformSettings)
+#undef DXTLT_SAFE_PAIR
+
+// ---- transform_bcN_auto: any estimator type with
+//        bool max_compressed_size(size_t len, size_t& out)          (false = error)
+//        bool estimate_compressed_size(const uint8_t* in, size_t len, uint8_t* scratch, size_t scratch_len, size_t& out)
+//      (the shape of SizeEstimationOperations, api-common/src/estimate/mod.rs:24) ----
+struct DetermineBestTransformError {
+    enum Kind { Ok, AllocateError, SizeEstimationError } kind = Ok;
+    bool is_ok() const { return kind == Ok; }
+};
+
+template <class Estimator>
+struct EstimateSettings {  // Bc1EstimateSettings<T> etc. (transform_auto.rs)
+    Estimator size_estimator;
+    bool use_all_decorrelation_modes = false;
+};
+
+namespace detail_auto {
+template <class E>
+uint32_t max_trampoline(void* ctx, size_t len, size_t* out)
+{
+    return static_cast<E*>(ctx)->max_compressed_size(len, *out) ? 0u : 1u;
+}
+template <class E>
+uint32_t est_trampoline(void* ctx, const uint8_t* in, size_t len, uint8_t* scratch, size_t scratch_len, size_t* out)
+{
+    return static_cast<E*>(ctx)->estimate_compressed_size(in, len, scratch, scratch_len, *out) ? 0u : 1u;
+}
+template <class E>
+DltSizeEstimator make_vtable(E& e)
+{
+    DltSizeEstimator v;
+    v.Context = &e;
+    v.MaxCompressedSize = &max_trampoline<E>;
+    v.EstimateCompressedSize = &est_trampoline<E>;
+    return v;
+}
+inline DetermineBestTransformError map(int32_t rc)
+{
+    DetermineBestTransformError e;
+    if (rc == DXTLT_OK) return e;
+    if (rc == DXTLT_E_ESTIMATOR) { e.kind = DetermineBestTransformError::SizeEstimationError; return e; }
+    if (rc == DXTLT_E_ALLOCATION) { e.kind = DetermineBestTransformError::AllocateError; return e; }
+    throw DeviceError(rc, dxtlt_last_error());
+}
+}  // namespace detail_auto
+
+template <class E>
+std::pair<Bc1TransformSettings, DetermineBestTransformError> transform_bc1_auto(const uint8_t* input_ptr, uint8_t* output_ptr,
+                                                                                size_t len, EstimateSettings<E>& options)
+{
+    DltSizeEstimator v = detail_auto::make_vtable(options.size_estimator);
+    uint8_t mode = 1;
+    bool sc = true;
+    int32_t rc = dxtlt_transform_bc1_auto(input_ptr, output_ptr, len, &v, options.use_all_decorrelation_modes, &mode, &sc, nullptr);
+    return {Bc1TransformSettings{static_cast<YCoCgVariant>(mode), sc}, detail_auto::map(rc)};
+}
+template <class E>
+std::pair<Bc2TransformSettings, DetermineBestTransformError> transform_bc2_auto(const uint8_t* input_ptr, uint8_t* output_ptr,
+                                                                                size_t len, EstimateSettings<E>& options)
+{
+    DltSizeEstimator v = detail_auto::make_vtable(options.size_estimator);
+    uint8_t mode = 1;
+    bool sc = true;
+    int32_t rc = dxtlt_transform_bc2_auto(input_ptr, output_ptr, len, &v, options.use_all_decorrelation_modes, &mode, &sc, nullptr);
+    return {Bc2TransformSettings{static_cast<YCoCgVariant>(mode), sc}, detail_auto::map(rc)};
+}
+template <class E>
+std::pair<Bc3TransformSettings, DetermineBestTransformError> transform_bc3_auto(const uint8_t* input_ptr, uint8_t* output_ptr,
+                                                                                size_t len, EstimateSettings<E>& options)
+{
+    DltSizeEstimator v = detail_auto::make_vtable(options.size_estimator);
+    uint8_t mode = 1;
+    bool sa = true, sc = true;
+    int32_t rc = dxtlt_transform_bc3_auto(input_ptr, output_ptr, len, &v, options.use_all_decorrelation_modes, &mode, &sa, &sc, nullptr);
+    return {Bc3TransformSettings{static_cast<YCoCgVariant>(mode), sa, sc}, detail_auto::map(rc)};
+}
+
+}  // namespace core
+
+// =====================================================================================================
+// api crates (stable API): builders.  NOTE the different YCoCgVariant numbering.
+// =====================================================================================================
+namespace api {
+
+enum class YCoCgVariant : uint8_t { Variant1 = 0, Variant2 = 1, Variant3 = 2, None = 3 };
+
+inline core::YCoCgVariant to_internal_variant(YCoCgVariant v)
+{
+    switch (v) {
+    case YCoCgVariant::Variant1: return core::YCoCgVariant::Variant1;
+    case YCoCgVariant::Variant2: return core::YCoCgVariant::Variant2;
+    case YCoCgVariant::Variant3: return core::YCoCgVariant::Variant3;
+    default: return core::YCoCgVariant::None;
+    }
+}
+inline YCoCgVariant from_internal_variant(core::YCoCgVariant v)
+{
+    switch (v) {
+    case core::YCoCgVariant::Variant1: return YCoCgVariant::Variant1;
+    case core::YCoCgVariant::Variant2: return YCoCgVariant::Variant2;
+    case core::YCoCgVariant::Variant3: return YCoCgVariant::Variant3;
+    default: return YCoCgVariant::None;
+    }
+}
+
+struct Error {  // Bc1Error<E> / Bc2Error<E> (error.rs:11-35)
+    enum Kind { Ok, InvalidLength, OutputBufferTooSmall, AllocationFailed, SizeEstimationFailed } kind = Ok;
+    size_t length = 0, needed = 0, actual = 0;
+    bool is_ok() const { return kind == Ok; }
+    bool is_err() const { return kind != Ok; }
+    static Error from(const core::ValidationError& v)
+    {
+        Error e;
+        if (v.kind == core::ValidationError::InvalidLength) { e.kind = InvalidLength; e.length = v.length; }
+        if (v.kind == core::ValidationError::OutputBufferTooSmall) { e.kind = OutputBufferTooSmall; e.needed = v.needed; e.actual = v.actual; }
+        return e;
+    }
+};
+
+#define DXTLT_MANUAL_BUILDER(N)                                                                                        \
+    class Bc##N##ManualTransformBuilder {                                                                              \
+    public:                                                                                                            \
+        Bc##N##ManualTransformBuilder() = default; /* new(): Variant1 + split */                                       \
+        Bc##N##ManualTransformBuilder decorrelation_mode(YCoCgVariant mode) const                                      \
+        {                                                                                                              \
+            Bc##N##ManualTransformBuilder b = *this;                                                                   \
+            b.settings_.decorrelation_mode = to_internal_variant(mode);                                                \
+            return b;                                                                                                  \
+        }                                                                                                              \
+        Bc##N##ManualTransformBuilder split_colour_endpoints(bool split) const                                         \
+        {                                                                                                              \
+            Bc##N##ManualTransformBuilder b = *this;                                                                   \
+            b.settings_.split_colour_endpoints = split;                                                                \
+            return b;                                                                                                  \
+        }                                                                                                              \
+        Error transform(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len) const              \
+        {                                                                                                              \
+            return Error::from(core::transform_bc##N##_with_settings_safe(input, input_len, output, output_len, settings_)); \
+        }                                                                                                              \
+        Error untransform(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len) const            \
+        {                                                                                                              \
+            return Error::from(core::untransform_bc##N##_with_settings_safe(input, input_len, output, output_len, settings_)); \
+        }                                                                                                              \
+        const core::Bc##N##TransformSettings& settings() const { return settings_; }                                   \
+                                                                                                                       \
+    private:                                                                                                           \
+        core::Bc##N##TransformSettings settings_{};                                                                    \
+    };                                                                                                                 \
+                                                                                                                       \
+    template <class Estimator>                                                                                         \
+    class Bc##N##AutoTransformBuilder {                                                                                \
+    public:                                                                                                            \
+        explicit Bc##N##AutoTransformBuilder(Estimator e) : options_{std::move(e), false} {}                           \
+        static Bc##N##AutoTransformBuilder new_ultra(Estimator e)                                                      \
+        {                                                                                                              \
+            Bc##N##AutoTransformBuilder b(std::move(e));                                                               \
+            b.options_.use_all_decorrelation_modes = true;                                                             \
+            return b;                                                                                                  \
+        }                                                                                                              \
+        Bc##N##AutoTransformBuilder& use_all_decorrelation_modes(bool use_all)                                         \
+        {                                                                                                              \
+            options_.use_all_decorrelation_modes = use_all;                                                            \
+            return *this;                                                                                              \
+        }                                                                                                              \
+        /* Ok -> a manual builder configured with the chosen settings (auto_transform_builder.rs:123) */               \
+        std::pair<Bc##N##ManualTransformBuilder, Error> transform(const uint8_t* input, size_t input_len, uint8_t* output, \
+                                                                  size_t output_len)                                   \
+        {                                                                                                              \
+            Error e = Error::from(core::detail_safe::validate(input_len, output_len, N == 1 ? 8 : 16));                \
+            if (e.is_err()) return {Bc##N##ManualTransformBuilder(), e};                                               \
+            auto r = core::transform_bc##N##_auto(input, output, input_len, options_);                                 \
+            if (r.second.kind == core::DetermineBestTransformError::SizeEstimationError) e.kind = Error::SizeEstimationFailed; \
+            if (r.second.kind == core::DetermineBestTransformError::AllocateError) e.kind = Error::AllocationFailed;   \
+            Bc##N##ManualTransformBuilder m = Bc##N##ManualTransformBuilder()                                          \
+                                                  .decorrelation_mode(from_internal_variant(r.first.decorrelation_mode)) \
+                                                  .split_colour_endpoints(r.first.split_colour_endpoints);             \
+            return {m, e};                                                                                             \
+        }                                                                                                              \
+                                                                                                                       \
+    private:                                                                                                           \
+        core::EstimateSettings<Estimator> options_;                                                                    \
+    };
+DXTLT_MANUAL_BUILDER(1)
+DXTLT_MANUAL_BUILDER(2)
+#undef DXTLT_MANUAL_BUILDER
+
+}  // namespace api
+}  // namespace dxt_lossless_transform

@@ -1,0 +1,153 @@
+// C++ host API (include/dxt_lossless_transform.hpp) test program, driven by tests/test_cpp_api.py.
+//   test_cpp_api cpu   -- validation paths only (no device needed)
+//   test_cpp_api gpu   -- round trips on the device, reference-generator inputs
+// The reference's own tests this mirrors: bc1 transform/safe/transform_with_settings.rs tests (:225-330),
+// bc1-api transform/manual_transform_builder.rs and auto_transform_builder.rs tests.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dxt_lossless_transform.hpp"
+
+using namespace dxt_lossless_transform;
+
+static int failures = 0;
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond);     \
+            ++failures;                                                    \
+        }                                                                  \
+    } while (0)
+
+// reference generator for BC1 (bc1 test_prelude.rs:81-105)
+static std::vector<uint8_t> gen_bc1(size_t blocks)
+{
+    std::vector<uint8_t> d(blocks * 8);
+    uint8_t c = 0, i = 128;
+    for (size_t b = 0; b < blocks; ++b) {
+        for (int k = 0; k < 4; ++k) {
+            d[b * 8 + k] = (uint8_t)(c + k);
+            d[b * 8 + 4 + k] = (uint8_t)(i + k);
+        }
+        c = (uint8_t)(c + 4);
+        i = (uint8_t)(i + 4);
+    }
+    return d;
+}
+
+struct DummyEstimator {  // bc1 test_prelude.rs:44-62: max 0, estimate = len
+    int calls = 0;
+    bool max_compressed_size(size_t, size_t& out) { out = 0; return true; }
+    bool estimate_compressed_size(const uint8_t*, size_t len, uint8_t*, size_t, size_t& out) { ++calls; out = len; return true; }
+};
+struct FailingEstimator {  // bc1 transform/mod.rs:120-138
+    bool max_compressed_size(size_t, size_t& out) { out = 0; return true; }
+    bool estimate_compressed_size(const uint8_t*, size_t, uint8_t*, size_t, size_t&) { return false; }
+};
+
+static void cpu_tests()
+{
+    // defaults and combinations
+    core::Bc1TransformSettings d1;
+    CHECK(d1.decorrelation_mode == core::YCoCgVariant::Variant1 && d1.split_colour_endpoints);
+    core::Bc3TransformSettings d3;
+    CHECK(d3.split_alpha_endpoints && d3.split_colour_endpoints);
+    CHECK(core::Bc1TransformSettings::all_combinations().size() == 8);
+    CHECK(core::Bc3TransformSettings::all_combinations().size() == 16);
+    CHECK((int)api::YCoCgVariant::None == 3 && (int)core::YCoCgVariant::None == 0);
+    CHECK(api::to_internal_variant(api::YCoCgVariant::Variant2) == core::YCoCgVariant::Variant2);
+    CHECK(api::from_internal_variant(core::YCoCgVariant::None) == api::YCoCgVariant::None);
+
+    // safe wrappers: length first, then size (no device touched)
+    std::vector<uint8_t> in(24), out(24);
+    auto e = core::transform_bc1_with_settings_safe(in.data(), 12, out.data(), 24, {});
+    CHECK(e.kind == core::ValidationError::InvalidLength && e.length == 12);
+    e = core::transform_bc1_with_settings_safe(in.data(), 24, out.data(), 16, {});
+    CHECK(e.kind == core::ValidationError::OutputBufferTooSmall && e.needed == 24 && e.actual == 16);
+    e = core::untransform_bc3_with_settings_safe(in.data(), 24, out.data(), 1, {});
+    CHECK(e.kind == core::ValidationError::InvalidLength);
+    auto be = api::Bc1ManualTransformBuilder().transform(in.data(), 20, out.data(), 24);
+    CHECK(be.kind == api::Error::InvalidLength);
+    be = api::Bc2ManualTransformBuilder().untransform(in.data(), 16, out.data(), 8);
+    CHECK(be.kind == api::Error::OutputBufferTooSmall);
+    // builder setters are value-returning, like the Rust builder
+    auto b = api::Bc1ManualTransformBuilder().decorrelation_mode(api::YCoCgVariant::None).split_colour_endpoints(false);
+    CHECK(b.settings().decorrelation_mode == core::YCoCgVariant::None && !b.settings().split_colour_endpoints);
+    // zero-length input is Ok and needs no device
+    CHECK(core::transform_bc1_with_settings_safe(in.data(), 0, out.data(), 0, {}).is_ok());
+    // auto builder validates before estimating
+    api::Bc1AutoTransformBuilder<DummyEstimator> ab{DummyEstimator{}};
+    CHECK(ab.transform(in.data(), 20, out.data(), 24).second.kind == api::Error::InvalidLength);
+}
+
+static void gpu_tests()
+{
+    const size_t blocks = 3001;
+    std::vector<uint8_t> x = gen_bc1(blocks), y(x.size()), z(x.size());
+    for (auto s : core::Bc1TransformSettings::all_combinations()) {
+        CHECK(core::transform_bc1_with_settings_safe(x.data(), x.size(), y.data(), y.size(), s).is_ok());
+        CHECK(core::untransform_bc1_with_settings_safe(y.data(), y.size(), z.data(), z.size(), s).is_ok());
+        CHECK(z == x);
+        // index stream is verbatim in the second half for every setting
+        bool idx_ok = true;
+        for (size_t b = 0; b < blocks && idx_ok; ++b)
+            idx_ok = std::memcmp(&y[4 * blocks + 4 * b], &x[8 * b + 4], 4) == 0;
+        CHECK(idx_ok);
+    }
+    // hand-derived vector: generator n=3, Variant1 + split
+    std::vector<uint8_t> g = gen_bc1(3), t(24);
+    core::transform_bc1_with_settings(g.data(), t.data(), 24, {});
+    const uint8_t want[24] = {0x04, 0x10, 0x02, 0x9f, 0x50, 0xe6, 0x9b, 0xf7, 0x89, 0xbe, 0xd7, 0x05,
+                              0x80, 0x81, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x8b};
+    CHECK(std::memcmp(t.data(), want, 24) == 0);
+
+    // BC2 / BC3 round trips through the pointer API
+    std::vector<uint8_t> w(16 * 1777), w2(w.size()), w3(w.size());
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (uint8_t)(i * 131 + (i >> 7));
+    for (auto s : core::Bc3TransformSettings::all_combinations()) {
+        core::transform_bc3_with_settings(w.data(), w2.data(), w.size(), s);
+        core::untransform_bc3_with_settings(w2.data(), w3.data(), w.size(), s);
+        CHECK(w3 == w);
+    }
+    for (auto s : core::Bc2TransformSettings::all_combinations()) {
+        core::transform_bc2_with_settings(w.data(), w2.data(), w.size(), s);
+        core::untransform_bc2_with_settings(w2.data(), w3.data(), w.size(), s);
+        CHECK(w3 == w);
+    }
+
+    // builders (stable API)
+    auto mb = api::Bc1ManualTransformBuilder().decorrelation_mode(api::YCoCgVariant::Variant3).split_colour_endpoints(false);
+    CHECK(mb.transform(x.data(), x.size(), y.data(), y.size()).is_ok());
+    CHECK(mb.untransform(y.data(), y.size(), z.data(), z.size()).is_ok());
+    CHECK(z == x);
+
+    // auto: constant estimator -> strict '<' keeps the first candidate (None, no split); 4 candidates tried
+    api::Bc1AutoTransformBuilder<DummyEstimator> ab{DummyEstimator{}};
+    auto r = ab.transform(x.data(), x.size(), y.data(), y.size());
+    CHECK(r.second.is_ok());
+    CHECK(r.first.settings().decorrelation_mode == core::YCoCgVariant::None && !r.first.settings().split_colour_endpoints);
+    CHECK(r.first.untransform(y.data(), y.size(), z.data(), z.size()).is_ok());
+    CHECK(z == x);
+    auto ultra = api::Bc2AutoTransformBuilder<DummyEstimator>::new_ultra(DummyEstimator{});
+    CHECK(ultra.transform(w.data(), w.size(), w2.data(), w2.size()).second.is_ok());
+    api::Bc1AutoTransformBuilder<FailingEstimator> fb{FailingEstimator{}};
+    CHECK(fb.transform(x.data(), x.size(), y.data(), y.size()).second.kind == api::Error::SizeEstimationFailed);
+    core::EstimateSettings<DummyEstimator> es{DummyEstimator{}, true};
+    auto r3 = core::transform_bc3_auto(w.data(), w2.data(), w.size(), es);
+    CHECK(r3.second.is_ok() && es.size_estimator.calls == 32);  // 16 candidates x (alpha + colour endpoints)
+}
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    try {
+        cpu_tests();
+        if (gpu) gpu_tests();
+    } catch (const DeviceError& e) {
+        std::printf("DeviceError %d: %s\n", e.code, e.what());
+        return 2;
+    }
+    std::printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", failures);
+    return failures ? 1 : 0;
+}

@@ -293,6 +293,44 @@ def test_host_pointer_chunked_pipeline(pkg, oracle, dev, fmt):
             assert np.array_equal(z, x), (fmt, n, settings_id(s), "inverse")
 
 
+def test_concurrent_callers(pkg, oracle, dev):
+    """The reference's functions are reentrant and its CLI calls them from rayon workers, one file per task
+    (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:166-184).  Eight threads hammer the host-pointer
+    entry points with different formats, sizes and settings at once; every result must be exact."""
+    import threading
+
+    jobs = []
+    for i in range(8):
+        fmt = FORMATS[i % 3]
+        n = 1000 + 7919 * i + (i % 2) * 300_000
+        s = list(all_settings(fmt))[(5 * i) % (16 if fmt == "bc3" else 8)]
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x7EAD + i)
+        jobs.append((fmt, s, x, fwd_oracle(oracle, fmt, x, s)))
+    errors = []
+
+    def work(fmt, s, x, want):
+        try:
+            st = pkg_settings(pkg, fmt, s)
+            for _ in range(6):
+                y = np.zeros_like(x)
+                getattr(pkg, f"transform_{fmt}_with_settings")(x, y, st)
+                if not np.array_equal(y, want):
+                    raise AssertionError(f"{fmt} {s}: forward mismatch")
+                z = np.zeros_like(x)
+                getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, st)
+                if not np.array_equal(z, x):
+                    raise AssertionError(f"{fmt} {s}: inverse mismatch")
+        except Exception as e:  # noqa: BLE001 - collected and re-raised on the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
     n = 9 * 2048 + 123
