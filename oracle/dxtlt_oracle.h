@@ -100,6 +100,13 @@ uint64_t oracle_sum_u64(const uint8_t *data, size_t len_bytes);
 void oracle_run_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t len, int variant,
                    int split_alpha, int split_colour, int threads);
 
+/* BC7 mode-split transform, version 0 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has no
+ * BC7 transform, so these two are a definition, not a restatement: PARITY UNPINNED.  (dxtlt_oracle_bc7.c) */
+void oracle_transform_bc7(const uint8_t *in, uint8_t *out, size_t len);
+void oracle_untransform_bc7(const uint8_t *in, uint8_t *out, size_t len);
+/* force a valid mode marker into byte 0 of every block: mode = (byte 15 & 7) */
+void oracle_bc7_force_modes(uint8_t *blocks, size_t len);
+
 #ifdef __cplusplus
 }
 #endif

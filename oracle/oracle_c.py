@@ -20,12 +20,11 @@ OK, INVALID_LENGTH, OUTPUT_TOO_SMALL = 0, 1, 2
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (``make -C oracle``) if the .so is missing or stale."""
-    src = os.path.join(_HERE, "dxtlt_oracle.c")
-    hdr = os.path.join(_HERE, "dxtlt_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("dxtlt_oracle.c", "dxtlt_oracle_bc7.c", "dxtlt_oracle.h")]
     stale = (
         force
         or not os.path.exists(_SO)
-        or (os.path.exists(src) and os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+        or any(os.path.exists(f) and os.path.getmtime(_SO) < os.path.getmtime(f) for f in srcs)
     )
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libdxtlt_oracle.so"], stdout=subprocess.DEVNULL)
@@ -71,6 +70,11 @@ def lib() -> C.CDLL:
         l.oracle_sum_u64.restype = C.c_uint64
         l.oracle_run_mt.argtypes = [i, i, u8p, u8p, sz, i, i, i, i]
         l.oracle_run_mt.restype = None
+        for n in ("oracle_transform_bc7", "oracle_untransform_bc7"):
+            getattr(l, n).argtypes = [u8p, u8p, sz]
+            getattr(l, n).restype = None
+        l.oracle_bc7_force_modes.argtypes = [u8p, sz]
+        l.oracle_bc7_force_modes.restype = None
         _lib = l
     return _lib
 
@@ -154,3 +158,19 @@ def decorrelate(v: int, variant: int) -> int:
 
 def recorrelate(v: int, variant: int) -> int:
     return int(lib().oracle_recorrelate_565(v, variant))
+
+
+def transform_bc7(data, inverse: bool = False) -> np.ndarray:
+    """BC7 mode-split transform v0 (docs/BC7_FORMAT.md) -- this build's own format, parity unpinned."""
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % 16 == 0
+    out = np.empty_like(a)
+    (lib().oracle_untransform_bc7 if inverse else lib().oracle_transform_bc7)(_ptr(a), _ptr(out), a.size)
+    return out
+
+
+def bc7_force_modes(data: np.ndarray) -> np.ndarray:
+    """In place: give every block a valid mode marker, mode = (byte 15 & 7)."""
+    assert data.dtype == np.uint8 and data.size % 16 == 0 and data.flags.c_contiguous
+    lib().oracle_bc7_force_modes(_ptr(data), data.size)
+    return data

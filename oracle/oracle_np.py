@@ -178,3 +178,50 @@ def splitmix64(seed: int, first_qword: int, count: int) -> np.ndarray:
         z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & m
         z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & m
         return z ^ (z >> np.uint64(31))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BC7 mode-split transform, version 0 (docs/BC7_FORMAT.md) -- a format defined by this build; parity unpinned.
+# ------------------------------------------------------------------------------------------------------------
+BC7_HEAD = np.array([9, 9, 11, 11, 5, 7, 7, 11, 15])
+
+
+def bc7_modes(first: np.ndarray) -> np.ndarray:
+    """mode = trailing zero count of byte 0, 8 when byte 0 is zero"""
+    f = first.astype(np.int64)
+    low = f & -f  # lowest set bit, 0 for 0
+    m = np.full(f.shape, 8, dtype=np.int64)
+    nz = low != 0
+    m[nz] = np.log2(low[nz]).astype(np.int64)
+    return m
+
+
+def transform_bc7(data) -> np.ndarray:
+    blk = _u8(data).reshape(-1, 16)
+    modes = bc7_modes(blk[:, 0])
+    parts = [blk[:, 0].copy()]
+    for m in range(9):
+        sel = blk[modes == m]
+        h = BC7_HEAD[m]
+        parts.append(sel[:, 1:1 + h].reshape(-1))
+        parts.append(sel[:, 1 + h:].reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def untransform_bc7(data) -> np.ndarray:
+    a = _u8(data)
+    n = a.size // 16
+    first = a[:n]
+    modes = bc7_modes(first)
+    out = np.empty((n, 16), dtype=np.uint8)
+    out[:, 0] = first
+    pos = n
+    for m in range(9):
+        idx = np.nonzero(modes == m)[0]
+        h = int(BC7_HEAD[m])
+        c = idx.size
+        out[idx, 1:1 + h] = a[pos:pos + c * h].reshape(c, h)
+        pos += c * h
+        out[idx, 1 + h:] = a[pos:pos + c * (15 - h)].reshape(c, 15 - h)
+        pos += c * (15 - h)
+    return out.reshape(-1)
