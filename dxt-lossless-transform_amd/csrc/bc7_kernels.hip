@@ -29,7 +29,7 @@ constexpr int kThreads = 256;
 constexpr int kTileBlocks = 1024;  // 16 KiB of blocks per workgroup
 constexpr int kVecs = kTileBlocks / kThreads;
 constexpr int kGroupTiles = 1024;  // tiles per scan group
-constexpr int kImageBytes = 15 * kTileBlocks + 18 * 32;
+constexpr int kImageBytes = 15 * kTileBlocks + 18 * 32;  // pieces + (31 bytes of slack each, rounded up)
 
 __device__ __forceinline__ int head_bytes(int m)
 {
@@ -203,16 +203,21 @@ bc7_scan(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, u
 // 4. scatter / gather
 // ---------------------------------------------------------------------------------------------------------
 struct TileTables {
-    uint32_t slot[16][9];   // per (vector j, wave w) slot: blocks of mode m in earlier slots of this tile
-    uint32_t count[9];      // blocks of mode m in this tile
+    uint32_t raw[16][9];    // per (vector j, wave w) slot: blocks of mode m in that slot
+    uint32_t slot[16][9];   // ... exclusive prefix over the slots (= blocks of mode m earlier in this tile)
     int lds_off[18];        // LDS offset of piece r (congruent to its global address modulo 16)
     int bytes[18];
     int seg_prefix[19];     // 16-byte segments of the pieces, flattened
     uint64_t g_off[18];     // global byte offset of piece r inside the transformed buffer
 };
 
-// ranks of this lane's blocks inside their modes; fills tb.slot (exclusive) and tb.count
-__device__ __forceinline__ void rank_blocks(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables& tb)
+// Ranks of this lane's blocks inside their modes and the tile's piece table, with two workgroup barriers:
+//   ballots -> raw slot counts -> barrier -> 144 lanes turn them into exclusive slot prefixes while lanes 0..17 (wave 0)
+//   derive their piece's size from the same raw counts and lay the 18 pieces out with wave-level prefix sums -> barrier.
+// LDS layout rule: piece r starts at align16(P_r) + (g_off[r] & 15) with P_r = sum over earlier pieces of (bytes + 31),
+// so every piece has room for its own misalignment and its 16-byte segments never touch a neighbour's.
+__device__ __forceinline__ void rank_and_layout(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables& tb,
+                                                uint64_t origin)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -225,25 +230,56 @@ __device__ __forceinline__ void rank_blocks(const int (&mode)[kVecs], uint32_t (
             if (mode[j] == m)
                 rank_in_wave[j] = (uint32_t)__popcll(mask & lt);
             if (lane == 0)
-                tb.slot[j * 4 + wave][m] = (uint32_t)__popcll(mask);
+                tb.raw[j * 4 + wave][m] = (uint32_t)__popcll(mask);
         }
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
-        uint32_t running = 0;
-        for (int s = 0; s < 16; ++s) {
-            const uint32_t c = tb.slot[s][threadIdx.x];
-            tb.slot[s][threadIdx.x] = running;
-            running += c;
+    if (threadIdx.x < 144) {
+        const int sidx = threadIdx.x / 9, m = threadIdx.x - sidx * 9;
+        uint32_t excl = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            excl += i < sidx ? tb.raw[i][m] : 0;
+        tb.slot[sidx][m] = excl;
+    }
+    if (wave == 0) {
+        int bytes = 0, a0 = 0, nseg = 0;
+        if (lane < 18) {
+            const int m = lane < 9 ? lane : lane - 9;
+            const int w = lane < 9 ? head_bytes(m) : 15 - head_bytes(m);
+            uint32_t count = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                count += tb.raw[i][m];
+            bytes = (int)count * w;
+            a0 = (int)(origin & 15);
+            nseg = bytes ? (a0 + bytes + 15) >> 4 : 0;
         }
-        tb.count[threadIdx.x] = running;
+        // inclusive prefix sums over lanes 0..17 of (bytes + 31) and of nseg
+        int p = lane < 18 ? bytes + 31 : 0, q = nseg;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int pu = __shfl_up(p, o), qu = __shfl_up(q, o);
+            if (lane >= o) {
+                p += pu;
+                q += qu;
+            }
+        }
+        if (lane < 18) {
+            const int excl_p = p - (bytes + 31);
+            tb.lds_off[lane] = ((excl_p + 15) & ~15) + a0;
+            tb.bytes[lane] = bytes;
+            tb.g_off[lane] = origin;
+            tb.seg_prefix[lane] = q - nseg;
+            if (lane == 17)
+                tb.seg_prefix[18] = q;
+        }
     }
     __syncthreads();
 }
 
 // piece table: 9 head pieces then 9 tail pieces.  Lanes 0..17 fetch their tile prefix and stream base at kernel entry
-// (fetch_piece_origin), so that this dependent global read overlaps the tile's block loads instead of following
-// them; once the per-tile counts are known one lane lays the pieces out in LDS.
+// (fetch_piece_origin), so that this dependent global read overlaps the tile's block loads instead of following them.
 __device__ __forceinline__ uint64_t fetch_piece_origin(const uint32_t* prefix, const uint64_t* totals, uint64_t num_tiles,
                                                        uint64_t tile, uint64_t n_blocks)
 {
@@ -257,30 +293,6 @@ __device__ __forceinline__ uint64_t fetch_piece_origin(const uint32_t* prefix, c
     if (r >= 9)
         base += totals[m] * (uint64_t)head_bytes(m);
     return base + (uint64_t)prefix[(uint64_t)m * num_tiles + tile] * w;
-}
-
-__device__ __forceinline__ void build_pieces(TileTables& tb, uint64_t origin)
-{
-    if (threadIdx.x < 18) {
-        const int r = threadIdx.x, m = r < 9 ? r : r - 9;
-        const uint32_t w = r < 9 ? head_bytes(m) : 15 - head_bytes(m);
-        tb.g_off[r] = origin;
-        tb.bytes[r] = (int)(tb.count[m] * w);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int running = 0, segs = 0;
-        for (int r = 0; r < 18; ++r) {
-            const int a0 = (int)(tb.g_off[r] & 15);
-            running = ((running + 15) & ~15) + a0;
-            tb.lds_off[r] = running;
-            tb.seg_prefix[r] = segs;
-            segs += tb.bytes[r] ? (a0 + tb.bytes[r] + 15) >> 4 : 0;
-            running += tb.bytes[r];
-        }
-        tb.seg_prefix[18] = segs;
-    }
-    __syncthreads();
 }
 
 // flattened copy of the 18 pieces between LDS and global memory; TO_GLOBAL selects the direction
@@ -343,8 +355,7 @@ bc7_scatter_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, cons
         }
     }
     uint32_t rank_in_wave[kVecs];
-    rank_blocks(mode, rank_in_wave, tb);
-    build_pieces(tb, origin);
+    rank_and_layout(mode, rank_in_wave, tb, origin);
 
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
@@ -388,8 +399,7 @@ bc7_gather_inv(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const
         }
     }
     uint32_t rank_in_wave[kVecs];
-    rank_blocks(mode, rank_in_wave, tb);
-    build_pieces(tb, origin);
+    rank_and_layout(mode, rank_in_wave, tb, origin);
     move_pieces<false>(img, tb, const_cast<uint8_t*>(soa), n_blocks * 16);
     __syncthreads();
 
