@@ -100,6 +100,13 @@ uint64_t oracle_sum_u64(const uint8_t *data, size_t len_bytes);
 void oracle_run_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t len, int variant,
                    int split_alpha, int split_colour, int threads);
 
+/* AVX2 port of the reference's SIMD strategy, BC1 default settings only (Variant1 + split colours), with a scalar
+ * tail; equals oracle_{un,}transform_bc1(..., VAR1, 1) byte for byte.  cpu_baseline leg only.  (dxtlt_oracle_avx2.c) */
+int oracle_simd_available(void);
+void oracle_bc1_default_simd_range(int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first,
+                                   size_t count);
+void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads);
+
 /* BC7 mode-split transform, version 0 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has no
  * BC7 transform, so these two are a definition, not a restatement: PARITY UNPINNED.  (dxtlt_oracle_bc7.c) */
 void oracle_transform_bc7(const uint8_t *in, uint8_t *out, size_t len);

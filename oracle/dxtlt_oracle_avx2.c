@@ -1,0 +1,213 @@
+/*
+ * dxtlt_oracle_avx2.c -- AVX2 port of the reference's SIMD strategy for BC1 default settings (YCoCg Variant1 + split
+ * colour endpoints), forward and inverse.  TEST INFRASTRUCTURE ONLY: it exists so that bench.py's cpu_baseline can also
+ * quote a vectorised CPU figure ("the reference's own SIMD path timed on the GPU box's host cores", BASELINE.json);
+ * tests/test_oracle.py requires it to equal the scalar oracle byte for byte.
+ *
+ * Strategy followed (not code): /root/reference/src/core/dxt-lossless-transform-bc1/src/transform/
+ * with_split_colour_and_recorr/transform/avx2.rs:13-130 -- 16 blocks (128 B) per iteration, dword de-interleave of
+ * colours and indices, YCoCg-R on 16-bit lanes (dxt-lossless-transform-common/src/intrinsics/color_565/decorrelate/
+ * avx2.rs:41-74), c0/c1 word split, four stores; the tail falls through to the scalar loop.  Written from that
+ * description with this file's own shuffle choices.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "dxtlt_oracle.h"
+
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#define HAVE_X86 1
+#else
+#define HAVE_X86 0
+#endif
+
+int oracle_simd_available(void)
+{
+#if HAVE_X86
+    return __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+
+#if HAVE_X86
+
+#define TGT __attribute__((target("avx2")))
+
+/* YCoCg-R variant 1 on sixteen RGB565 values in 16-bit lanes */
+TGT static inline __m256i decorrelate_var1_epi16(__m256i v)
+{
+    const __m256i m5 = _mm256_set1_epi16(0x1F);
+    const __m256i r = _mm256_srli_epi16(v, 11);
+    const __m256i g = _mm256_and_si256(_mm256_srli_epi16(v, 6), m5);
+    const __m256i gl = _mm256_and_si256(v, _mm256_set1_epi16(0x20));
+    const __m256i b = _mm256_and_si256(v, m5);
+    const __m256i co = _mm256_and_si256(_mm256_sub_epi16(r, b), m5);
+    const __m256i t = _mm256_and_si256(_mm256_add_epi16(b, _mm256_srli_epi16(co, 1)), m5);
+    const __m256i cg = _mm256_and_si256(_mm256_sub_epi16(g, t), m5);
+    const __m256i y = _mm256_and_si256(_mm256_add_epi16(t, _mm256_srli_epi16(cg, 1)), m5);
+    return _mm256_or_si256(_mm256_or_si256(_mm256_slli_epi16(y, 11), _mm256_slli_epi16(co, 6)), _mm256_or_si256(gl, cg));
+}
+
+TGT static inline __m256i recorrelate_var1_epi16(__m256i v)
+{
+    const __m256i m5 = _mm256_set1_epi16(0x1F);
+    const __m256i y = _mm256_srli_epi16(v, 11);
+    const __m256i co = _mm256_and_si256(_mm256_srli_epi16(v, 6), m5);
+    const __m256i gl = _mm256_and_si256(v, _mm256_set1_epi16(0x20));
+    const __m256i cg = _mm256_and_si256(v, m5);
+    const __m256i t = _mm256_and_si256(_mm256_sub_epi16(y, _mm256_srli_epi16(cg, 1)), m5);
+    const __m256i g = _mm256_and_si256(_mm256_add_epi16(cg, t), m5);
+    const __m256i b = _mm256_and_si256(_mm256_sub_epi16(t, _mm256_srli_epi16(co, 1)), m5);
+    const __m256i r = _mm256_and_si256(_mm256_add_epi16(b, co), m5);
+    return _mm256_or_si256(_mm256_or_si256(_mm256_slli_epi16(r, 11), _mm256_slli_epi16(g, 6)), _mm256_or_si256(gl, b));
+}
+
+/* blocks [first, first+count) of an n_total-block buffer; count is a multiple of 16 */
+TGT static void bc1_default_fwd_avx2(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    uint8_t *c0 = out + 2 * first, *c1 = out + 2 * n_total + 2 * first, *idx = out + 4 * n_total + 4 * first;
+    const uint8_t *p = in + 8 * first;
+    /* inside each 128-bit lane: low words of the four dwords first, then their high words */
+    const __m256i words = _mm256_setr_epi8(0, 1, 4, 5, 8, 9, 12, 13, 2, 3, 6, 7, 10, 11, 14, 15, 0, 1, 4, 5, 8, 9, 12, 13, 2, 3,
+                                           6, 7, 10, 11, 14, 15);
+    for (size_t i = 0; i < count; i += 16, p += 128, c0 += 32, c1 += 32, idx += 64) {
+        const __m256 a = _mm256_loadu_ps((const float *)(p + 0));   /* blocks 0-3 */
+        const __m256 b = _mm256_loadu_ps((const float *)(p + 32));  /* blocks 4-7 */
+        const __m256 c = _mm256_loadu_ps((const float *)(p + 64));
+        const __m256 d = _mm256_loadu_ps((const float *)(p + 96));
+        /* even dwords = colours, odd dwords = indices; shuffle_ps works per 128-bit lane, permute4x64 restores order */
+        __m256i col_lo = _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(a, b, 0x88)), 0xD8);
+        __m256i col_hi = _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(c, d, 0x88)), 0xD8);
+        const __m256i idx_lo = _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(a, b, 0xDD)), 0xD8);
+        const __m256i idx_hi = _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(c, d, 0xDD)), 0xD8);
+        col_lo = decorrelate_var1_epi16(col_lo);
+        col_hi = decorrelate_var1_epi16(col_hi);
+        /* split (c0,c1) word pairs: [c0 x4 | c1 x4] per lane -> [c0 x8][c1 x8] */
+        const __m256i s_lo = _mm256_permute4x64_epi64(_mm256_shuffle_epi8(col_lo, words), 0xD8);
+        const __m256i s_hi = _mm256_permute4x64_epi64(_mm256_shuffle_epi8(col_hi, words), 0xD8);
+        _mm256_storeu_si256((__m256i *)c0, _mm256_permute2x128_si256(s_lo, s_hi, 0x20));
+        _mm256_storeu_si256((__m256i *)c1, _mm256_permute2x128_si256(s_lo, s_hi, 0x31));
+        _mm256_storeu_si256((__m256i *)idx, idx_lo);
+        _mm256_storeu_si256((__m256i *)(idx + 32), idx_hi);
+    }
+}
+
+TGT static void bc1_default_inv_avx2(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    const uint8_t *c0 = in + 2 * first, *c1 = in + 2 * n_total + 2 * first, *idx = in + 4 * n_total + 4 * first;
+    uint8_t *p = out + 8 * first;
+    for (size_t i = 0; i < count; i += 16, p += 128, c0 += 32, c1 += 32, idx += 64) {
+        const __m256i v0 = _mm256_loadu_si256((const __m256i *)c0);  /* c0 of 16 blocks */
+        const __m256i v1 = _mm256_loadu_si256((const __m256i *)c1);
+        /* per-lane word interleave gives blocks 0-3,8-11 / 4-7,12-15; fix the order with lane permutes */
+        const __m256i lo = _mm256_unpacklo_epi16(v0, v1);
+        const __m256i hi = _mm256_unpackhi_epi16(v0, v1);
+        __m256i col_a = _mm256_permute2x128_si256(lo, hi, 0x20);  /* blocks 0-7 */
+        __m256i col_b = _mm256_permute2x128_si256(lo, hi, 0x31);  /* blocks 8-15 */
+        col_a = recorrelate_var1_epi16(col_a);
+        col_b = recorrelate_var1_epi16(col_b);
+        const __m256i ia = _mm256_loadu_si256((const __m256i *)idx);
+        const __m256i ib = _mm256_loadu_si256((const __m256i *)(idx + 32));
+        /* dword interleave colours/indices -> blocks */
+        const __m256i a_lo = _mm256_unpacklo_epi32(col_a, ia), a_hi = _mm256_unpackhi_epi32(col_a, ia);
+        const __m256i b_lo = _mm256_unpacklo_epi32(col_b, ib), b_hi = _mm256_unpackhi_epi32(col_b, ib);
+        _mm256_storeu_si256((__m256i *)(p + 0), _mm256_permute2x128_si256(a_lo, a_hi, 0x20));
+        _mm256_storeu_si256((__m256i *)(p + 32), _mm256_permute2x128_si256(a_lo, a_hi, 0x31));
+        _mm256_storeu_si256((__m256i *)(p + 64), _mm256_permute2x128_si256(b_lo, b_hi, 0x20));
+        _mm256_storeu_si256((__m256i *)(p + 96), _mm256_permute2x128_si256(b_lo, b_hi, 0x31));
+    }
+}
+
+#endif /* HAVE_X86 */
+
+/* scalar range kernels live in dxtlt_oracle.c; re-stated minimally here for the tail */
+static void bc1_default_scalar_range(int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    for (size_t b = first; b < first + count; ++b) {
+        if (!inverse) {
+            uint16_t c0, c1;
+            uint32_t ix;
+            memcpy(&c0, in + 8 * b, 2);
+            memcpy(&c1, in + 8 * b + 2, 2);
+            memcpy(&ix, in + 8 * b + 4, 4);
+            c0 = oracle_decorrelate_565(c0, ORACLE_YCOCG_VAR1);
+            c1 = oracle_decorrelate_565(c1, ORACLE_YCOCG_VAR1);
+            memcpy(out + 2 * b, &c0, 2);
+            memcpy(out + 2 * n_total + 2 * b, &c1, 2);
+            memcpy(out + 4 * n_total + 4 * b, &ix, 4);
+        } else {
+            uint16_t c0, c1;
+            uint32_t ix;
+            memcpy(&c0, in + 2 * b, 2);
+            memcpy(&c1, in + 2 * n_total + 2 * b, 2);
+            memcpy(&ix, in + 4 * n_total + 4 * b, 4);
+            c0 = oracle_recorrelate_565(c0, ORACLE_YCOCG_VAR1);
+            c1 = oracle_recorrelate_565(c1, ORACLE_YCOCG_VAR1);
+            memcpy(out + 8 * b, &c0, 2);
+            memcpy(out + 8 * b + 2, &c1, 2);
+            memcpy(out + 8 * b + 4, &ix, 4);
+        }
+    }
+}
+
+void oracle_bc1_default_simd_range(int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    size_t body = 0;
+#if HAVE_X86
+    if (oracle_simd_available()) {
+        body = count & ~(size_t)15;
+        if (inverse)
+            bc1_default_inv_avx2(in, out, n_total, first, body);
+        else
+            bc1_default_fwd_avx2(in, out, n_total, first, body);
+    }
+#endif
+    bc1_default_scalar_range(inverse, in, out, n_total, first + body, count - body);
+}
+
+/* contiguous block ranges over `threads` pthreads (cpu_baseline only) */
+#include <pthread.h>
+#include <stdlib.h>
+
+struct simd_job {
+    int inverse;
+    const uint8_t *in;
+    uint8_t *out;
+    size_t n_total, first, count;
+};
+
+static void *simd_worker(void *arg)
+{
+    struct simd_job *j = (struct simd_job *)arg;
+    oracle_bc1_default_simd_range(j->inverse, j->in, j->out, j->n_total, j->first, j->count);
+    return NULL;
+}
+
+void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads)
+{
+    const size_t n = len / 8;
+    if (threads < 1)
+        threads = 1;
+    if ((size_t)threads > n / 16 + 1)
+        threads = (int)(n / 16 + 1);
+    struct simd_job *jobs = (struct simd_job *)calloc((size_t)threads, sizeof *jobs);
+    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof *tids);
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    per = (per + 15) & ~(size_t)15; /* keep every range a multiple of the vector width */
+    for (int t = 0; t < threads; ++t) {
+        size_t first = per * (size_t)t;
+        size_t count = first >= n ? 0 : (first + per > n ? n - first : per);
+        struct simd_job j = {inverse, in, out, n, first, count};
+        jobs[t] = j;
+        if (t > 0)
+            pthread_create(&tids[t], NULL, simd_worker, &jobs[t]);
+    }
+    simd_worker(&jobs[0]);
+    for (int t = 1; t < threads; ++t)
+        pthread_join(tids[t], NULL);
+    free(jobs);
+    free(tids);
+}

@@ -20,7 +20,8 @@ OK, INVALID_LENGTH, OUTPUT_TOO_SMALL = 0, 1, 2
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (``make -C oracle``) if the .so is missing or stale."""
-    srcs = [os.path.join(_HERE, f) for f in ("dxtlt_oracle.c", "dxtlt_oracle_bc7.c", "dxtlt_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("dxtlt_oracle.c", "dxtlt_oracle_bc7.c", "dxtlt_oracle_avx2.c",
+                                             "dxtlt_oracle.h")]
     stale = (
         force
         or not os.path.exists(_SO)
@@ -75,6 +76,9 @@ def lib() -> C.CDLL:
             getattr(l, n).restype = None
         l.oracle_bc7_force_modes.argtypes = [u8p, sz]
         l.oracle_bc7_force_modes.restype = None
+        l.oracle_simd_available.argtypes, l.oracle_simd_available.restype = [], i
+        l.oracle_bc1_default_simd_mt.argtypes = [i, u8p, u8p, sz, i]
+        l.oracle_bc1_default_simd_mt.restype = None
         _lib = l
     return _lib
 
@@ -158,6 +162,15 @@ def decorrelate(v: int, variant: int) -> int:
 
 def recorrelate(v: int, variant: int) -> int:
     return int(lib().oracle_recorrelate_565(v, variant))
+
+
+def simd_available() -> bool:
+    return bool(lib().oracle_simd_available())
+
+
+def run_bc1_default_simd(src: np.ndarray, dst: np.ndarray, inverse: bool, threads: int) -> None:
+    """AVX2 port (scalar when the CPU has no AVX2) of BC1 {Variant1, split}; cpu_baseline leg and its test only."""
+    lib().oracle_bc1_default_simd_mt(int(inverse), _ptr(src), _ptr(dst), src.size, int(threads))
 
 
 def transform_bc7(data, inverse: bool = False) -> np.ndarray:

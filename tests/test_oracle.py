@@ -172,6 +172,21 @@ def test_splitmix_matches_numpy(oracle):
     assert np.array_equal(whole[8 * 40:], oracle.fill_splitmix64(8 * 60, 7, 40))
 
 
+def test_avx2_port_equals_scalar_oracle(oracle):
+    """The vectorised CPU baseline (AVX2 port of the reference's SIMD strategy, BC1 default settings) must be the same
+    function as the scalar oracle: every block count around the 16-block vector width, several thread counts."""
+    for n in list(range(0, 50)) + [255, 256, 257, 100_003]:
+        x = oracle.fill_splitmix64(n * 8, 0xA7C2 + n)
+        want = oracle.transform("bc1", x, 1, True)
+        for threads in (1, 3):
+            got = np.full_like(x, 0xEE)
+            oracle.run_bc1_default_simd(x, got, False, threads)
+            assert np.array_equal(got, want), (n, threads)
+            back = np.full_like(x, 0xEE)
+            oracle.run_bc1_default_simd(want, back, True, threads)
+            assert np.array_equal(back, x), (n, threads, "inverse")
+
+
 def test_mt_range_split_matches_single_thread(oracle):
     for fmt in FORMATS:
         x = oracle.fill_splitmix64(1001 * BLOCK[fmt], 99)
