@@ -293,6 +293,35 @@ def test_host_pointer_chunked_pipeline(pkg, oracle, dev, fmt):
             assert np.array_equal(z, x), (fmt, n, settings_id(s), "inverse")
 
 
+def test_device_calls_are_stream_ordered(pkg, oracle, dev):
+    """The *_device entry points only enqueue: work lands on the stream that is current in torch, in order with the
+    producer before it (a fill) and the consumer after it (the inverse), with no synchronisation in between; two
+    streams run independent transforms at once."""
+    n = 6 * 1024 * 1024  # blocks
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    bufs = []
+    for i, st in enumerate(streams):
+        fmt = ("bc1", "bc3")[i]
+        s = (1, 1, 1)
+        with torch.cuda.stream(st):
+            x = torch.empty(n * BLOCK[fmt], dtype=torch.uint8, device=dev)
+            y = torch.empty_like(x)
+            z = torch.empty_like(x)
+            pkg.fill_splitmix64(x, 0x57EA + i)
+            getattr(pkg, f"transform_{fmt}_with_settings")(x, y, pkg_settings(pkg, fmt, s))
+            getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, pkg_settings(pkg, fmt, s))
+        bufs.append((fmt, s, x, y, z, 0x57EA + i))
+    for st in streams:
+        st.synchronize()
+    for fmt, s, x, y, z, seed in bufs:
+        host = oracle.fill_splitmix64(x.numel(), seed)
+        assert np.array_equal(x.cpu().numpy(), host)
+        want = np.empty_like(host)
+        oracle.run_mt(fmt, host, want, s[0], bool(s[2]), bool(s[1]), False, 8)
+        assert np.array_equal(y.cpu().numpy(), want)
+        assert torch.equal(z, x)
+
+
 def test_concurrent_callers(pkg, oracle, dev):
     """The reference's functions are reentrant and its CLI calls them from rayon workers, one file per task
     (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:166-184).  Eight threads hammer the host-pointer
