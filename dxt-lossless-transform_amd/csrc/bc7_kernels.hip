@@ -301,10 +301,14 @@ __device__ __forceinline__ void move_pieces(uint8_t* img, const TileTables& tb, 
 {
     const int total = tb.seg_prefix[18];
     for (int s = threadIdx.x; s < total; s += kThreads) {
+        // last piece r whose first segment is <= s (seg_prefix is non-decreasing; empty pieces repeat a value)
         int r = 0;
 #pragma unroll
-        for (int i = 1; i < 18; ++i)
-            r += (s >= tb.seg_prefix[i]) ? 1 : 0;   // seg_prefix is non-decreasing
+        for (int step = 16; step > 0; step >>= 1) {
+            const int cand = r + step;
+            if (cand < 18 && tb.seg_prefix[cand] <= s)
+                r = cand;
+        }
         const int k = s - tb.seg_prefix[r];
         const uint64_t g = tb.g_off[r];
         const int a0 = (int)(g & 15);
