@@ -439,6 +439,36 @@ __global__ void __launch_bounds__(THREADS) inv_direct_blk(const uint8_t* __restr
     }
 }
 
+// inverse, one wave per workgroup, stream slices fetched straight into the LDS image by LDS-DMA
+// (global_load_lds_dwordx4: per-lane global source, LDS destination = wave base + lane*16), no VGPR round trip
+template <int NTAUX>
+__global__ void __launch_bounds__(64) inv_dma64(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t ntiles,
+                                                uint64_t N)
+{
+    constexpr int TB = 1024, T = 128;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TB];
+    const int t = threadIdx.x;
+    const uint64_t tile = blockIdx.x;
+    const int o = t * 16;
+    uint64_t g;
+    if (o < 2 * T) g = 0 * N + tile * (2 * T) + o;
+    else if (o < 4 * T) g = 2 * N + tile * (2 * T) + (o - 2 * T);
+    else g = 4 * N + tile * (4 * T) + (o - 4 * T);
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(in + g),
+                                     (void __attribute__((address_space(3)))*)lds, 16, 0, NTAUX);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int u = t;
+    const uint32_t c0 = *(uint32_t*)(lds + 4 * u), c1 = *(uint32_t*)(lds + 2 * T + 4 * u);
+    const u32x2 idx = *(u32x2*)(lds + 4 * T + 8 * u);
+    u32x4 q;
+    q.x = recorrelate2<1>((c0 & 0xFFFFu) | (c1 << 16));
+    q.y = idx.x;
+    q.z = recorrelate2<1>((c0 >> 16) | (c1 & 0xFFFF0000u));
+    q.w = idx.y;
+    st16<true>(out + tile * TB + (uint64_t)u * 16, q);
+}
+
 __global__ void fill_k(uint64_t* p, uint64_t n, uint64_t seed)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -494,18 +524,15 @@ int main(int argc, char** argv)
 
 
 
-#define ADD_COPY(NT, TH, U) add("copy_blk " #NT " T" #TH " U" #U, 0, [=] { copy_blk<NT, TH, U><<<(unsigned)((nvec + TH * U - 1) / (TH * U)), TH>>>(x, y, nvec); })
-    ADD_COPY(true, 64, 1); ADD_COPY(true, 256, 1);
-#define ADD_FWD(NT, TH, V, TPW) add("fwd_blk " #NT " T" #TH " V" #V " tpw" #TPW, 1, [=] { \
-        const uint64_t nt = len / (V * TH * 16); fwd_blk<NT, TH, V><<<(unsigned)((nt + TPW - 1) / TPW), TH>>>(x, y, nt, N, TPW); })
-    ADD_FWD(true, 64, 1, 1); ADD_FWD(true, 128, 1, 1); ADD_FWD(true, 256, 1, 1); ADD_FWD(true, 64, 2, 1); ADD_FWD(true, 128, 2, 1);
+
 #define ADD_INV(NT, TH, V, TPW) add("inv_blk " #NT " T" #TH " V" #V " tpw" #TPW, 2, [=] { \
         const uint64_t nt = len / (V * TH * 16); inv_blk<NT, TH, V><<<(unsigned)((nt + TPW - 1) / TPW), TH>>>(yref, z, nt, N, TPW); })
-    ADD_INV(true, 64, 1, 1); ADD_INV(true, 128, 1, 1); ADD_INV(true, 256, 1, 1); ADD_INV(true, 64, 2, 1); ADD_INV(true, 128, 2, 1);
-#define ADD_DIR(NT, TH, U) add("fwd_direct_blk " #NT " T" #TH " U" #U, 1, [=] { fwd_direct_blk<NT, TH, U><<<(unsigned)(nvec / (TH * U)), TH>>>(x, y, nvec, N); })
-    ADD_DIR(true, 256, 1); ADD_DIR(true, 128, 1);
-#define ADD_IDIR(NT, TH, U) add("inv_direct_blk " #NT " T" #TH " U" #U, 2, [=] { inv_direct_blk<NT, TH, U><<<(unsigned)(nvec / (TH * U)), TH>>>(yref, z, nvec, N); })
-    ADD_IDIR(true, 256, 1); ADD_IDIR(false, 256, 1); ADD_IDIR(true, 64, 1); ADD_IDIR(true, 256, 2);
+    ADD_INV(true, 64, 1, 1); ADD_INV(true, 128, 1, 1);
+    add("inv_dma64 aux0", 2, [=] { inv_dma64<0><<<(unsigned)(len / 1024), 64>>>(yref, z, len / 1024, N); });
+    add("inv_dma64 nt(aux2)", 2, [=] { inv_dma64<2><<<(unsigned)(len / 1024), 64>>>(yref, z, len / 1024, N); });
+#define ADD_FWD(NT, TH, V, TPW) add("fwd_blk " #NT " T" #TH " V" #V " tpw" #TPW, 1, [=] { \
+        const uint64_t nt = len / (V * TH * 16); fwd_blk<NT, TH, V><<<(unsigned)((nt + TPW - 1) / TPW), TH>>>(x, y, nt, N, TPW); })
+    ADD_FWD(true, 128, 1, 1);
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
