@@ -556,4 +556,6 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 
 const char* dxtlt_version(void) { return "dxtlt-gfx950 0.1.0"; }
 
+void dxtlt_release_thread_resources(void) { g_host_ctx.release(); }
+
 }  // extern "C"

@@ -151,6 +151,9 @@ int32_t dxtlt_device_count(void);
 void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path);
 /* "dxtlt-gfx950 <version>" */
 const char *dxtlt_version(void);
+/* The host-pointer entry points keep, per calling thread and device, one stream and a grow-only pair of staging
+ * buffers (so that file-after-file callers pay allocation once).  This frees the calling thread's set. */
+void dxtlt_release_thread_resources(void);
 
 #ifdef __cplusplus
 }
