@@ -16,6 +16,8 @@
  *   - the round-trip-for-every-n harness (bc1 test_prelude.rs:154-317 and twins),
  *   - the YCoCg-R 13/16-colour round-trip sets (decorrelate.rs:413-446, avx2.rs:194-266),
  *   - the real-texture round trips on assets/tests/r2-256-bc{1,2,3}.dds.
+ * In the strict sense the transformed bytes are PARITY UNPINNED (no reference-produced
+ * vector exists and the reference cannot be run here); everything the reference does pin is checked.
  * Forward-byte parity therefore rests on the code-defined layout plus an
  * independently written numpy restatement (oracle/oracle_np.py) agreeing with
  * this file on every case; see DESIGN.md "Oracle".
