@@ -374,6 +374,27 @@ def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
     assert np.array_equal(z, x)
 
 
+def test_mixed_bc1_bc3_archive(pkg, oracle, dev):
+    """BASELINE.json configs[4] in miniature on the visible device(s): an archive of alternating BC1 / BC3 textures
+    (16 MiB each, ragged sizes too), each transformed with its format's default settings through the sharded entry point
+    (contiguous block ranges per device, per-stream placement on the host), compared byte for byte with the CPU oracle;
+    then restored."""
+    rng = np.random.default_rng(55)
+    for i in range(8):
+        fmt = "bc1" if i % 2 == 0 else "bc3"
+        blocks = (16 << 20) // BLOCK[fmt] + int(rng.integers(0, 3)) * int(rng.integers(1, 5000))
+        x = oracle.fill_splitmix64(blocks * BLOCK[fmt], 0x0A5C0005 + i)
+        st = pkg_settings(pkg, fmt, (1, 1, 1))
+        y = np.zeros_like(x)
+        pkg.transform_sharded(fmt, False, x, y, st, 0)
+        want = np.empty_like(x)
+        oracle.run_mt(fmt, x, want, 1, True, True, False, 8)
+        assert np.array_equal(y, want), (i, fmt, blocks)
+        z = np.zeros_like(x)
+        pkg.transform_sharded(fmt, True, y, z, st, 0)
+        assert np.array_equal(z, x), (i, fmt, blocks, "inverse")
+
+
 def test_real_textures(pkg, oracle, dev):
     """assets/tests/r2-256-bc{1,2,3}.dds payloads: every settings combination, forward bytes and round trip
     (reference: debug_bcN roundtrip commands)."""
