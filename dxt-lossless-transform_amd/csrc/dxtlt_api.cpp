@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -164,8 +165,27 @@ thread_local HostCtx g_host_ctx;
 // negligible next to either copy.  A chunk is a block range of the whole array (dxtlt_transform_range_device
 // semantics), so on the SoA side every chunk moves one slice per stream.
 // ---------------------------------------------------------------------------------------------------
-constexpr size_t kPipelineMinBytes = 32u << 20;   // below this one H2D + kernel + D2H is as fast
-constexpr uint64_t kPipelineChunkBytes = 32u << 20;
+// Pipeline thresholds; overridable once per process through the environment for experiments
+// (DXTLT_PIPELINE_MIN_BYTES, DXTLT_PIPELINE_CHUNK_BYTES).
+size_t env_bytes(const char* name, size_t fallback)
+{
+    const char* v = std::getenv(name);
+    if (v == nullptr || *v == 0)
+        return fallback;
+    const unsigned long long x = std::strtoull(v, nullptr, 10);
+    return x ? (size_t)x : fallback;
+}
+// Measured (profiles/r01_j_*): one-shot H2D + kernel + D2H runs at ~25.5 GiB/s at every size; the pipeline costs
+// ~150 us per chunk and only wins from ~100 MiB up (16 MiB chunks: 32 / 36 / 38 GiB/s at 128 / 256 / 512 MiB; 32 MiB
+// chunks: 40-42 GiB/s from 512 MiB up).
+const size_t kPipelineMinBytes = env_bytes("DXTLT_PIPELINE_MIN_BYTES", 96u << 20);
+const uint64_t kPipelineChunkOverride = env_bytes("DXTLT_PIPELINE_CHUNK_BYTES", 0) & ~(uint64_t)0xFFFF;
+inline uint64_t pipeline_chunk_bytes(uint64_t len)
+{
+    if (kPipelineChunkOverride)
+        return kPipelineChunkOverride;
+    return len >= (1ull << 30) ? (32ull << 20) : (16ull << 20);
+}
 std::atomic<int> g_host_pipeline{1};
 
 struct PipeShared {
@@ -180,7 +200,7 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
 {
     const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
     const dxtlt::Streams S = dxtlt::make_streams(format, format == 3 && sa, sc);
-    uint64_t chunk_blocks = kPipelineChunkBytes / B;  // a multiple of every tile size
+    uint64_t chunk_blocks = pipeline_chunk_bytes(blocks * B) / B;  // a multiple of every tile size
     const int nchunks = (int)((blocks + chunk_blocks - 1) / chunk_blocks);
     const int dev = c.device;
 

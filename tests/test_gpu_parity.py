@@ -276,9 +276,9 @@ def test_host_pointer_entry_points(pkg, oracle, dev, fmt):
 
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_host_pointer_chunked_pipeline(pkg, oracle, dev, fmt):
-    """Buffers of 32 MiB and more take the chunked upload / kernel / download pipeline (two host threads, block-range
-    kernels): several chunks, a ragged last chunk, an odd block count."""
-    for nbytes_target in ((32 << 20), (100 << 20) + 48 * BLOCK[fmt] + BLOCK[fmt]):
+    """Buffers of 96 MiB and more take the chunked upload / kernel / download pipeline (two host threads, block-range
+    kernels, 16 MiB chunks): several chunks, a ragged last chunk, an odd block count."""
+    for nbytes_target in ((96 << 20), (100 << 20) + 48 * BLOCK[fmt] + BLOCK[fmt]):
         n = nbytes_target // BLOCK[fmt]
         x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x919E + n)
         for s in [(1, 1, 1), (0, 0, 0), (3, 0, 1)]:
