@@ -374,6 +374,28 @@ def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
     assert np.array_equal(z, x)
 
 
+def test_host_pointers_beyond_four_gib(pkg, oracle, dev):
+    """A single host buffer just over 2^32 bytes through the drop-in entry point (chunked pipeline, 32 MiB chunks,
+    per-stream slices at offsets above 4 GiB): sampled windows against the oracle and an exact round trip."""
+    fmt, s = "bc3", (1, 1, 1)
+    n = (1 << 32) // 16 + 3 * 1024 + 1  # odd block count on top
+    x = oracle.fill_splitmix64(n * 16, 0x4A1B)
+    st = pkg_settings(pkg, fmt, s)
+    y = np.empty_like(x)
+    pkg.transform_bc3_with_settings(x, y, st)
+    table = pkg.stream_table(fmt, st)
+    win = 4096
+    for first in (0, n - win, (1 << 32) // 16 - win // 2, n // 3):
+        want = fwd_oracle(oracle, fmt, x[first * 16:(first + win) * 16], s)
+        got = np.empty_like(want)
+        for off, w in table:
+            got[off * win: off * win + w * win] = y[off * n + w * first: off * n + w * (first + win)]
+        assert np.array_equal(got, want), first
+    z = np.empty_like(x)
+    pkg.untransform_bc3_with_settings(y, z, st)
+    assert np.array_equal(z, x)
+
+
 def test_mixed_bc1_bc3_archive(pkg, oracle, dev):
     """BASELINE.json configs[4] in miniature on the visible device(s): an archive of alternating BC1 / BC3 textures
     (16 MiB each, ragged sizes too), each transformed with its format's default settings through the sharded entry point
