@@ -374,6 +374,35 @@ def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
     assert np.array_equal(z, x)
 
 
+def test_randomised_dispatch(pkg, oracle, dev):
+    """400 seeded random cases: format, settings, block count (0..40 000), and independent byte offsets of the input and
+    output device pointers (0..31) -- every combination of aligned-tile / shifted-tile / element-kernel dispatch with
+    ragged tails -- forward bytes against the oracle, inverse against the input, and guard bytes on both sides."""
+    rng = np.random.default_rng(0xD15BA7C4)
+    for case in range(400):
+        fmt = FORMATS[int(rng.integers(0, 3))]
+        settings = list(all_settings(fmt))
+        s = settings[int(rng.integers(0, len(settings)))]
+        n = int(rng.integers(0, 40_001)) if case % 4 else int(rng.integers(0, 40)) * TILE[fmt]
+        a, b = int(rng.integers(0, 32)) if case % 3 else 0, int(rng.integers(0, 32)) if case % 5 else 0
+        nbytes = n * BLOCK[fmt]
+        x = oracle.fill_splitmix64(nbytes, 0xFA22 + case)
+        st = pkg_settings(pkg, fmt, s)
+        xd = torch.full((nbytes + 64,), 0x11, dtype=torch.uint8, device=dev)
+        xd[a:a + nbytes] = torch.from_numpy(x).to(dev)
+        yd = torch.full((nbytes + 64,), 0x22, dtype=torch.uint8, device=dev)
+        getattr(pkg, f"transform_{fmt}_with_settings")(xd[a:a + nbytes], yd[b:b + nbytes], st)
+        zd = torch.full((nbytes + 64,), 0x33, dtype=torch.uint8, device=dev)
+        getattr(pkg, f"untransform_{fmt}_with_settings")(yd[b:b + nbytes], zd[a:a + nbytes], st)
+        torch.cuda.synchronize()
+        tag = (case, fmt, settings_id(s), n, a, b)
+        yh, zh = yd.cpu().numpy(), zd.cpu().numpy()
+        assert np.array_equal(yh[b:b + nbytes], fwd_oracle(oracle, fmt, x, s)), tag
+        assert np.array_equal(zh[a:a + nbytes], x), tag
+        assert (yh[:b] == 0x22).all() and (yh[b + nbytes:] == 0x22).all(), tag
+        assert (zh[:a] == 0x33).all() and (zh[a + nbytes:] == 0x33).all(), tag
+
+
 def test_host_pointers_beyond_four_gib(pkg, oracle, dev):
     """A single host buffer just over 2^32 bytes through the drop-in entry point (chunked pipeline, 32 MiB chunks,
     per-stream slices at offsets above 4 GiB): sampled windows against the oracle and an exact round trip."""
