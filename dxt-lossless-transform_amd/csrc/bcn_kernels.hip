@@ -44,13 +44,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;        // element-granular / fill kernels
 // Default tile workgroup size (tile = threads * 16 bytes) per format and direction, chosen by measurement on the
-// 8 GiB workloads (profiles/r01_g_tile_threads_sweep.txt, two runs): fraction of peak, fwd / inv
-//   BC1  64: .79-.81/.82-.84   128: .83/.83   256: .82-.83/.79-.80   512: .80/.75-.76
-//   BC2  64: .78/.81-.82       128: .81/.76   256: .81-.82/.79-.80   512: .81/.77-.78
-//   BC3  64: .72/.72-.75       128: .77/.72-.73   256: .79/.78-.80   512: .78/.77-.79
+// 8 GiB workloads with the final store policy (profiles/r01_q_tile_threads_sweep_sc1_stores.txt): fraction of peak, fwd / inv
+//   BC1  64: .82/.83   128: .85/.84   256: .84/.82   512: .81/.78
+//   BC2  64: .80/.81   128: .83/.82   256: .84/.82   512: .82/.79
+//   BC3  64: .71/.72   128: .80/.78   256: .84/.81   512: .82/.80
+// (with plain `nt` stores the optimum was smaller for the inverse: profiles/r01_g_tile_threads_sweep.txt)
 constexpr int default_tile_threads(int fmt, bool inverse)
 {
-    return fmt == kBc1 ? (inverse ? 64 : 128) : fmt == kBc2 ? (inverse ? 64 : 256) : 256;
+    (void)inverse;
+    return fmt == kBc1 ? 128 : 256;
 }
 
 #ifndef DXTLT_NONTEMPORAL
@@ -66,10 +68,16 @@ __device__ __forceinline__ u32x4 gload16(const void* p)
 #endif
 }
 
+// Streaming 16-byte store.  Cache policy measured on the 8 GiB BC1 forward kernel (tools/kernel_lab.hip,
+// profiles/r01_p_kernel_lab_cache_policies.txt), loads `nt` in every row:
+//   store plain 0.805 | nt 0.827 | sc1 0.838 | sc0 sc1 0.829 | sc1 nt 0.841 | sc0 sc1 nt 0.842   (fraction of 8 TB/s)
+// `sc1` makes the store write-through and drops the line from the XCD's L2 (MI355X_MICROARCH.md, store flavours), which
+// is what a write-once stream wants; `nt` on top marks it streaming.  There is no builtin for that combination, so
+// the instruction is spelled out; it has no result, and the compiler still waits for the operands it produced.
 __device__ __forceinline__ void gstore16(void* p, u32x4 v)
 {
 #if DXTLT_NONTEMPORAL
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<u32x4*>(p) = v;
 #endif
@@ -502,8 +510,9 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
     shifted_segment<FMT, SA, SC, T>(t * 16, total_blocks, blk0, sh, s, k, la, g, shift);
     if (k == 0 && shift > 0)
         copy_partial_segment<true>(soa + g, lds + la, shift, 16);
-    else
-        gstore16(soa + g, lds_at<u32x4>(lds, la));
+    else  // plain `nt`, not the write-through store: the first/last 128-byte line of a slice is completed by the
+          // neighbouring tile and must stay in L2 until then (with sc1: 0.39-0.50 of peak instead of 0.72-0.76)
+        __builtin_nontemporal_store(lds_at<u32x4>(lds, la), reinterpret_cast<u32x4*>(soa + g));
     if (t < S.n) {  // the extra, partial last segment of stream t
 #pragma unroll
         for (int ss = 0; ss < S.n; ++ss) {

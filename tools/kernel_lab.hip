@@ -469,6 +469,51 @@ __global__ void __launch_bounds__(64) inv_dma64(const uint8_t* __restrict__ in, 
     st16<true>(out + tile * TB + (uint64_t)u * 16, q);
 }
 
+// cache-policy experiment: one-shot copy / forward with the store (and load) policy chosen by inline asm
+// POLICY: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt
+template <int POLICY>
+__device__ __forceinline__ void st16_policy(void* p, u32x4 v)
+{
+    if (POLICY == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int POLICY>
+__device__ __forceinline__ u32x4 ld16_policy(const void* p)
+{
+    u32x4 v;
+    if (POLICY == 0) asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int LP, int SP>
+__global__ void __launch_bounds__(128) fwd_policy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t ntiles,
+                                                  uint64_t N)
+{
+    constexpr int TB = 2048, T = 256;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TB];
+    const int t = threadIdx.x;
+    const uint64_t tile = blockIdx.x;
+    const u32x4 q = ld16_policy<LP>(in + tile * TB + (uint64_t)t * 16);
+    bc1_scatter(lds, 2 * T, t, q);
+    __syncthreads();
+    const int o = t * 16;
+    const u32x4 v = *(u32x4*)(lds + o);
+    uint64_t g;
+    if (o < 2 * T) g = 0 * N + tile * (2 * T) + o;
+    else if (o < 4 * T) g = 2 * N + tile * (2 * T) + (o - 2 * T);
+    else g = 4 * N + tile * (4 * T) + (o - 4 * T);
+    st16_policy<SP>(out + g, v);
+}
+
 __global__ void fill_k(uint64_t* p, uint64_t n, uint64_t seed)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -525,11 +570,10 @@ int main(int argc, char** argv)
 
 
 
-#define ADD_INV(NT, TH, V, TPW) add("inv_blk " #NT " T" #TH " V" #V " tpw" #TPW, 2, [=] { \
-        const uint64_t nt = len / (V * TH * 16); inv_blk<NT, TH, V><<<(unsigned)((nt + TPW - 1) / TPW), TH>>>(yref, z, nt, N, TPW); })
-    ADD_INV(true, 64, 1, 1); ADD_INV(true, 128, 1, 1);
-    add("inv_dma64 aux0", 2, [=] { inv_dma64<0><<<(unsigned)(len / 1024), 64>>>(yref, z, len / 1024, N); });
-    add("inv_dma64 nt(aux2)", 2, [=] { inv_dma64<2><<<(unsigned)(len / 1024), 64>>>(yref, z, len / 1024, N); });
+
+#define ADD_POL(LP, SP) add("fwd_policy T128 load" #LP " store" #SP, 1, [=] { fwd_policy<LP, SP><<<(unsigned)(len / 2048), 128>>>(x, y, len / 2048, N); })
+    ADD_POL(1, 1); ADD_POL(0, 0); ADD_POL(1, 0); ADD_POL(0, 1); ADD_POL(1, 2); ADD_POL(1, 3); ADD_POL(1, 4); ADD_POL(1, 5);
+    ADD_POL(2, 1); ADD_POL(4, 1); ADD_POL(3, 1); ADD_POL(5, 5);
 #define ADD_FWD(NT, TH, V, TPW) add("fwd_blk " #NT " T" #TH " V" #V " tpw" #TPW, 1, [=] { \
         const uint64_t nt = len / (V * TH * 16); fwd_blk<NT, TH, V><<<(unsigned)((nt + TPW - 1) / TPW), TH>>>(x, y, nt, N, TPW); })
     ADD_FWD(true, 128, 1, 1);
