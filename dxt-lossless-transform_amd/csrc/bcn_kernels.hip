@@ -25,7 +25,9 @@
 //     0.79-0.80, against 0.81-0.83 for a plain dwordx4 copy launched the same way.  The hardware
 //     dispatcher is the better scheduler for a pure stream: short-lived workgroups de-synchronise reads
 //     and writes and keep every channel busy.
-//   * Non-temporal loads/stores (every byte is touched exactly once): +2-3 % over default policy.
+//   * Non-temporal loads (every byte is touched exactly once): +2-3 % over default policy.  Stores of aligned tiles
+//     are write-through streaming stores (`sc1 nt`): another +1-3 % (profiles/r01_p, r01_q).  Shifted tiles share
+//     128-B lines with their neighbours and keep plain `nt` stores, so L2 can merge the two halves of a line.
 //   * 64-bit block indices and byte offsets everywhere (8 GiB of BC1 = 2^30 blocks).
 //   * Stream bases that are not 16-byte aligned (odd block counts, ranges starting at odd blocks) take the
 //     "shifted tile" kernels further down: same structure, each stream's LDS slice displaced by its
