@@ -18,6 +18,8 @@
 // algorithmic 2*len; inverse reads `first` twice and everything else once = 2.06*len.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bc7_launch.h"
 
 namespace dxtlt {
@@ -104,29 +106,43 @@ bc7_hist_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ first_out, u
             part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
+constexpr int kInvTilesPerWave = 4;
+
 __global__ void __launch_bounds__(kThreads)
 bc7_hist_inv(const uint8_t* __restrict__ first_in, uint32_t* __restrict__ hist, uint64_t n_blocks, uint64_t num_tiles)
 {
-    // one tile per WAVE: 64 lanes x 16 first-bytes = 1024 blocks; 4 tiles per workgroup
+    // one tile per wave and step: 64 lanes x 16 first-bytes = 1024 blocks; every wave takes kInvTilesPerWave
+    // consecutive tiles with all loads issued up front (a wave with a single 1 KiB load is pure latency)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + wave;
-    if (tile >= num_tiles)
-        return;
-    const uint64_t b0 = tile * kTileBlocks + (uint64_t)lane * 16;
-    PackedCounts c{0, 0};
-    if (b0 + 16 <= n_blocks) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(first_in + b0));
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * (kThreads / 64) + wave) * kInvTilesPerWave;
+    u32x4 v[kInvTilesPerWave];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            count_mode(c, mode_of(w[k >> 2] >> (8 * (k & 3))));
-    } else {
-        for (uint64_t b = b0; b < n_blocks && b < b0 + 16; ++b)
-            count_mode(c, mode_of(first_in[b]));
+    for (int i = 0; i < kInvTilesPerWave; ++i) {
+        const uint64_t b0 = (tile0 + i) * kTileBlocks + (uint64_t)lane * 16;
+        v[i] = u32x4{0, 0, 0, 0};
+        if (b0 + 16 <= n_blocks)
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(first_in + b0));
     }
-    c = wave_sum(c);
-    if (lane < 9)
-        hist[(uint64_t)lane * num_tiles + tile] = unpack_count(c, lane);
+#pragma unroll
+    for (int i = 0; i < kInvTilesPerWave; ++i) {
+        const uint64_t tile = tile0 + i;
+        if (tile >= num_tiles)
+            break;
+        const uint64_t b0 = tile * kTileBlocks + (uint64_t)lane * 16;
+        PackedCounts c{0, 0};
+        if (b0 + 16 <= n_blocks) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                count_mode(c, mode_of(w[k >> 2] >> (8 * (k & 3))));
+        } else {
+            for (uint64_t b = b0; b < n_blocks && b < b0 + 16; ++b)
+                count_mode(c, mode_of(first_in[b]));
+        }
+        c = wave_sum(c);
+        if (lane < 9)
+            hist[(uint64_t)lane * num_tiles + tile] = unpack_count(c, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -295,13 +311,218 @@ __device__ __forceinline__ uint64_t fetch_piece_origin(const uint32_t* prefix, c
     return base + (uint64_t)prefix[(uint64_t)m * num_tiles + tile] * w;
 }
 
-// flattened copy of the 18 pieces between LDS and global memory; TO_GLOBAL selects the direction
+// ---- record-wide LDS access -----------------------------------------------------------------------------
+// Head and tail records sit at arbitrary byte offsets of the LDS image.  gfx950 executes DS reads/writes at any
+// byte alignment (the compiler emits ds_{read,write}_b32/b64 for align-1 accesses), so a record is moved as two
+// possibly overlapping words instead of one access per byte: W = 8 for records of 8 bytes or more, else 4, at
+// record offsets 0 and size - W.  Overlapping bytes carry identical data.
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
+__device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { *reinterpret_cast<u64_unaligned*>(p) = v; }
+__device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { *reinterpret_cast<u32_unaligned*>(p) = v; }
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return *reinterpret_cast<const u64_unaligned*>(p); }
+__device__ __forceinline__ uint64_t ld32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
+
+// the 8 bytes of the block (lo = bytes 0..7, hi = bytes 8..15) that start at byte pos, 1 <= pos <= 15; zero-filled
+__device__ __forceinline__ uint64_t bytes_from(uint64_t lo, uint64_t hi, int pos)
+{
+    const int s = 8 * pos;
+    return pos < 8 ? (lo >> s) | (hi << (64 - s)) : hi >> (s - 64);
+}
+
+// OR a chunk into the block at byte pos, 1 <= pos <= 12 (chunks never reach past byte 15)
+__device__ __forceinline__ void place(uint64_t& lo, uint64_t& hi, uint64_t chunk, int pos)
+{
+    const int s = 8 * pos;
+    if (pos < 8) {
+        lo |= chunk << s;
+        hi |= chunk >> (64 - s);
+    } else {
+        hi |= chunk << (s - 64);
+    }
+}
+
+template <int REC>
+__device__ __forceinline__ void put_records(uint8_t* hp, uint8_t* tp, int h, uint64_t lo, uint64_t hi)
+{
+    const int t = 15 - h;
+    if (REC == 0) {
+        uint8_t* ho = hp - 1;
+        uint8_t* to = tp - 1 - h;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const uint8_t byte = (uint8_t)((k < 8 ? lo : hi) >> (8 * (k & 7)));
+            (k <= h ? ho : to)[k] = byte;
+        }
+        return;
+    }
+    if (h >= 8) {   // modes 0-3, 7, 8: head 9/11/15 bytes, tail 6/4/0
+        st64(hp, bytes_from(lo, hi, 1));
+        st64(hp + h - 8, bytes_from(lo, hi, h - 7));
+        if (t) {
+            st32(tp, (uint32_t)bytes_from(lo, hi, h + 1));
+            st32(tp + t - 4, (uint32_t)(hi >> 32));
+        }
+    } else {        // modes 4-6: head 5/7 bytes, tail 10/8
+        st32(hp, (uint32_t)(lo >> 8));
+        st32(hp + h - 4, (uint32_t)bytes_from(lo, hi, h - 3));
+        st64(tp, bytes_from(lo, hi, h + 1));
+        st64(tp + t - 8, hi);
+    }
+}
+
+template <int REC>
+__device__ __forceinline__ void get_records(const uint8_t* hp, const uint8_t* tp, int h, uint64_t& lo, uint64_t& hi)
+{
+    const int t = 15 - h;
+    if (REC == 0) {
+        const uint8_t* ho = hp - 1;
+        const uint8_t* to = tp - 1 - h;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const uint64_t byte = (k <= h ? ho : to)[k];
+            if (k < 8) lo |= byte << (8 * k);
+            else hi |= byte << (8 * (k - 8));
+        }
+        return;
+    }
+    if (h >= 8) {
+        place(lo, hi, ld64(hp), 1);
+        place(lo, hi, ld64(hp + h - 8), h - 7);
+        if (t) {
+            place(lo, hi, ld32(tp), h + 1);
+            hi |= ld32(tp + t - 4) << 32;
+        }
+    } else {
+        place(lo, hi, ld32(hp), 1);
+        place(lo, hi, ld32(hp + h - 4), h - 3);
+        place(lo, hi, ld64(tp), h + 1);
+        hi |= ld64(tp + t - 8);
+    }
+}
+
+// ---- piece movement ---------------------------------------------------------------------------------------
+// Bytes [lo, hi) of one 16-byte segment, both pointers 16-byte aligned at byte 0 of the segment: an ascending
+// ladder of naturally aligned 1/2/4/8-byte moves from lo, then a descending one for what is left.
+template <typename Mover>
+__device__ __forceinline__ void partial_segment(int lo, int hi, Mover mv)
+{
+    int p = lo;
+    if ((p & 1) && p + 1 <= hi) { mv(p, 1); p += 1; }
+    if ((p & 2) && p + 2 <= hi) { mv(p, 2); p += 2; }
+    if ((p & 4) && p + 4 <= hi) { mv(p, 4); p += 4; }
+    if ((p & 8) && p + 8 <= hi) { mv(p, 8); p += 8; }
+    const int rem = hi - p;
+    if (rem & 8) { mv(p, 8); p += 8; }
+    if (rem & 4) { mv(p, 4); p += 4; }
+    if (rem & 2) { mv(p, 2); p += 2; }
+    if (rem & 1) { mv(p, 1); }
+}
+
+__device__ __forceinline__ void typed_move(uint8_t* dst, const uint8_t* src, int p, int w)
+{
+    if (w == 1) dst[p] = src[p];
+    if (w == 2) *reinterpret_cast<uint16_t*>(dst + p) = *reinterpret_cast<const uint16_t*>(src + p);
+    if (w == 4) *reinterpret_cast<uint32_t*>(dst + p) = *reinterpret_cast<const uint32_t*>(src + p);
+    if (w == 8) *reinterpret_cast<uint64_t*>(dst + p) = *reinterpret_cast<const uint64_t*>(src + p);
+}
+
+constexpr int kMoveIters = (kImageBytes / 16 + kThreads - 1) / kThreads;  // upper bound on segments per lane
+
+// Flattened copy of the 18 pieces between LDS and global memory, one 16-byte segment per lane and step.  The
+// segment prefix table is wave-uniform and lives in SGPRs; the piece of a segment is a count of compares.
+struct SegmentRef {
+    bool live, whole;
+    int lseg, lo, hi;
+    uint64_t gseg;
+};
+
+__device__ __forceinline__ SegmentRef locate_segment(const TileTables& tb, const int (&sp)[19], int s)
+{
+    SegmentRef ref{};
+    ref.live = s < sp[18];
+    if (!ref.live)
+        return ref;
+    int r = 0;
+#pragma unroll
+    for (int i = 1; i < 18; ++i)
+        r += sp[i] <= s ? 1 : 0;   // last piece whose first segment is <= s (empty pieces repeat a value)
+    const int k = s - tb.seg_prefix[r];
+    const uint64_t g = tb.g_off[r];
+    const int a0 = (int)(g & 15);
+    ref.gseg = g - a0 + (uint64_t)16 * k;
+    ref.lseg = tb.lds_off[r] - a0 + 16 * k;
+    ref.lo = k == 0 ? a0 : 0;
+    const int end = a0 + tb.bytes[r] - 16 * k;
+    ref.hi = end < 16 ? end : 16;
+    ref.whole = ref.lo == 0 && ref.hi == 16;
+    return ref;
+}
+
+__device__ __forceinline__ void load_segment_table(const TileTables& tb, int (&sp)[19])
+{
+#pragma unroll
+    for (int i = 0; i < 19; ++i)
+        sp[i] = __builtin_amdgcn_readfirstlane(tb.seg_prefix[i]);
+}
+
+__device__ __forceinline__ void pieces_to_global(uint8_t* img, const TileTables& tb, uint8_t* soa)
+{
+    int sp[19];
+    load_segment_table(tb, sp);
+#pragma unroll
+    for (int it = 0; it < kMoveIters; ++it) {
+        const SegmentRef ref = locate_segment(tb, sp, it * kThreads + (int)threadIdx.x);
+        if (!ref.live)
+            continue;
+        if (ref.whole) {
+            // neighbouring tiles share 128-byte lines here: plain streaming store, L2 merges the halves
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(img + ref.lseg),
+                                        reinterpret_cast<u32x4*>(soa + ref.gseg));
+        } else {
+            uint8_t* dst = soa + ref.gseg;
+            const uint8_t* src = img + ref.lseg;
+            partial_segment(ref.lo, ref.hi, [&](int p, int w) { typed_move(dst, src, p, w); });
+        }
+    }
+}
+
+__device__ __forceinline__ void pieces_from_global(uint8_t* img, const TileTables& tb, const uint8_t* soa,
+                                                   uint64_t total_bytes)
+{
+    int sp[19];
+    load_segment_table(tb, sp);
+    SegmentRef ref[kMoveIters];
+    u32x4 v[kMoveIters];
+    // all loads of the lane are in flight before the first LDS write.  A whole aligned segment is fetched whenever it
+    // lies inside the buffer: the bytes of neighbouring pieces land in this piece's LDS padding.
+#pragma unroll
+    for (int it = 0; it < kMoveIters; ++it) {
+        ref[it] = locate_segment(tb, sp, it * kThreads + (int)threadIdx.x);
+        ref[it].whole = ref[it].live && ref[it].gseg + 16 <= total_bytes && ref[it].lseg >= 0;
+        v[it] = u32x4{0, 0, 0, 0};
+        if (ref[it].whole)
+            v[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(soa + ref[it].gseg));
+    }
+#pragma unroll
+    for (int it = 0; it < kMoveIters; ++it) {
+        if (ref[it].whole) {
+            *reinterpret_cast<u32x4*>(img + ref[it].lseg) = v[it];
+        } else if (ref[it].live) {
+            uint8_t* dst = img + ref[it].lseg;
+            const uint8_t* src = soa + ref[it].gseg;
+            partial_segment(ref[it].lo, ref[it].hi, [&](int p, int w) { typed_move(dst, src, p, w); });
+        }
+    }
+}
+
+// first version of the mover: binary search over the LDS-resident prefix table, byte loops for partial segments
 template <bool TO_GLOBAL>
-__device__ __forceinline__ void move_pieces(uint8_t* img, const TileTables& tb, uint8_t* soa, uint64_t total_bytes)
+__device__ __forceinline__ void move_pieces_v0(uint8_t* img, const TileTables& tb, uint8_t* soa, uint64_t total_bytes)
 {
     const int total = tb.seg_prefix[18];
     for (int s = threadIdx.x; s < total; s += kThreads) {
-        // last piece r whose first segment is <= s (seg_prefix is non-decreasing; empty pieces repeat a value)
         int r = 0;
 #pragma unroll
         for (int step = 16; step > 0; step >>= 1) {
@@ -325,7 +546,6 @@ __device__ __forceinline__ void move_pieces(uint8_t* img, const TileTables& tb, 
                     soa[gseg + p] = img[lseg + p];
             }
         } else {
-            // the whole aligned segment may be fetched when it lies inside the buffer: spare bytes land in padding
             if (gseg + 16 <= total_bytes && lseg >= 0) {
                 *reinterpret_cast<u32x4*>(img + lseg) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(soa + gseg));
             } else {
@@ -336,6 +556,13 @@ __device__ __forceinline__ void move_pieces(uint8_t* img, const TileTables& tb, 
     }
 }
 
+__device__ __forceinline__ void store_block(uint8_t* p, u32x4 v)
+{
+    // AoS output: whole 1 KiB runs per wave instruction, nobody else touches these lines -> write-through streaming
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int REC, int MOVE>
 __global__ void __launch_bounds__(kThreads)
 bc7_scatter_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
                 const uint64_t* __restrict__ totals, uint64_t n_blocks, uint64_t num_tiles)
@@ -366,20 +593,17 @@ bc7_scatter_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, cons
         if (mode[j] < 9) {
             const int m = mode[j], h = head_bytes(m);
             const int rank = (int)(tb.slot[j * 4 + wave][m] + rank_in_wave[j]);
-            const int ho = tb.lds_off[m] + rank * h - 1;            // byte k of the block goes to ho + k (k <= h)
-            const int to = tb.lds_off[9 + m] + rank * (15 - h) - 1 - h;  // ... or to + k (k > h)
-            const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-            for (int k = 1; k < 16; ++k) {
-                const uint8_t byte = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                img[(k <= h ? ho : to) + k] = byte;
-            }
+            const uint64_t lo = (uint64_t)q[j].x | ((uint64_t)q[j].y << 32);
+            const uint64_t hi = (uint64_t)q[j].z | ((uint64_t)q[j].w << 32);
+            put_records<REC>(img + tb.lds_off[m] + rank * h, img + tb.lds_off[9 + m] + rank * (15 - h), h, lo, hi);
         }
     }
     __syncthreads();
-    move_pieces<true>(img, tb, soa, n_blocks * 16);
+    if (MOVE == 0) move_pieces_v0<true>(img, tb, soa, n_blocks * 16);
+    else pieces_to_global(img, tb, soa);
 }
 
+template <int REC, int MOVE>
 __global__ void __launch_bounds__(kThreads)
 bc7_gather_inv(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
                const uint64_t* __restrict__ totals, uint64_t n_blocks, uint64_t num_tiles)
@@ -404,7 +628,8 @@ bc7_gather_inv(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const
     }
     uint32_t rank_in_wave[kVecs];
     rank_and_layout(mode, rank_in_wave, tb, origin);
-    move_pieces<false>(img, tb, const_cast<uint8_t*>(soa), n_blocks * 16);
+    if (MOVE == 0) move_pieces_v0<false>(img, tb, const_cast<uint8_t*>(soa), n_blocks * 16);
+    else pieces_from_global(img, tb, soa, n_blocks * 16);
     __syncthreads();
 
 #pragma unroll
@@ -413,13 +638,571 @@ bc7_gather_inv(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const
             const uint64_t b = tile * kTileBlocks + (uint64_t)j * kThreads + threadIdx.x;
             const int m = mode[j], h = head_bytes(m);
             const int rank = (int)(tb.slot[j * 4 + wave][m] + rank_in_wave[j]);
-            const int ho = tb.lds_off[m] + rank * h - 1;
-            const int to = tb.lds_off[9 + m] + rank * (15 - h) - 1 - h;
-            uint32_t w[4] = {b0[j] & 0xFF, 0, 0, 0};
+            uint64_t lo = b0[j] & 0xFF, hi = 0;
+            get_records<REC>(img + tb.lds_off[m] + rank * h, img + tb.lds_off[9 + m] + rank * (15 - h), h, lo, hi);
+            store_block(aos + b * 16, u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)});
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 4b. scatter / gather, second version.  The first one is VALU-issue bound (1120 VALU instructions per wave for
+//     256 blocks, ~80 % VALU utilisation, profiles/r01_l); this one removes instructions:
+//       * ranks from a 4-bit match (4 ballots + 2 mbcnt per vector) instead of 9 ballots with 9 selects;
+//         the first lane of every mode class stores the class size, the wave pre-zeroes its own table rows;
+//       * a wave owns 256 consecutive blocks (vector j = blocks wave*256 + j*64 + lane), so its four table rows
+//         are consecutive;
+//       * record bytes go out with constant instruction offsets from five base pointers (bytes 1-5 always head;
+//         6-7, 8-9, 10-11, 12-15 head or tail by one compare each);
+//       * every record stamps the LDS rows it touches with its piece number, so the mover maps row -> piece with
+//         one byte read instead of a search over the piece table;
+//       * the 18 stream bases come from a one-wave kernel after the scan instead of a loop in every tile.
+// ---------------------------------------------------------------------------------------------------------
+// volatile byte view of an LDS array, in the LDS address space (a plain volatile pointer would turn into flat_* ops)
+typedef volatile uint8_t __attribute__((address_space(3))) lds_byte;
+__device__ __forceinline__ lds_byte* lds_bytes(uint8_t* p) { return (lds_byte*)p; }
+
+constexpr int kRows = kImageBytes / 16;            // 996 LDS rows of 16 bytes
+constexpr int kStampBytes = 1024;
+static_assert(kRows <= kStampBytes && kImageBytes % 16 == 0, "stamp table covers the image");
+constexpr int kRowIters = (kRows + kThreads - 1) / kThreads;
+
+struct PieceRef {           // 16 bytes, read with one ds_read_b128
+    uint64_t g_row0;        // global byte offset of the piece's first row (16-byte aligned)
+    int32_t lds_first;      // LDS byte offset of the piece's first byte; row0 = lds_first >> 4, a0 = lds_first & 15
+    int32_t bytes;
+};
+
+struct TileTables2 {
+    uint32_t raw[16][9];
+    uint32_t slot[16][9];
+    __attribute__((aligned(16))) PieceRef piece[18];
+    int seg_prefix[19];     // 16-byte rows of the pieces, flattened (search-based mover)
+    __attribute__((aligned(16))) uint8_t stamp[kStampBytes];   // row -> piece + 1; 0 = padding row (stamp-based mover)
+};
+
+__device__ __forceinline__ int head_bytes2(int m)
+{
+    // H[m] = 5 + 2 * {2, 2, 3, 3, 0, 1, 1, 3, 5}[m], three bits per mode
+    return 5 + 2 * (int)((0x56486d2u >> (3 * m)) & 7u);
+}
+
+__global__ void __launch_bounds__(64)
+bc7_stream_bases(const uint64_t* __restrict__ totals, uint64_t* __restrict__ bases, uint64_t n_blocks)
+{
+    const int r = threadIdx.x;
+    if (r >= 18)
+        return;
+    const int m = r < 9 ? r : r - 9;
+    uint64_t base = n_blocks;
+    for (int mm = 0; mm < m; ++mm)
+        base += totals[mm] * 15;
+    if (r >= 9)
+        base += totals[m] * (uint64_t)head_bytes2(m);
+    bases[r] = base;
+}
+
+// rank of this lane among the earlier lanes of the wave holding the same key (0..15), and the class size
+__device__ __forceinline__ void match_rank(int key, uint32_t& rank, uint32_t& count)
+{
+    uint32_t lo = ~0u, hi = ~0u;
 #pragma unroll
-            for (int k = 1; k < 16; ++k)
-                w[k >> 2] |= (uint32_t)img[(k <= h ? ho : to) + k] << (8 * (k & 3));
-            __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4*>(aos + b * 16));
+    for (int bit = 0; bit < 4; ++bit) {
+        const bool mine = (key >> bit) & 1;
+        const uint64_t b = __ballot(mine);
+        const uint64_t sel = mine ? b : ~b;
+        lo &= (uint32_t)sel;
+        hi &= (uint32_t)(sel >> 32);
+    }
+    rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    count = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+}
+
+__device__ __forceinline__ void rank_and_layout2(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables2& tb,
+                                                 uint64_t origin)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < kStampBytes / 16)
+        reinterpret_cast<u32x4*>(tb.stamp)[threadIdx.x] = u32x4{0, 0, 0, 0};
+    if (lane < 36)
+        (&tb.raw[wave * 4][0])[lane] = 0;   // this wave's four rows; LDS operations of one wave stay in order
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        uint32_t count;
+        match_rank(mode[j], rank_in_wave[j], count);
+        if (rank_in_wave[j] == 0 && mode[j] < 9)
+            tb.raw[wave * 4 + j][mode[j]] = count;
+    }
+    __syncthreads();
+    if (threadIdx.x < 144) {
+        const int sidx = threadIdx.x / 9, m = threadIdx.x - sidx * 9;
+        uint32_t excl = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            excl += i < sidx ? tb.raw[i][m] : 0;
+        tb.slot[sidx][m] = excl;
+    }
+    if (wave == 3) {   // the piece table: lanes 0..17 of the last wave (the first three carry the slot prefixes)
+        int bytes = 0, a0 = 0;
+        if (lane < 18) {
+            const int m = lane < 9 ? lane : lane - 9;
+            const int w = lane < 9 ? head_bytes2(m) : 15 - head_bytes2(m);
+            uint32_t count = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                count += tb.raw[i][m];
+            bytes = (int)count * w;
+            a0 = (int)(origin & 15);
+        }
+        const int nseg = bytes ? (a0 + bytes + 15) >> 4 : 0;
+        int p = lane < 18 ? bytes + 31 : 0, q = nseg;   // inclusive prefixes of (bytes + 31) and of the row counts
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int pu = __shfl_up(p, o), qu = __shfl_up(q, o);
+            if (lane >= o) {
+                p += pu;
+                q += qu;
+            }
+        }
+        if (lane < 18) {
+            tb.seg_prefix[lane] = q - nseg;
+            if (lane == 17)
+                tb.seg_prefix[18] = q;
+            const int excl_p = p - (bytes + 31);
+            PieceRef ref;
+            ref.lds_first = ((excl_p + 15) & ~15) + a0;
+            ref.bytes = bytes;
+            ref.g_row0 = origin - (uint64_t)a0;
+            tb.piece[lane] = ref;
+        }
+    }
+    __syncthreads();
+}
+
+// lanes 0..17 of wave 3: global byte offset of this tile's piece r.  Branch-free (the other lanes fetch piece 0 or 17
+// and ignore it) so that the two loads are issued together with the tile's block loads instead of ahead of them.
+__device__ __forceinline__ uint64_t fetch_piece_origin2(const uint32_t* prefix, const uint64_t* bases, uint64_t num_tiles,
+                                                        uint64_t tile)
+{
+    int r = (int)threadIdx.x - 192;
+    r = r < 0 ? 0 : (r > 17 ? 17 : r);
+    const int m = r < 9 ? r : r - 9;
+    const uint64_t w = r < 9 ? head_bytes2(m) : 15 - head_bytes2(m);
+    return bases[r] + (uint64_t)prefix[(uint64_t)m * num_tiles + tile] * w;
+}
+
+struct RecordPlace {
+    int head, tail, h;   // LDS byte offsets of the block's head and tail records
+    int head0, tail0;    // ... and of the first byte of their pieces
+};
+
+__device__ __forceinline__ RecordPlace place_records(const TileTables2& tb, int m, int slot_row, uint32_t rank_in_wave)
+{
+    RecordPlace rp;
+    rp.h = head_bytes2(m);
+    const int rank = (int)(tb.slot[slot_row][m] + rank_in_wave);
+    rp.head0 = tb.piece[m].lds_first;
+    rp.tail0 = tb.piece[9 + m].lds_first;
+    rp.head = rp.head0 + rank * rp.h;
+    rp.tail = rp.tail0 + rank * (15 - rp.h);
+    return rp;
+}
+
+// Every LDS row of a piece is stamped exactly once, by the record that owns the row's first piece byte: a record
+// stamps its first row when it starts the piece or starts exactly on the row boundary (otherwise its predecessor
+// already reaches into that row), and its last row when it crosses into it.  (Stamping from every record makes
+// dozens of lanes write the same byte, which the LDS serialises: measured 3000 wait cycles per wave.)
+__device__ __forceinline__ void stamp_record(TileTables2& tb, int first, int bytes, int piece_first, uint8_t mark)
+{
+    const int row_s = first >> 4, row_e = (first + bytes - 1) >> 4;
+    if (first == piece_first || (first & 15) == 0)
+        tb.stamp[row_s] = mark;
+    if (row_e != row_s)
+        tb.stamp[row_e] = mark;
+}
+
+struct RowRef {
+    bool live, whole;
+    int lo, hi;
+    uint64_t gseg;
+};
+
+__device__ __forceinline__ RowRef locate_row(const TileTables2& tb, int row)
+{
+    RowRef ref{};
+    const int st = row < kRows ? tb.stamp[row] : 0;
+    ref.live = st != 0;
+    if (!ref.live)
+        return ref;
+    const PieceRef pc = tb.piece[st - 1];
+    const int a0 = pc.lds_first & 15;
+    const int k = row - (pc.lds_first >> 4);
+    ref.gseg = pc.g_row0 + (uint64_t)(16 * k);
+    ref.lo = k == 0 ? a0 : 0;
+    const int end = a0 + pc.bytes - 16 * k;
+    ref.hi = end < 16 ? end : 16;
+    ref.whole = ref.lo == 0 && ref.hi == 16;
+    return ref;
+}
+
+// search-based alternative: flat segment index s -> piece by 17 compares against the SGPR-resident prefix table
+__device__ __forceinline__ RowRef locate_segment2(const TileTables2& tb, const int (&sp)[19], int s, int& row)
+{
+    RowRef ref{};
+    row = 0;
+    ref.live = s < sp[18];
+    if (!ref.live)
+        return ref;
+    int r = 0;
+#pragma unroll
+    for (int i = 1; i < 18; ++i)
+        r += sp[i] <= s ? 1 : 0;
+    const int k = s - tb.seg_prefix[r];
+    const PieceRef pc = tb.piece[r];
+    const int a0 = pc.lds_first & 15;
+    row = (pc.lds_first >> 4) + k;
+    ref.gseg = pc.g_row0 + (uint64_t)(16 * k);
+    ref.lo = k == 0 ? a0 : 0;
+    const int end = a0 + pc.bytes - 16 * k;
+    ref.hi = end < 16 ? end : 16;
+    ref.whole = ref.lo == 0 && ref.hi == 16;
+    return ref;
+}
+
+template <bool STAMPS>
+__global__ void __launch_bounds__(kThreads)
+bc7_scatter_fwd2(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
+                 const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t img[kImageBytes];
+    __shared__ TileTables2 tb;
+    const uint64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
+
+    u32x4 q[kVecs];
+    int mode[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
+        // no branch around the load: all four are in flight together (lanes past the end re-read the last block)
+        q[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(aos + (b < n_blocks ? b : n_blocks - 1) * 16));
+        mode[j] = b < n_blocks ? mode_of(q[j].x) : 9;
+    }
+    uint32_t rank_in_wave[kVecs];
+    rank_and_layout2(mode, rank_in_wave, tb, origin);
+
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        if (mode[j] < 9) {
+            const RecordPlace rp = place_records(tb, mode[j], wave * 4 + j, rank_in_wave[j]);
+            if (STAMPS) {
+                stamp_record(tb, rp.head, rp.h, rp.head0, (uint8_t)(mode[j] + 1));
+                if (rp.h < 15)
+                    stamp_record(tb, rp.tail, 15 - rp.h, rp.tail0, (uint8_t)(mode[j] + 10));
+            }
+            // volatile: the compiler would otherwise fuse neighbouring byte accesses into ds_write_b32/b16 at odd
+            // addresses, which the LDS executes far slower than the separate byte writes (measured, r01_s)
+            lds_byte* ho = lds_bytes(img) + rp.head - 1;             // block byte k (1 <= k <= h) -> ho[k]
+            lds_byte* to = lds_bytes(img) + rp.tail - 1 - rp.h;      // block byte k (k > h)       -> to[k]
+            lds_byte* p67 = rp.h >= 7 ? ho : to;
+            lds_byte* p89 = rp.h >= 9 ? ho : to;
+            lds_byte* pab = rp.h >= 11 ? ho : to;
+            lds_byte* pcf = rp.h >= 15 ? ho : to;
+            const uint32_t w0 = q[j].x, w1 = q[j].y, w2 = q[j].z, w3 = q[j].w;
+            ho[1] = (uint8_t)(w0 >> 8);
+            ho[2] = (uint8_t)(w0 >> 16);
+            ho[3] = (uint8_t)(w0 >> 24);
+            ho[4] = (uint8_t)w1;
+            ho[5] = (uint8_t)(w1 >> 8);
+            p67[6] = (uint8_t)(w1 >> 16);
+            p67[7] = (uint8_t)(w1 >> 24);
+            p89[8] = (uint8_t)w2;
+            p89[9] = (uint8_t)(w2 >> 8);
+            pab[10] = (uint8_t)(w2 >> 16);
+            pab[11] = (uint8_t)(w2 >> 24);
+            pcf[12] = (uint8_t)w3;
+            pcf[13] = (uint8_t)(w3 >> 8);
+            pcf[14] = (uint8_t)(w3 >> 16);
+            pcf[15] = (uint8_t)(w3 >> 24);
+        }
+    }
+    __syncthreads();
+
+    int sp[19];
+    if (!STAMPS) {
+#pragma unroll
+        for (int i = 0; i < 19; ++i)
+            sp[i] = __builtin_amdgcn_readfirstlane(tb.seg_prefix[i]);
+    }
+#pragma unroll
+    for (int it = 0; it < kRowIters; ++it) {
+        int row = it * kThreads + (int)threadIdx.x;
+        const RowRef ref = STAMPS ? locate_row(tb, row) : locate_segment2(tb, sp, row, row);
+        if (!ref.live)
+            continue;
+        if (ref.whole) {
+            // neighbouring tiles share 128-byte lines here: plain streaming store, L2 merges the halves
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(img + 16 * row),
+                                        reinterpret_cast<u32x4*>(soa + ref.gseg));
+        } else {
+            uint8_t* dst = soa + ref.gseg;
+            const uint8_t* src = img + 16 * row;
+            partial_segment(ref.lo, ref.hi, [&](int p, int w) { typed_move(dst, src, p, w); });
+        }
+    }
+}
+
+template <bool STAMPS>
+__global__ void __launch_bounds__(kThreads)
+bc7_gather_inv2(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
+                const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t img[kImageBytes];
+    __shared__ TileTables2 tb;
+    const uint64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
+    const uint64_t total_bytes = n_blocks * 16;
+
+    int mode[kVecs];
+    uint32_t b0[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
+        b0[j] = soa[b < n_blocks ? b : n_blocks - 1];   // branch-free: the four loads overlap
+        mode[j] = b < n_blocks ? mode_of(b0[j]) : 9;
+    }
+    uint32_t rank_in_wave[kVecs];
+    rank_and_layout2(mode, rank_in_wave, tb, origin);
+
+    RecordPlace rp[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        if (mode[j] < 9) {
+            rp[j] = place_records(tb, mode[j], wave * 4 + j, rank_in_wave[j]);
+            if (STAMPS) {
+                stamp_record(tb, rp[j].head, rp[j].h, rp[j].head0, (uint8_t)(mode[j] + 1));
+                if (rp[j].h < 15)
+                    stamp_record(tb, rp[j].tail, 15 - rp[j].h, rp[j].tail0, (uint8_t)(mode[j] + 10));
+            }
+        }
+    }
+    int sp[19];
+    if (STAMPS) {
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 19; ++i)
+            sp[i] = __builtin_amdgcn_readfirstlane(tb.seg_prefix[i]);
+    }
+
+    // rows in: all loads of the lane are in flight before the first LDS write.  A whole aligned row is fetched
+    // whenever it lies inside the buffer: the bytes of neighbouring pieces land in this piece's LDS padding.
+    RowRef ref[kRowIters];
+    int rows[kRowIters];
+    u32x4 v[kRowIters];
+#pragma unroll
+    for (int it = 0; it < kRowIters; ++it) {
+        rows[it] = it * kThreads + (int)threadIdx.x;
+        ref[it] = STAMPS ? locate_row(tb, rows[it]) : locate_segment2(tb, sp, rows[it], rows[it]);
+        ref[it].whole = ref[it].live && ref[it].gseg + 16 <= total_bytes;
+        // unconditional (rows that are not fetched whole read offset 0 and drop the result): no branch, no wait
+        v[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(soa + (ref[it].whole ? ref[it].gseg : 0)));
+    }
+#pragma unroll
+    for (int it = 0; it < kRowIters; ++it) {
+        const int row = rows[it];
+        if (ref[it].whole) {
+            *reinterpret_cast<u32x4*>(img + 16 * row) = v[it];
+        } else if (ref[it].live) {
+            uint8_t* dst = img + 16 * row;
+            const uint8_t* src = soa + ref[it].gseg;
+            partial_segment(ref[it].lo, ref[it].hi, [&](int p, int w) { typed_move(dst, src, p, w); });
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        if (mode[j] < 9) {
+            const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
+            // volatile: keeps 15 ds_read_u8; fused unaligned ds_read_u16/b32 are far slower on this LDS
+            const lds_byte* ho = lds_bytes(img) + rp[j].head - 1;
+            const lds_byte* to = lds_bytes(img) + rp[j].tail - 1 - rp[j].h;
+            const lds_byte* p67 = rp[j].h >= 7 ? ho : to;
+            const lds_byte* p89 = rp[j].h >= 9 ? ho : to;
+            const lds_byte* pab = rp[j].h >= 11 ? ho : to;
+            const lds_byte* pcf = rp[j].h >= 15 ? ho : to;
+            u32x4 o;
+            o.x = (b0[j] & 0xFF) | ((uint32_t)ho[1] << 8) | ((uint32_t)ho[2] << 16) | ((uint32_t)ho[3] << 24);
+            o.y = (uint32_t)ho[4] | ((uint32_t)ho[5] << 8) | ((uint32_t)p67[6] << 16) | ((uint32_t)p67[7] << 24);
+            o.z = (uint32_t)p89[8] | ((uint32_t)p89[9] << 8) | ((uint32_t)pab[10] << 16) | ((uint32_t)pab[11] << 24);
+            o.w = (uint32_t)pcf[12] | ((uint32_t)pcf[13] << 8) | ((uint32_t)pcf[14] << 16) | ((uint32_t)pcf[15] << 24);
+            store_block(aos + b * 16, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 4c. scatter / gather, direct version: no LDS image.  gfx950 global memory instructions take any byte address, and
+//     the lanes of one mode class with consecutive ranks touch consecutive records, so a wave instruction still
+//     covers contiguous runs of the stream.  Forward: every block stores its head and its tail record as two
+//     possibly overlapping words each (put_records_global).  Inverse: one 16-byte load at the head record and one
+//     at the tail record, merged in registers.  LDS holds only the rank tables.
+// ---------------------------------------------------------------------------------------------------------
+struct TileTables3 {
+    uint32_t raw[16][9];
+    uint32_t slot[16][9];
+    uint64_t piece_g[18];   // global byte offset of the tile's piece r
+};
+
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+
+__device__ __forceinline__ void rank_and_origins(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables3& tb,
+                                                 uint64_t origin)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 36)
+        (&tb.raw[wave * 4][0])[lane] = 0;
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        uint32_t count;
+        match_rank(mode[j], rank_in_wave[j], count);
+        if (rank_in_wave[j] == 0 && mode[j] < 9)
+            tb.raw[wave * 4 + j][mode[j]] = count;
+    }
+    if (wave == 3 && lane < 18)
+        tb.piece_g[lane] = origin;
+    __syncthreads();
+    if (threadIdx.x < 144) {
+        const int sidx = threadIdx.x / 9, m = threadIdx.x - sidx * 9;
+        uint32_t excl = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            excl += i < sidx ? tb.raw[i][m] : 0;
+        tb.slot[sidx][m] = excl;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void put_records_global(uint8_t* hp, uint8_t* tp, int h, uint64_t lo, uint64_t hi)
+{
+    const int t = 15 - h;
+    if (h >= 8) {   // modes 0-3, 7, 8: head 9/11/15 bytes, tail 6/4/0
+        st64(hp, bytes_from(lo, hi, 1));
+        st64(hp + h - 8, bytes_from(lo, hi, h - 7));
+        if (t) {
+            st32(tp, (uint32_t)bytes_from(lo, hi, h + 1));
+            st32(tp + t - 4, (uint32_t)(hi >> 32));
+        }
+    } else {        // modes 4-6: head 5/7 bytes, tail 10/8
+        st32(hp, (uint32_t)(lo >> 8));
+        st32(hp + h - 4, (uint32_t)bytes_from(lo, hi, h - 3));
+        st64(tp, bytes_from(lo, hi, h + 1));
+        st64(tp + t - 8, hi);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+bc7_scatter_fwd3(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
+                 const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
+{
+    __shared__ TileTables3 tb;
+    const uint64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
+
+    u32x4 q[kVecs];
+    int mode[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
+        q[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(aos + (b < n_blocks ? b : n_blocks - 1) * 16));
+        mode[j] = b < n_blocks ? mode_of(q[j].x) : 9;
+    }
+    uint32_t rank_in_wave[kVecs];
+    rank_and_origins(mode, rank_in_wave, tb, origin);
+
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        if (mode[j] < 9) {
+            const int m = mode[j], h = head_bytes2(m);
+            const uint64_t rank = tb.slot[wave * 4 + j][m] + rank_in_wave[j];
+            const uint64_t lo = (uint64_t)q[j].x | ((uint64_t)q[j].y << 32);
+            const uint64_t hi = (uint64_t)q[j].z | ((uint64_t)q[j].w << 32);
+            put_records_global(soa + tb.piece_g[m] + rank * (uint64_t)h, soa + tb.piece_g[9 + m] + rank * (uint64_t)(15 - h), h,
+                               lo, hi);
+        }
+    }
+}
+
+// 16 bytes at p, or -- when that would run past the end of the buffer -- the 16 last bytes of the buffer shifted down
+__device__ __forceinline__ void load_record16(const uint8_t* soa, uint64_t at, uint64_t total_bytes, uint64_t& lo, uint64_t& hi)
+{
+    const bool safe = at + 16 <= total_bytes;
+    const uint64_t from = safe ? at : total_bytes - 16;
+    const u32x4 v = *reinterpret_cast<const u32x4_unaligned*>(soa + from);
+    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    if (!safe) {
+        const int skip = (int)(at - from);   // 1..15 bytes
+        const uint64_t l2 = bytes_from(lo, hi, skip);
+        hi = skip < 8 ? hi >> (8 * skip) : 0;
+        lo = l2;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+bc7_gather_inv3(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
+                const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
+{
+    __shared__ TileTables3 tb;
+    const uint64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
+    const uint64_t total_bytes = n_blocks * 16;
+
+    int mode[kVecs];
+    uint32_t b0[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
+        b0[j] = soa[b < n_blocks ? b : n_blocks - 1];
+        mode[j] = b < n_blocks ? mode_of(b0[j]) : 9;
+    }
+    uint32_t rank_in_wave[kVecs];
+    rank_and_origins(mode, rank_in_wave, tb, origin);
+
+    uint64_t hl[kVecs], hh[kVecs], tl[kVecs], th[kVecs];
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        const int m = mode[j] < 9 ? mode[j] : 8, h = head_bytes2(m);
+        const uint64_t rank = mode[j] < 9 ? tb.slot[wave * 4 + j][m] + rank_in_wave[j] : 0;
+        // lanes past the end and mode 8 (no tail) fetch something harmless: offset 0 is always inside the buffer
+        const uint64_t gh = mode[j] < 9 ? tb.piece_g[m] + rank * (uint64_t)h : 0;
+        const uint64_t gt = mode[j] < 8 ? tb.piece_g[9 + m] + rank * (uint64_t)(15 - h) : 0;
+        load_record16(soa, gh, total_bytes, hl[j], hh[j]);
+        load_record16(soa, gt, total_bytes, tl[j], th[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kVecs; ++j) {
+        if (mode[j] < 9) {
+            const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
+            const int s = head_bytes2(mode[j]) + 1;           // bytes 0..s-1 = mode byte + head, tail from byte s
+            uint64_t lo = (b0[j] & 0xFF) | (hl[j] << 8);
+            uint64_t hi = (hh[j] << 8) | (hl[j] >> 56);
+            if (s < 8) {           // s = 6: head is 5 bytes
+                lo &= (1ull << (8 * s)) - 1;
+                lo |= tl[j] << (8 * s);
+                hi = (th[j] << (8 * s)) | (tl[j] >> (64 - 8 * s));
+            } else if (s == 8) {
+                hi = tl[j];
+            } else if (s < 16) {   // s = 10 or 12
+                hi &= (1ull << (8 * (s - 8))) - 1;
+                hi |= tl[j] << (8 * (s - 8));
+            }
+            store_block(aos + b * 16, u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)});
         }
     }
 }
@@ -451,6 +1234,7 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
         return hipErrorInvalidValue;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     uint64_t* totals = reinterpret_cast<uint64_t*>(ws);                    // 9 x u64: blocks per mode
+    uint64_t* bases = reinterpret_cast<uint64_t*>(ws + 96);                // 18 x u64: stream bases (version 2 kernels)
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 256);
     uint32_t* prefix = hist + 9 * tiles;
     uint32_t* gsum = prefix + 9 * tiles;
@@ -460,18 +1244,34 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
     if (!inverse)
         hipLaunchKernelGGL(bc7_hist_fwd, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, hist, n_blocks, tiles);
     else
-        hipLaunchKernelGGL(bc7_hist_inv, dim3((unsigned)((tiles + 3) / 4)), dim3(kThreads), 0, stream, s8, hist, n_blocks,
-                           tiles);
+        hipLaunchKernelGGL(bc7_hist_inv, dim3((unsigned)((tiles + kInvTilesPerWave * 4 - 1) / (kInvTilesPerWave * 4))), dim3(kThreads), 0,
+                           stream, s8, hist, n_blocks, tiles);
     hipLaunchKernelGGL(bc7_group_sums, dim3((unsigned)groups, 9), dim3(kThreads), 0, stream, hist, gsum, tiles,
                        (uint32_t)groups);
     hipLaunchKernelGGL(bc7_scan, dim3((unsigned)groups, 9), dim3(1024), 0, stream, hist, gsum, prefix, totals, tiles,
                        (uint32_t)groups);
-    if (!inverse)
-        hipLaunchKernelGGL(bc7_scatter_fwd, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, totals,
-                           n_blocks, tiles);
-    else
-        hipLaunchKernelGGL(bc7_gather_inv, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, totals,
-                           n_blocks, tiles);
+    static const int variant = [] { const char* e = getenv("DXTLT_BC7_VARIANT"); return e ? atoi(e) : 4; }();
+    auto go = [&](auto fwd_kernel, auto inv_kernel, const uint64_t* table) {
+        if (!inverse)
+            hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, table, n_blocks,
+                               tiles);
+        else
+            hipLaunchKernelGGL(inv_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, table, n_blocks,
+                               tiles);
+    };
+    if (variant >= 4) {
+        hipLaunchKernelGGL(bc7_stream_bases, dim3(1), dim3(64), 0, stream, totals, bases, n_blocks);
+        if (variant == 5) go(bc7_scatter_fwd3, bc7_gather_inv3, bases);
+        else if (variant == 6) go(bc7_scatter_fwd2<false>, bc7_gather_inv2<false>, bases);
+        else go(bc7_scatter_fwd2<true>, bc7_gather_inv2<true>, bases);
+        return hipGetLastError();
+    }
+    switch (variant) {
+    case 0: go(bc7_scatter_fwd<0, 0>, bc7_gather_inv<0, 0>, totals); break;
+    case 1: go(bc7_scatter_fwd<1, 0>, bc7_gather_inv<1, 0>, totals); break;
+    case 2: go(bc7_scatter_fwd<0, 1>, bc7_gather_inv<0, 1>, totals); break;
+    default: go(bc7_scatter_fwd<1, 1>, bc7_gather_inv<1, 1>, totals); break;
+    }
     return hipGetLastError();
 }
 
