@@ -10,15 +10,13 @@
 //   2. bc7_group_sums  per group of 1024 tiles: sum of the tile histograms
 //   3. bc7_scan        per group: exclusive prefix of every mode's counts over all earlier tiles; the last group
 //                      also records the nine grand totals, from which the 18 stream bases follow
-//   4. bc7_scatter_fwd / bc7_gather_inv   per tile: rank every block inside its mode (wave ballots + a 16x9 LDS
+//   3b. bc7_stream_bases  one wave: the 18 stream bases from the nine totals
+//   4. bc7_scatter_fwd / bc7_gather_inv   per tile: rank every block inside its mode (wave match + a 16x9 LDS
 //                      table), build the tile's 18 stream pieces in LDS at offsets congruent to their global
-//                      addresses modulo 16, and move every piece with aligned 16-byte accesses (partial first/last
-//                      segments bytewise) -- the shifted-tile scheme of bcn_kernels.hip applied to 18 variable pieces.
+//                      addresses modulo 16, and move every piece with aligned 16-byte accesses.
 // HBM traffic: forward reads the blocks twice (histogram, then scatter) and writes them once = 3*len against an
 // algorithmic 2*len; inverse reads `first` twice and everything else once = 2.06*len.
 #include <hip/hip_runtime.h>
-
-#include <cstdlib>
 
 #include "bc7_launch.h"
 
@@ -35,8 +33,8 @@ constexpr int kImageBytes = 15 * kTileBlocks + 18 * 32;  // pieces + (31 bytes o
 
 __device__ __forceinline__ int head_bytes(int m)
 {
-    // H[m] = {9, 9, 11, 11, 5, 7, 7, 11, 15}, packed 4 bits each
-    return (int)((0xFB775BB99ull >> (4 * m)) & 0xF);
+    // H[m] = 5 + 2 * {2, 2, 3, 3, 0, 1, 1, 3, 5}[m], three bits per mode
+    return 5 + 2 * (int)((0x56486d2u >> (3 * m)) & 7u);
 }
 
 __device__ __forceinline__ int mode_of(uint32_t b0)
@@ -215,193 +213,6 @@ bc7_scan(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, u
         totals[m] = (uint64_t)gbase + wbase + incl;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 4. scatter / gather
-// ---------------------------------------------------------------------------------------------------------
-struct TileTables {
-    uint32_t raw[16][9];    // per (vector j, wave w) slot: blocks of mode m in that slot
-    uint32_t slot[16][9];   // ... exclusive prefix over the slots (= blocks of mode m earlier in this tile)
-    int lds_off[18];        // LDS offset of piece r (congruent to its global address modulo 16)
-    int bytes[18];
-    int seg_prefix[19];     // 16-byte segments of the pieces, flattened
-    uint64_t g_off[18];     // global byte offset of piece r inside the transformed buffer
-};
-
-// Ranks of this lane's blocks inside their modes and the tile's piece table, with two workgroup barriers:
-//   ballots -> raw slot counts -> barrier -> 144 lanes turn them into exclusive slot prefixes while lanes 0..17 (wave 0)
-//   derive their piece's size from the same raw counts and lay the 18 pieces out with wave-level prefix sums -> barrier.
-// LDS layout rule: piece r starts at align16(P_r) + (g_off[r] & 15) with P_r = sum over earlier pieces of (bytes + 31),
-// so every piece has room for its own misalignment and its 16-byte segments never touch a neighbour's.
-__device__ __forceinline__ void rank_and_layout(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables& tb,
-                                                uint64_t origin)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        rank_in_wave[j] = 0;
-#pragma unroll
-        for (int m = 0; m < 9; ++m) {
-            const uint64_t mask = __ballot(mode[j] == m);
-            if (mode[j] == m)
-                rank_in_wave[j] = (uint32_t)__popcll(mask & lt);
-            if (lane == 0)
-                tb.raw[j * 4 + wave][m] = (uint32_t)__popcll(mask);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 144) {
-        const int sidx = threadIdx.x / 9, m = threadIdx.x - sidx * 9;
-        uint32_t excl = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            excl += i < sidx ? tb.raw[i][m] : 0;
-        tb.slot[sidx][m] = excl;
-    }
-    if (wave == 0) {
-        int bytes = 0, a0 = 0, nseg = 0;
-        if (lane < 18) {
-            const int m = lane < 9 ? lane : lane - 9;
-            const int w = lane < 9 ? head_bytes(m) : 15 - head_bytes(m);
-            uint32_t count = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                count += tb.raw[i][m];
-            bytes = (int)count * w;
-            a0 = (int)(origin & 15);
-            nseg = bytes ? (a0 + bytes + 15) >> 4 : 0;
-        }
-        // inclusive prefix sums over lanes 0..17 of (bytes + 31) and of nseg
-        int p = lane < 18 ? bytes + 31 : 0, q = nseg;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const int pu = __shfl_up(p, o), qu = __shfl_up(q, o);
-            if (lane >= o) {
-                p += pu;
-                q += qu;
-            }
-        }
-        if (lane < 18) {
-            const int excl_p = p - (bytes + 31);
-            tb.lds_off[lane] = ((excl_p + 15) & ~15) + a0;
-            tb.bytes[lane] = bytes;
-            tb.g_off[lane] = origin;
-            tb.seg_prefix[lane] = q - nseg;
-            if (lane == 17)
-                tb.seg_prefix[18] = q;
-        }
-    }
-    __syncthreads();
-}
-
-// piece table: 9 head pieces then 9 tail pieces.  Lanes 0..17 fetch their tile prefix and stream base at kernel entry
-// (fetch_piece_origin), so that this dependent global read overlaps the tile's block loads instead of following them.
-__device__ __forceinline__ uint64_t fetch_piece_origin(const uint32_t* prefix, const uint64_t* totals, uint64_t num_tiles,
-                                                       uint64_t tile, uint64_t n_blocks)
-{
-    if (threadIdx.x >= 18)
-        return 0;
-    const int r = threadIdx.x, m = r < 9 ? r : r - 9;
-    const uint64_t w = r < 9 ? head_bytes(m) : 15 - head_bytes(m);
-    uint64_t base = n_blocks;
-    for (int mm = 0; mm < m; ++mm)
-        base += totals[mm] * 15;
-    if (r >= 9)
-        base += totals[m] * (uint64_t)head_bytes(m);
-    return base + (uint64_t)prefix[(uint64_t)m * num_tiles + tile] * w;
-}
-
-// ---- record-wide LDS access -----------------------------------------------------------------------------
-// Head and tail records sit at arbitrary byte offsets of the LDS image.  gfx950 executes DS reads/writes at any
-// byte alignment (the compiler emits ds_{read,write}_b32/b64 for align-1 accesses), so a record is moved as two
-// possibly overlapping words instead of one access per byte: W = 8 for records of 8 bytes or more, else 4, at
-// record offsets 0 and size - W.  Overlapping bytes carry identical data.
-typedef uint64_t u64_unaligned __attribute__((aligned(1)));
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-
-__device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { *reinterpret_cast<u64_unaligned*>(p) = v; }
-__device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { *reinterpret_cast<u32_unaligned*>(p) = v; }
-__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return *reinterpret_cast<const u64_unaligned*>(p); }
-__device__ __forceinline__ uint64_t ld32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
-
-// the 8 bytes of the block (lo = bytes 0..7, hi = bytes 8..15) that start at byte pos, 1 <= pos <= 15; zero-filled
-__device__ __forceinline__ uint64_t bytes_from(uint64_t lo, uint64_t hi, int pos)
-{
-    const int s = 8 * pos;
-    return pos < 8 ? (lo >> s) | (hi << (64 - s)) : hi >> (s - 64);
-}
-
-// OR a chunk into the block at byte pos, 1 <= pos <= 12 (chunks never reach past byte 15)
-__device__ __forceinline__ void place(uint64_t& lo, uint64_t& hi, uint64_t chunk, int pos)
-{
-    const int s = 8 * pos;
-    if (pos < 8) {
-        lo |= chunk << s;
-        hi |= chunk >> (64 - s);
-    } else {
-        hi |= chunk << (s - 64);
-    }
-}
-
-template <int REC>
-__device__ __forceinline__ void put_records(uint8_t* hp, uint8_t* tp, int h, uint64_t lo, uint64_t hi)
-{
-    const int t = 15 - h;
-    if (REC == 0) {
-        uint8_t* ho = hp - 1;
-        uint8_t* to = tp - 1 - h;
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const uint8_t byte = (uint8_t)((k < 8 ? lo : hi) >> (8 * (k & 7)));
-            (k <= h ? ho : to)[k] = byte;
-        }
-        return;
-    }
-    if (h >= 8) {   // modes 0-3, 7, 8: head 9/11/15 bytes, tail 6/4/0
-        st64(hp, bytes_from(lo, hi, 1));
-        st64(hp + h - 8, bytes_from(lo, hi, h - 7));
-        if (t) {
-            st32(tp, (uint32_t)bytes_from(lo, hi, h + 1));
-            st32(tp + t - 4, (uint32_t)(hi >> 32));
-        }
-    } else {        // modes 4-6: head 5/7 bytes, tail 10/8
-        st32(hp, (uint32_t)(lo >> 8));
-        st32(hp + h - 4, (uint32_t)bytes_from(lo, hi, h - 3));
-        st64(tp, bytes_from(lo, hi, h + 1));
-        st64(tp + t - 8, hi);
-    }
-}
-
-template <int REC>
-__device__ __forceinline__ void get_records(const uint8_t* hp, const uint8_t* tp, int h, uint64_t& lo, uint64_t& hi)
-{
-    const int t = 15 - h;
-    if (REC == 0) {
-        const uint8_t* ho = hp - 1;
-        const uint8_t* to = tp - 1 - h;
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const uint64_t byte = (k <= h ? ho : to)[k];
-            if (k < 8) lo |= byte << (8 * k);
-            else hi |= byte << (8 * (k - 8));
-        }
-        return;
-    }
-    if (h >= 8) {
-        place(lo, hi, ld64(hp), 1);
-        place(lo, hi, ld64(hp + h - 8), h - 7);
-        if (t) {
-            place(lo, hi, ld32(tp), h + 1);
-            hi |= ld32(tp + t - 4) << 32;
-        }
-    } else {
-        place(lo, hi, ld32(hp), 1);
-        place(lo, hi, ld32(hp + h - 4), h - 3);
-        place(lo, hi, ld64(tp), h + 1);
-        hi |= ld64(tp + t - 8);
-    }
-}
-
 // ---- piece movement ---------------------------------------------------------------------------------------
 // Bytes [lo, hi) of one 16-byte segment, both pointers 16-byte aligned at byte 0 of the segment: an ascending
 // ladder of naturally aligned 1/2/4/8-byte moves from lo, then a descending one for what is left.
@@ -428,235 +239,29 @@ __device__ __forceinline__ void typed_move(uint8_t* dst, const uint8_t* src, int
     if (w == 8) *reinterpret_cast<uint64_t*>(dst + p) = *reinterpret_cast<const uint64_t*>(src + p);
 }
 
-constexpr int kMoveIters = (kImageBytes / 16 + kThreads - 1) / kThreads;  // upper bound on segments per lane
-
-// Flattened copy of the 18 pieces between LDS and global memory, one 16-byte segment per lane and step.  The
-// segment prefix table is wave-uniform and lives in SGPRs; the piece of a segment is a count of compares.
-struct SegmentRef {
-    bool live, whole;
-    int lseg, lo, hi;
-    uint64_t gseg;
-};
-
-__device__ __forceinline__ SegmentRef locate_segment(const TileTables& tb, const int (&sp)[19], int s)
-{
-    SegmentRef ref{};
-    ref.live = s < sp[18];
-    if (!ref.live)
-        return ref;
-    int r = 0;
-#pragma unroll
-    for (int i = 1; i < 18; ++i)
-        r += sp[i] <= s ? 1 : 0;   // last piece whose first segment is <= s (empty pieces repeat a value)
-    const int k = s - tb.seg_prefix[r];
-    const uint64_t g = tb.g_off[r];
-    const int a0 = (int)(g & 15);
-    ref.gseg = g - a0 + (uint64_t)16 * k;
-    ref.lseg = tb.lds_off[r] - a0 + 16 * k;
-    ref.lo = k == 0 ? a0 : 0;
-    const int end = a0 + tb.bytes[r] - 16 * k;
-    ref.hi = end < 16 ? end : 16;
-    ref.whole = ref.lo == 0 && ref.hi == 16;
-    return ref;
-}
-
-__device__ __forceinline__ void load_segment_table(const TileTables& tb, int (&sp)[19])
-{
-#pragma unroll
-    for (int i = 0; i < 19; ++i)
-        sp[i] = __builtin_amdgcn_readfirstlane(tb.seg_prefix[i]);
-}
-
-__device__ __forceinline__ void pieces_to_global(uint8_t* img, const TileTables& tb, uint8_t* soa)
-{
-    int sp[19];
-    load_segment_table(tb, sp);
-#pragma unroll
-    for (int it = 0; it < kMoveIters; ++it) {
-        const SegmentRef ref = locate_segment(tb, sp, it * kThreads + (int)threadIdx.x);
-        if (!ref.live)
-            continue;
-        if (ref.whole) {
-            // neighbouring tiles share 128-byte lines here: plain streaming store, L2 merges the halves
-            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(img + ref.lseg),
-                                        reinterpret_cast<u32x4*>(soa + ref.gseg));
-        } else {
-            uint8_t* dst = soa + ref.gseg;
-            const uint8_t* src = img + ref.lseg;
-            partial_segment(ref.lo, ref.hi, [&](int p, int w) { typed_move(dst, src, p, w); });
-        }
-    }
-}
-
-__device__ __forceinline__ void pieces_from_global(uint8_t* img, const TileTables& tb, const uint8_t* soa,
-                                                   uint64_t total_bytes)
-{
-    int sp[19];
-    load_segment_table(tb, sp);
-    SegmentRef ref[kMoveIters];
-    u32x4 v[kMoveIters];
-    // all loads of the lane are in flight before the first LDS write.  A whole aligned segment is fetched whenever it
-    // lies inside the buffer: the bytes of neighbouring pieces land in this piece's LDS padding.
-#pragma unroll
-    for (int it = 0; it < kMoveIters; ++it) {
-        ref[it] = locate_segment(tb, sp, it * kThreads + (int)threadIdx.x);
-        ref[it].whole = ref[it].live && ref[it].gseg + 16 <= total_bytes && ref[it].lseg >= 0;
-        v[it] = u32x4{0, 0, 0, 0};
-        if (ref[it].whole)
-            v[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(soa + ref[it].gseg));
-    }
-#pragma unroll
-    for (int it = 0; it < kMoveIters; ++it) {
-        if (ref[it].whole) {
-            *reinterpret_cast<u32x4*>(img + ref[it].lseg) = v[it];
-        } else if (ref[it].live) {
-            uint8_t* dst = img + ref[it].lseg;
-            const uint8_t* src = soa + ref[it].gseg;
-            partial_segment(ref[it].lo, ref[it].hi, [&](int p, int w) { typed_move(dst, src, p, w); });
-        }
-    }
-}
-
-// first version of the mover: binary search over the LDS-resident prefix table, byte loops for partial segments
-template <bool TO_GLOBAL>
-__device__ __forceinline__ void move_pieces_v0(uint8_t* img, const TileTables& tb, uint8_t* soa, uint64_t total_bytes)
-{
-    const int total = tb.seg_prefix[18];
-    for (int s = threadIdx.x; s < total; s += kThreads) {
-        int r = 0;
-#pragma unroll
-        for (int step = 16; step > 0; step >>= 1) {
-            const int cand = r + step;
-            if (cand < 18 && tb.seg_prefix[cand] <= s)
-                r = cand;
-        }
-        const int k = s - tb.seg_prefix[r];
-        const uint64_t g = tb.g_off[r];
-        const int a0 = (int)(g & 15);
-        const uint64_t gseg = g - a0 + (uint64_t)16 * k;
-        const int lseg = tb.lds_off[r] - a0 + 16 * k;
-        const int lo = k == 0 ? a0 : 0;
-        const int end = a0 + tb.bytes[r] - 16 * k;
-        const int hi = end < 16 ? end : 16;
-        if (TO_GLOBAL) {
-            if (lo == 0 && hi == 16) {
-                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(img + lseg), reinterpret_cast<u32x4*>(soa + gseg));
-            } else {
-                for (int p = lo; p < hi; ++p)
-                    soa[gseg + p] = img[lseg + p];
-            }
-        } else {
-            if (gseg + 16 <= total_bytes && lseg >= 0) {
-                *reinterpret_cast<u32x4*>(img + lseg) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(soa + gseg));
-            } else {
-                for (int p = lo; p < hi; ++p)
-                    img[lseg + p] = soa[gseg + p];
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ void store_block(uint8_t* p, u32x4 v)
 {
     // AoS output: whole 1 KiB runs per wave instruction, nobody else touches these lines -> write-through streaming
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int REC, int MOVE>
-__global__ void __launch_bounds__(kThreads)
-bc7_scatter_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
-                const uint64_t* __restrict__ totals, uint64_t n_blocks, uint64_t num_tiles)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t img[kImageBytes];
-    __shared__ TileTables tb;
-    const uint64_t tile = blockIdx.x;
-    const int wave = threadIdx.x >> 6;
-    const uint64_t origin = fetch_piece_origin(prefix, totals, num_tiles, tile, n_blocks);
-
-    u32x4 q[kVecs];
-    int mode[kVecs];
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        const uint64_t b = tile * kTileBlocks + (uint64_t)j * kThreads + threadIdx.x;
-        mode[j] = 9;
-        q[j] = u32x4{0, 0, 0, 0};
-        if (b < n_blocks) {
-            q[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(aos + b * 16));
-            mode[j] = mode_of(q[j].x);
-        }
-    }
-    uint32_t rank_in_wave[kVecs];
-    rank_and_layout(mode, rank_in_wave, tb, origin);
-
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        if (mode[j] < 9) {
-            const int m = mode[j], h = head_bytes(m);
-            const int rank = (int)(tb.slot[j * 4 + wave][m] + rank_in_wave[j]);
-            const uint64_t lo = (uint64_t)q[j].x | ((uint64_t)q[j].y << 32);
-            const uint64_t hi = (uint64_t)q[j].z | ((uint64_t)q[j].w << 32);
-            put_records<REC>(img + tb.lds_off[m] + rank * h, img + tb.lds_off[9 + m] + rank * (15 - h), h, lo, hi);
-        }
-    }
-    __syncthreads();
-    if (MOVE == 0) move_pieces_v0<true>(img, tb, soa, n_blocks * 16);
-    else pieces_to_global(img, tb, soa);
-}
-
-template <int REC, int MOVE>
-__global__ void __launch_bounds__(kThreads)
-bc7_gather_inv(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
-               const uint64_t* __restrict__ totals, uint64_t n_blocks, uint64_t num_tiles)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t img[kImageBytes];
-    __shared__ TileTables tb;
-    const uint64_t tile = blockIdx.x;
-    const int wave = threadIdx.x >> 6;
-    const uint64_t origin = fetch_piece_origin(prefix, totals, num_tiles, tile, n_blocks);
-
-    int mode[kVecs];
-    uint32_t b0[kVecs];
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        const uint64_t b = tile * kTileBlocks + (uint64_t)j * kThreads + threadIdx.x;
-        mode[j] = 9;
-        b0[j] = 0;
-        if (b < n_blocks) {
-            b0[j] = soa[b];
-            mode[j] = mode_of(b0[j]);
-        }
-    }
-    uint32_t rank_in_wave[kVecs];
-    rank_and_layout(mode, rank_in_wave, tb, origin);
-    if (MOVE == 0) move_pieces_v0<false>(img, tb, const_cast<uint8_t*>(soa), n_blocks * 16);
-    else pieces_from_global(img, tb, soa, n_blocks * 16);
-    __syncthreads();
-
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        if (mode[j] < 9) {
-            const uint64_t b = tile * kTileBlocks + (uint64_t)j * kThreads + threadIdx.x;
-            const int m = mode[j], h = head_bytes(m);
-            const int rank = (int)(tb.slot[j * 4 + wave][m] + rank_in_wave[j]);
-            uint64_t lo = b0[j] & 0xFF, hi = 0;
-            get_records<REC>(img + tb.lds_off[m] + rank * h, img + tb.lds_off[9 + m] + rank * (15 - h), h, lo, hi);
-            store_block(aos + b * 16, u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)});
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// 4b. scatter / gather, second version.  The first one is VALU-issue bound (1120 VALU instructions per wave for
-//     256 blocks, ~80 % VALU utilisation, profiles/r01_l); this one removes instructions:
-//       * ranks from a 4-bit match (4 ballots + 2 mbcnt per vector) instead of 9 ballots with 9 selects;
-//         the first lane of every mode class stores the class size, the wave pre-zeroes its own table rows;
-//       * a wave owns 256 consecutive blocks (vector j = blocks wave*256 + j*64 + lane), so its four table rows
-//         are consecutive;
-//       * record bytes go out with constant instruction offsets from five base pointers (bytes 1-5 always head;
-//         6-7, 8-9, 10-11, 12-15 head or tail by one compare each);
-//       * every record stamps the LDS rows it touches with its piece number, so the mover maps row -> piece with
-//         one byte read instead of a search over the piece table;
-//       * the 18 stream bases come from a one-wave kernel after the scan instead of a loop in every tile.
+// 4. scatter / gather.  One tile of 1024 blocks per workgroup; a wave owns 256 consecutive blocks (vector j = blocks
+//    wave*256 + j*64 + lane).  The tile's 18 stream pieces are built in an LDS image at offsets congruent to their
+//    global addresses modulo 16 and moved as aligned 16-byte rows (partial first/last rows with typed 1/2/4/8-byte
+//    moves) -- the shifted-tile scheme of bcn_kernels.hip applied to 18 variable pieces.  What the first version
+//    (profiles/r01_l: 1120 VALU instructions per wave, VALU-issue bound) taught, profiles/r01_s:
+//      * ranks from a 4-bit match (4 ballots + 2 mbcnt per vector) instead of 9 ballots with 9 selects; the first
+//        lane of every mode class stores the class size, every wave pre-zeroes its own four table rows;
+//      * record bytes move with constant instruction offsets from five base pointers (bytes 1-5 always head; 6-7,
+//        8-9, 10-11, 12-15 head or tail by one compare each) -- and as single bytes: DS instructions at addresses
+//        that are not multiples of their width run several times slower, so the byte pointers are volatile to stop
+//        clang from fusing them;
+//      * every LDS row is stamped once with its piece number by the record that owns its first byte, so the mover
+//        maps row -> piece with one byte read instead of a search over the piece table;
+//      * no branch around a global load: all loads of a lane are in flight together (lanes past the end re-read
+//        something harmless);
+//      * the 18 stream bases come from a one-wave kernel after the scan instead of a loop in every tile.
 // ---------------------------------------------------------------------------------------------------------
 // volatile byte view of an LDS array, in the LDS address space (a plain volatile pointer would turn into flat_* ops)
 typedef volatile uint8_t __attribute__((address_space(3))) lds_byte;
@@ -673,19 +278,12 @@ struct PieceRef {           // 16 bytes, read with one ds_read_b128
     int32_t bytes;
 };
 
-struct TileTables2 {
+struct TileTables {
     uint32_t raw[16][9];
     uint32_t slot[16][9];
     __attribute__((aligned(16))) PieceRef piece[18];
-    int seg_prefix[19];     // 16-byte rows of the pieces, flattened (search-based mover)
-    __attribute__((aligned(16))) uint8_t stamp[kStampBytes];   // row -> piece + 1; 0 = padding row (stamp-based mover)
+    __attribute__((aligned(16))) uint8_t stamp[kStampBytes];   // row -> piece + 1; 0 = padding row
 };
-
-__device__ __forceinline__ int head_bytes2(int m)
-{
-    // H[m] = 5 + 2 * {2, 2, 3, 3, 0, 1, 1, 3, 5}[m], three bits per mode
-    return 5 + 2 * (int)((0x56486d2u >> (3 * m)) & 7u);
-}
 
 __global__ void __launch_bounds__(64)
 bc7_stream_bases(const uint64_t* __restrict__ totals, uint64_t* __restrict__ bases, uint64_t n_blocks)
@@ -698,7 +296,7 @@ bc7_stream_bases(const uint64_t* __restrict__ totals, uint64_t* __restrict__ bas
     for (int mm = 0; mm < m; ++mm)
         base += totals[mm] * 15;
     if (r >= 9)
-        base += totals[m] * (uint64_t)head_bytes2(m);
+        base += totals[m] * (uint64_t)head_bytes(m);
     bases[r] = base;
 }
 
@@ -718,7 +316,7 @@ __device__ __forceinline__ void match_rank(int key, uint32_t& rank, uint32_t& co
     count = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
 }
 
-__device__ __forceinline__ void rank_and_layout2(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables2& tb,
+__device__ __forceinline__ void rank_and_layout(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables& tb,
                                                  uint64_t origin)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -746,7 +344,7 @@ __device__ __forceinline__ void rank_and_layout2(const int (&mode)[kVecs], uint3
         int bytes = 0, a0 = 0;
         if (lane < 18) {
             const int m = lane < 9 ? lane : lane - 9;
-            const int w = lane < 9 ? head_bytes2(m) : 15 - head_bytes2(m);
+            const int w = lane < 9 ? head_bytes(m) : 15 - head_bytes(m);
             uint32_t count = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
@@ -754,20 +352,14 @@ __device__ __forceinline__ void rank_and_layout2(const int (&mode)[kVecs], uint3
             bytes = (int)count * w;
             a0 = (int)(origin & 15);
         }
-        const int nseg = bytes ? (a0 + bytes + 15) >> 4 : 0;
-        int p = lane < 18 ? bytes + 31 : 0, q = nseg;   // inclusive prefixes of (bytes + 31) and of the row counts
+        int p = lane < 18 ? bytes + 31 : 0;   // inclusive prefix of (bytes + 31) over the pieces
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
-            const int pu = __shfl_up(p, o), qu = __shfl_up(q, o);
-            if (lane >= o) {
+            const int pu = __shfl_up(p, o);
+            if (lane >= o)
                 p += pu;
-                q += qu;
-            }
         }
         if (lane < 18) {
-            tb.seg_prefix[lane] = q - nseg;
-            if (lane == 17)
-                tb.seg_prefix[18] = q;
             const int excl_p = p - (bytes + 31);
             PieceRef ref;
             ref.lds_first = ((excl_p + 15) & ~15) + a0;
@@ -781,13 +373,13 @@ __device__ __forceinline__ void rank_and_layout2(const int (&mode)[kVecs], uint3
 
 // lanes 0..17 of wave 3: global byte offset of this tile's piece r.  Branch-free (the other lanes fetch piece 0 or 17
 // and ignore it) so that the two loads are issued together with the tile's block loads instead of ahead of them.
-__device__ __forceinline__ uint64_t fetch_piece_origin2(const uint32_t* prefix, const uint64_t* bases, uint64_t num_tiles,
+__device__ __forceinline__ uint64_t fetch_piece_origin(const uint32_t* prefix, const uint64_t* bases, uint64_t num_tiles,
                                                         uint64_t tile)
 {
     int r = (int)threadIdx.x - 192;
     r = r < 0 ? 0 : (r > 17 ? 17 : r);
     const int m = r < 9 ? r : r - 9;
-    const uint64_t w = r < 9 ? head_bytes2(m) : 15 - head_bytes2(m);
+    const uint64_t w = r < 9 ? head_bytes(m) : 15 - head_bytes(m);
     return bases[r] + (uint64_t)prefix[(uint64_t)m * num_tiles + tile] * w;
 }
 
@@ -796,10 +388,10 @@ struct RecordPlace {
     int head0, tail0;    // ... and of the first byte of their pieces
 };
 
-__device__ __forceinline__ RecordPlace place_records(const TileTables2& tb, int m, int slot_row, uint32_t rank_in_wave)
+__device__ __forceinline__ RecordPlace place_records(const TileTables& tb, int m, int slot_row, uint32_t rank_in_wave)
 {
     RecordPlace rp;
-    rp.h = head_bytes2(m);
+    rp.h = head_bytes(m);
     const int rank = (int)(tb.slot[slot_row][m] + rank_in_wave);
     rp.head0 = tb.piece[m].lds_first;
     rp.tail0 = tb.piece[9 + m].lds_first;
@@ -812,7 +404,7 @@ __device__ __forceinline__ RecordPlace place_records(const TileTables2& tb, int 
 // stamps its first row when it starts the piece or starts exactly on the row boundary (otherwise its predecessor
 // already reaches into that row), and its last row when it crosses into it.  (Stamping from every record makes
 // dozens of lanes write the same byte, which the LDS serialises: measured 3000 wait cycles per wave.)
-__device__ __forceinline__ void stamp_record(TileTables2& tb, int first, int bytes, int piece_first, uint8_t mark)
+__device__ __forceinline__ void stamp_record(TileTables& tb, int first, int bytes, int piece_first, uint8_t mark)
 {
     const int row_s = first >> 4, row_e = (first + bytes - 1) >> 4;
     if (first == piece_first || (first & 15) == 0)
@@ -827,7 +419,7 @@ struct RowRef {
     uint64_t gseg;
 };
 
-__device__ __forceinline__ RowRef locate_row(const TileTables2& tb, int row)
+__device__ __forceinline__ RowRef locate_row(const TileTables& tb, int row)
 {
     RowRef ref{};
     const int st = row < kRows ? tb.stamp[row] : 0;
@@ -845,40 +437,15 @@ __device__ __forceinline__ RowRef locate_row(const TileTables2& tb, int row)
     return ref;
 }
 
-// search-based alternative: flat segment index s -> piece by 17 compares against the SGPR-resident prefix table
-__device__ __forceinline__ RowRef locate_segment2(const TileTables2& tb, const int (&sp)[19], int s, int& row)
-{
-    RowRef ref{};
-    row = 0;
-    ref.live = s < sp[18];
-    if (!ref.live)
-        return ref;
-    int r = 0;
-#pragma unroll
-    for (int i = 1; i < 18; ++i)
-        r += sp[i] <= s ? 1 : 0;
-    const int k = s - tb.seg_prefix[r];
-    const PieceRef pc = tb.piece[r];
-    const int a0 = pc.lds_first & 15;
-    row = (pc.lds_first >> 4) + k;
-    ref.gseg = pc.g_row0 + (uint64_t)(16 * k);
-    ref.lo = k == 0 ? a0 : 0;
-    const int end = a0 + pc.bytes - 16 * k;
-    ref.hi = end < 16 ? end : 16;
-    ref.whole = ref.lo == 0 && ref.hi == 16;
-    return ref;
-}
-
-template <bool STAMPS>
 __global__ void __launch_bounds__(kThreads)
-bc7_scatter_fwd2(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
+bc7_scatter_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
                  const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[kImageBytes];
-    __shared__ TileTables2 tb;
+    __shared__ TileTables tb;
     const uint64_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
+    const uint64_t origin = fetch_piece_origin(prefix, bases, num_tiles, tile);
 
     u32x4 q[kVecs];
     int mode[kVecs];
@@ -890,17 +457,15 @@ bc7_scatter_fwd2(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, con
         mode[j] = b < n_blocks ? mode_of(q[j].x) : 9;
     }
     uint32_t rank_in_wave[kVecs];
-    rank_and_layout2(mode, rank_in_wave, tb, origin);
+    rank_and_layout(mode, rank_in_wave, tb, origin);
 
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
         if (mode[j] < 9) {
             const RecordPlace rp = place_records(tb, mode[j], wave * 4 + j, rank_in_wave[j]);
-            if (STAMPS) {
-                stamp_record(tb, rp.head, rp.h, rp.head0, (uint8_t)(mode[j] + 1));
-                if (rp.h < 15)
-                    stamp_record(tb, rp.tail, 15 - rp.h, rp.tail0, (uint8_t)(mode[j] + 10));
-            }
+            stamp_record(tb, rp.head, rp.h, rp.head0, (uint8_t)(mode[j] + 1));
+            if (rp.h < 15)
+                stamp_record(tb, rp.tail, 15 - rp.h, rp.tail0, (uint8_t)(mode[j] + 10));
             // volatile: the compiler would otherwise fuse neighbouring byte accesses into ds_write_b32/b16 at odd
             // addresses, which the LDS executes far slower than the separate byte writes (measured, r01_s)
             lds_byte* ho = lds_bytes(img) + rp.head - 1;             // block byte k (1 <= k <= h) -> ho[k]
@@ -929,16 +494,10 @@ bc7_scatter_fwd2(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, con
     }
     __syncthreads();
 
-    int sp[19];
-    if (!STAMPS) {
-#pragma unroll
-        for (int i = 0; i < 19; ++i)
-            sp[i] = __builtin_amdgcn_readfirstlane(tb.seg_prefix[i]);
-    }
 #pragma unroll
     for (int it = 0; it < kRowIters; ++it) {
-        int row = it * kThreads + (int)threadIdx.x;
-        const RowRef ref = STAMPS ? locate_row(tb, row) : locate_segment2(tb, sp, row, row);
+        const int row = it * kThreads + (int)threadIdx.x;
+        const RowRef ref = locate_row(tb, row);
         if (!ref.live)
             continue;
         if (ref.whole) {
@@ -953,16 +512,15 @@ bc7_scatter_fwd2(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, con
     }
 }
 
-template <bool STAMPS>
 __global__ void __launch_bounds__(kThreads)
-bc7_gather_inv2(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
+bc7_gather_inv(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
                 const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[kImageBytes];
-    __shared__ TileTables2 tb;
+    __shared__ TileTables tb;
     const uint64_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
+    const uint64_t origin = fetch_piece_origin(prefix, bases, num_tiles, tile);
     const uint64_t total_bytes = n_blocks * 16;
 
     int mode[kVecs];
@@ -974,45 +532,34 @@ bc7_gather_inv2(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, cons
         mode[j] = b < n_blocks ? mode_of(b0[j]) : 9;
     }
     uint32_t rank_in_wave[kVecs];
-    rank_and_layout2(mode, rank_in_wave, tb, origin);
+    rank_and_layout(mode, rank_in_wave, tb, origin);
 
     RecordPlace rp[kVecs];
 #pragma unroll
     for (int j = 0; j < kVecs; ++j) {
         if (mode[j] < 9) {
             rp[j] = place_records(tb, mode[j], wave * 4 + j, rank_in_wave[j]);
-            if (STAMPS) {
-                stamp_record(tb, rp[j].head, rp[j].h, rp[j].head0, (uint8_t)(mode[j] + 1));
-                if (rp[j].h < 15)
-                    stamp_record(tb, rp[j].tail, 15 - rp[j].h, rp[j].tail0, (uint8_t)(mode[j] + 10));
-            }
+            stamp_record(tb, rp[j].head, rp[j].h, rp[j].head0, (uint8_t)(mode[j] + 1));
+            if (rp[j].h < 15)
+                stamp_record(tb, rp[j].tail, 15 - rp[j].h, rp[j].tail0, (uint8_t)(mode[j] + 10));
         }
     }
-    int sp[19];
-    if (STAMPS) {
-        __syncthreads();
-    } else {
-#pragma unroll
-        for (int i = 0; i < 19; ++i)
-            sp[i] = __builtin_amdgcn_readfirstlane(tb.seg_prefix[i]);
-    }
+    __syncthreads();
 
     // rows in: all loads of the lane are in flight before the first LDS write.  A whole aligned row is fetched
     // whenever it lies inside the buffer: the bytes of neighbouring pieces land in this piece's LDS padding.
     RowRef ref[kRowIters];
-    int rows[kRowIters];
     u32x4 v[kRowIters];
 #pragma unroll
     for (int it = 0; it < kRowIters; ++it) {
-        rows[it] = it * kThreads + (int)threadIdx.x;
-        ref[it] = STAMPS ? locate_row(tb, rows[it]) : locate_segment2(tb, sp, rows[it], rows[it]);
+        ref[it] = locate_row(tb, it * kThreads + (int)threadIdx.x);
         ref[it].whole = ref[it].live && ref[it].gseg + 16 <= total_bytes;
         // unconditional (rows that are not fetched whole read offset 0 and drop the result): no branch, no wait
         v[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(soa + (ref[it].whole ? ref[it].gseg : 0)));
     }
 #pragma unroll
     for (int it = 0; it < kRowIters; ++it) {
-        const int row = rows[it];
+        const int row = it * kThreads + (int)threadIdx.x;
         if (ref[it].whole) {
             *reinterpret_cast<u32x4*>(img + 16 * row) = v[it];
         } else if (ref[it].live) {
@@ -1045,169 +592,6 @@ bc7_gather_inv2(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 4c. scatter / gather, direct version: no LDS image.  gfx950 global memory instructions take any byte address, and
-//     the lanes of one mode class with consecutive ranks touch consecutive records, so a wave instruction still
-//     covers contiguous runs of the stream.  Forward: every block stores its head and its tail record as two
-//     possibly overlapping words each (put_records_global).  Inverse: one 16-byte load at the head record and one
-//     at the tail record, merged in registers.  LDS holds only the rank tables.
-// ---------------------------------------------------------------------------------------------------------
-struct TileTables3 {
-    uint32_t raw[16][9];
-    uint32_t slot[16][9];
-    uint64_t piece_g[18];   // global byte offset of the tile's piece r
-};
-
-typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
-
-__device__ __forceinline__ void rank_and_origins(const int (&mode)[kVecs], uint32_t (&rank_in_wave)[kVecs], TileTables3& tb,
-                                                 uint64_t origin)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < 36)
-        (&tb.raw[wave * 4][0])[lane] = 0;
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        uint32_t count;
-        match_rank(mode[j], rank_in_wave[j], count);
-        if (rank_in_wave[j] == 0 && mode[j] < 9)
-            tb.raw[wave * 4 + j][mode[j]] = count;
-    }
-    if (wave == 3 && lane < 18)
-        tb.piece_g[lane] = origin;
-    __syncthreads();
-    if (threadIdx.x < 144) {
-        const int sidx = threadIdx.x / 9, m = threadIdx.x - sidx * 9;
-        uint32_t excl = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            excl += i < sidx ? tb.raw[i][m] : 0;
-        tb.slot[sidx][m] = excl;
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void put_records_global(uint8_t* hp, uint8_t* tp, int h, uint64_t lo, uint64_t hi)
-{
-    const int t = 15 - h;
-    if (h >= 8) {   // modes 0-3, 7, 8: head 9/11/15 bytes, tail 6/4/0
-        st64(hp, bytes_from(lo, hi, 1));
-        st64(hp + h - 8, bytes_from(lo, hi, h - 7));
-        if (t) {
-            st32(tp, (uint32_t)bytes_from(lo, hi, h + 1));
-            st32(tp + t - 4, (uint32_t)(hi >> 32));
-        }
-    } else {        // modes 4-6: head 5/7 bytes, tail 10/8
-        st32(hp, (uint32_t)(lo >> 8));
-        st32(hp + h - 4, (uint32_t)bytes_from(lo, hi, h - 3));
-        st64(tp, bytes_from(lo, hi, h + 1));
-        st64(tp + t - 8, hi);
-    }
-}
-
-__global__ void __launch_bounds__(kThreads)
-bc7_scatter_fwd3(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const uint32_t* __restrict__ prefix,
-                 const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
-{
-    __shared__ TileTables3 tb;
-    const uint64_t tile = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
-
-    u32x4 q[kVecs];
-    int mode[kVecs];
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
-        q[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(aos + (b < n_blocks ? b : n_blocks - 1) * 16));
-        mode[j] = b < n_blocks ? mode_of(q[j].x) : 9;
-    }
-    uint32_t rank_in_wave[kVecs];
-    rank_and_origins(mode, rank_in_wave, tb, origin);
-
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        if (mode[j] < 9) {
-            const int m = mode[j], h = head_bytes2(m);
-            const uint64_t rank = tb.slot[wave * 4 + j][m] + rank_in_wave[j];
-            const uint64_t lo = (uint64_t)q[j].x | ((uint64_t)q[j].y << 32);
-            const uint64_t hi = (uint64_t)q[j].z | ((uint64_t)q[j].w << 32);
-            put_records_global(soa + tb.piece_g[m] + rank * (uint64_t)h, soa + tb.piece_g[9 + m] + rank * (uint64_t)(15 - h), h,
-                               lo, hi);
-        }
-    }
-}
-
-// 16 bytes at p, or -- when that would run past the end of the buffer -- the 16 last bytes of the buffer shifted down
-__device__ __forceinline__ void load_record16(const uint8_t* soa, uint64_t at, uint64_t total_bytes, uint64_t& lo, uint64_t& hi)
-{
-    const bool safe = at + 16 <= total_bytes;
-    const uint64_t from = safe ? at : total_bytes - 16;
-    const u32x4 v = *reinterpret_cast<const u32x4_unaligned*>(soa + from);
-    lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-    if (!safe) {
-        const int skip = (int)(at - from);   // 1..15 bytes
-        const uint64_t l2 = bytes_from(lo, hi, skip);
-        hi = skip < 8 ? hi >> (8 * skip) : 0;
-        lo = l2;
-    }
-}
-
-__global__ void __launch_bounds__(kThreads)
-bc7_gather_inv3(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, const uint32_t* __restrict__ prefix,
-                const uint64_t* __restrict__ bases, uint64_t n_blocks, uint64_t num_tiles)
-{
-    __shared__ TileTables3 tb;
-    const uint64_t tile = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t origin = fetch_piece_origin2(prefix, bases, num_tiles, tile);
-    const uint64_t total_bytes = n_blocks * 16;
-
-    int mode[kVecs];
-    uint32_t b0[kVecs];
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
-        b0[j] = soa[b < n_blocks ? b : n_blocks - 1];
-        mode[j] = b < n_blocks ? mode_of(b0[j]) : 9;
-    }
-    uint32_t rank_in_wave[kVecs];
-    rank_and_origins(mode, rank_in_wave, tb, origin);
-
-    uint64_t hl[kVecs], hh[kVecs], tl[kVecs], th[kVecs];
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        const int m = mode[j] < 9 ? mode[j] : 8, h = head_bytes2(m);
-        const uint64_t rank = mode[j] < 9 ? tb.slot[wave * 4 + j][m] + rank_in_wave[j] : 0;
-        // lanes past the end and mode 8 (no tail) fetch something harmless: offset 0 is always inside the buffer
-        const uint64_t gh = mode[j] < 9 ? tb.piece_g[m] + rank * (uint64_t)h : 0;
-        const uint64_t gt = mode[j] < 8 ? tb.piece_g[9 + m] + rank * (uint64_t)(15 - h) : 0;
-        load_record16(soa, gh, total_bytes, hl[j], hh[j]);
-        load_record16(soa, gt, total_bytes, tl[j], th[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < kVecs; ++j) {
-        if (mode[j] < 9) {
-            const uint64_t b = tile * kTileBlocks + (uint64_t)(wave * 256 + j * 64 + lane);
-            const int s = head_bytes2(mode[j]) + 1;           // bytes 0..s-1 = mode byte + head, tail from byte s
-            uint64_t lo = (b0[j] & 0xFF) | (hl[j] << 8);
-            uint64_t hi = (hh[j] << 8) | (hl[j] >> 56);
-            if (s < 8) {           // s = 6: head is 5 bytes
-                lo &= (1ull << (8 * s)) - 1;
-                lo |= tl[j] << (8 * s);
-                hi = (th[j] << (8 * s)) | (tl[j] >> (64 - 8 * s));
-            } else if (s == 8) {
-                hi = tl[j];
-            } else if (s < 16) {   // s = 10 or 12
-                hi &= (1ull << (8 * (s - 8))) - 1;
-                hi |= tl[j] << (8 * (s - 8));
-            }
-            store_block(aos + b * 16, u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)});
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 static inline uint64_t tiles_for(uint64_t n_blocks) { return (n_blocks + kTileBlocks - 1) / kTileBlocks; }
@@ -1234,7 +618,7 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
         return hipErrorInvalidValue;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     uint64_t* totals = reinterpret_cast<uint64_t*>(ws);                    // 9 x u64: blocks per mode
-    uint64_t* bases = reinterpret_cast<uint64_t*>(ws + 96);                // 18 x u64: stream bases (version 2 kernels)
+    uint64_t* bases = reinterpret_cast<uint64_t*>(ws + 96);                // 18 x u64: stream bases
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 256);
     uint32_t* prefix = hist + 9 * tiles;
     uint32_t* gsum = prefix + 9 * tiles;
@@ -1250,28 +634,13 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
                        (uint32_t)groups);
     hipLaunchKernelGGL(bc7_scan, dim3((unsigned)groups, 9), dim3(1024), 0, stream, hist, gsum, prefix, totals, tiles,
                        (uint32_t)groups);
-    static const int variant = [] { const char* e = getenv("DXTLT_BC7_VARIANT"); return e ? atoi(e) : 4; }();
-    auto go = [&](auto fwd_kernel, auto inv_kernel, const uint64_t* table) {
-        if (!inverse)
-            hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, table, n_blocks,
-                               tiles);
-        else
-            hipLaunchKernelGGL(inv_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, table, n_blocks,
-                               tiles);
-    };
-    if (variant >= 4) {
-        hipLaunchKernelGGL(bc7_stream_bases, dim3(1), dim3(64), 0, stream, totals, bases, n_blocks);
-        if (variant == 5) go(bc7_scatter_fwd3, bc7_gather_inv3, bases);
-        else if (variant == 6) go(bc7_scatter_fwd2<false>, bc7_gather_inv2<false>, bases);
-        else go(bc7_scatter_fwd2<true>, bc7_gather_inv2<true>, bases);
-        return hipGetLastError();
-    }
-    switch (variant) {
-    case 0: go(bc7_scatter_fwd<0, 0>, bc7_gather_inv<0, 0>, totals); break;
-    case 1: go(bc7_scatter_fwd<1, 0>, bc7_gather_inv<1, 0>, totals); break;
-    case 2: go(bc7_scatter_fwd<0, 1>, bc7_gather_inv<0, 1>, totals); break;
-    default: go(bc7_scatter_fwd<1, 1>, bc7_gather_inv<1, 1>, totals); break;
-    }
+    hipLaunchKernelGGL(bc7_stream_bases, dim3(1), dim3(64), 0, stream, totals, bases, n_blocks);
+    if (!inverse)
+        hipLaunchKernelGGL(bc7_scatter_fwd, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, bases, n_blocks,
+                           tiles);
+    else
+        hipLaunchKernelGGL(bc7_gather_inv, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, bases, n_blocks,
+                           tiles);
     return hipGetLastError();
 }
 

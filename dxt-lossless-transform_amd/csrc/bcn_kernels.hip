@@ -117,6 +117,13 @@ __device__ __forceinline__ T& lds_at(uint8_t* lds, int byte_off)
     return *reinterpret_cast<T*>(lds + byte_off);
 }
 
+// volatile halfword view in the LDS address space (a plain volatile pointer would become flat_* instructions)
+typedef volatile uint16_t __attribute__((address_space(3))) lds_halfword;
+__device__ __forceinline__ lds_halfword* lds_halfwords(uint8_t* lds, int byte_off)
+{
+    return (lds_halfword*)(lds + byte_off);
+}
+
 template <int FMT, int VARIANT, bool SA, bool SC, int T>
 __device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
 {
@@ -151,10 +158,12 @@ __device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
         } else {
             lds_at<uint16_t>(lds, 0 * T + 2 * u) = (uint16_t)q.x;
         }
-        // 6-byte alpha-index record, only 2-byte aligned: three halfword stores
-        lds_at<uint16_t>(lds, 2 * T + 6 * u + 0) = (uint16_t)(q.x >> 16);
-        lds_at<uint16_t>(lds, 2 * T + 6 * u + 2) = (uint16_t)q.y;
-        lds_at<uint16_t>(lds, 2 * T + 6 * u + 4) = (uint16_t)(q.y >> 16);
+        // 6-byte alpha-index record, only 2-byte aligned: three halfword stores.  Volatile, or clang fuses the last
+        // two into a ds_write_b32 that is misaligned for every other lane -- such DS accesses run several times
+        // slower than aligned ones on gfx950 (profiles/r01_s).
+        lds_halfwords(lds, 2 * T + 6 * u)[0] = (uint16_t)(q.x >> 16);
+        lds_halfwords(lds, 2 * T + 6 * u)[1] = (uint16_t)q.y;
+        lds_halfwords(lds, 2 * T + 6 * u)[2] = (uint16_t)(q.y >> 16);
         if constexpr (SC) {
             lds_at<uint16_t>(lds, 8 * T + 2 * u) = (uint16_t)c;
             lds_at<uint16_t>(lds, 10 * T + 2 * u) = (uint16_t)(c >> 16);
