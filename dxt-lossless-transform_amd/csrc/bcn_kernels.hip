@@ -297,26 +297,81 @@ struct Shifts {
 };
 
 
+// LDS accesses of the shifted tiles.  A field of W bytes sits at an address that is only known to be congruent to
+// `addr & (W - 1)` (the stream's shift, uniform over the wave).  DS instructions at addresses that are not multiples
+// of their width execute on gfx950, but several times slower than aligned ones (profiles/r01_s), and clang -- which
+// assumes they are free -- fuses neighbouring narrow accesses into exactly such instructions.  So the field is moved
+// as the shortest sequence of naturally aligned 1/2/4/8-byte pieces for its misalignment, through volatile pointers
+// in the LDS address space (volatile stops the fusion; a plain volatile pointer would become flat_* instructions).
+template <typename T>
+using lds_volatile = volatile T __attribute__((address_space(3)));
+
+template <int SIZE>
+__device__ __forceinline__ void lds_put_piece(uint8_t* lds, int addr, uint64_t v)
+{
+    if constexpr (SIZE == 1) *(lds_volatile<uint8_t>*)(lds + addr) = (uint8_t)v;
+    if constexpr (SIZE == 2) *(lds_volatile<uint16_t>*)(lds + addr) = (uint16_t)v;
+    if constexpr (SIZE == 4) *(lds_volatile<uint32_t>*)(lds + addr) = (uint32_t)v;
+    if constexpr (SIZE == 8) *(lds_volatile<uint64_t>*)(lds + addr) = v;
+}
+
+template <int SIZE>
+__device__ __forceinline__ uint64_t lds_get_piece(uint8_t* lds, int addr)
+{
+    if constexpr (SIZE == 1) return *(lds_volatile<uint8_t>*)(lds + addr);
+    if constexpr (SIZE == 2) return *(lds_volatile<uint16_t>*)(lds + addr);
+    if constexpr (SIZE == 4) return *(lds_volatile<uint32_t>*)(lds + addr);
+    if constexpr (SIZE == 8) return *(lds_volatile<uint64_t>*)(lds + addr);
+    return 0;
+}
+
+// size of the piece that starts P bytes into a W-byte field whose address is K modulo W
+constexpr int lds_piece_size(int W, int K, int P)
+{
+    const int a = K + P;
+    int align = a == 0 ? W : (a & -a);
+    if (align > W) align = W;
+    int size = 1;
+    while (size * 2 <= align && size * 2 <= W - P) size *= 2;
+    return size;
+}
+
+template <int W, int K, int P = 0>
+__device__ __forceinline__ void lds_put_seq(uint8_t* lds, int addr, uint64_t v)
+{
+    if constexpr (P < W) {
+        constexpr int size = lds_piece_size(W, K, P);
+        lds_put_piece<size>(lds, addr + P, v >> (8 * P));
+        lds_put_seq<W, K, P + size>(lds, addr, v);
+    }
+}
+
+template <int W, int K, int P = 0>
+__device__ __forceinline__ uint64_t lds_get_seq(uint8_t* lds, int addr)
+{
+    if constexpr (P < W) {
+        constexpr int size = lds_piece_size(W, K, P);
+        return (lds_get_piece<size>(lds, addr + P) << (8 * P)) | lds_get_seq<W, K, P + size>(lds, addr);
+    }
+    return 0;
+}
+
 template <int W>
 __device__ __forceinline__ void lds_put(uint8_t* lds, int addr, uint64_t v)
 {
     if constexpr (W == 1) {
-        lds[addr] = (uint8_t)v;
-    } else if ((addr & (W - 1)) == 0) {
-        if constexpr (W == 2) lds_at<uint16_t>(lds, addr) = (uint16_t)v;
-        if constexpr (W == 4) lds_at<uint32_t>(lds, addr) = (uint32_t)v;
-        if constexpr (W == 8) lds_at<u32x2>(lds, addr) = u32x2{(uint32_t)v, (uint32_t)(v >> 32)};
-    } else if (W == 8 && (addr & 3) == 0) {
-        lds_at<uint32_t>(lds, addr) = (uint32_t)v;
-        lds_at<uint32_t>(lds, addr + 4) = (uint32_t)(v >> 32);
-    } else if ((addr & 1) == 0) {
-#pragma unroll
-        for (int i = 0; i < W / 2; ++i)
-            lds_at<uint16_t>(lds, addr + 2 * i) = (uint16_t)(v >> (16 * i));
+        lds_put_piece<1>(lds, addr, v);
     } else {
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-            lds[addr + i] = (uint8_t)(v >> (8 * i));
+        switch (addr & (W - 1)) {
+        case 0: lds_put_seq<W, 0>(lds, addr, v); break;
+        case 1: lds_put_seq<W, 1>(lds, addr, v); break;
+        case 2: if constexpr (W > 2) lds_put_seq<W, 2>(lds, addr, v); break;
+        case 3: if constexpr (W > 2) lds_put_seq<W, 3>(lds, addr, v); break;
+        case 4: if constexpr (W > 4) lds_put_seq<W, 4>(lds, addr, v); break;
+        case 5: if constexpr (W > 4) lds_put_seq<W, 5>(lds, addr, v); break;
+        case 6: if constexpr (W > 4) lds_put_seq<W, 6>(lds, addr, v); break;
+        default: if constexpr (W > 4) lds_put_seq<W, 7>(lds, addr, v); break;
+        }
     }
 }
 
@@ -324,28 +379,20 @@ template <int W>
 __device__ __forceinline__ uint64_t lds_get(uint8_t* lds, int addr)
 {
     if constexpr (W == 1) {
-        return lds[addr];
-    } else if ((addr & (W - 1)) == 0) {
-        if constexpr (W == 2) return lds_at<uint16_t>(lds, addr);
-        if constexpr (W == 4) return lds_at<uint32_t>(lds, addr);
-        if constexpr (W == 8) {
-            const u32x2 p = lds_at<u32x2>(lds, addr);
-            return (uint64_t)p.x | ((uint64_t)p.y << 32);
+        return lds_get_piece<1>(lds, addr);
+    } else {
+        switch (addr & (W - 1)) {
+        case 0: return lds_get_seq<W, 0>(lds, addr);
+        case 1: return lds_get_seq<W, 1>(lds, addr);
+        case 2: if constexpr (W > 2) return lds_get_seq<W, 2>(lds, addr); break;
+        case 3: if constexpr (W > 2) return lds_get_seq<W, 3>(lds, addr); break;
+        case 4: if constexpr (W > 4) return lds_get_seq<W, 4>(lds, addr); break;
+        case 5: if constexpr (W > 4) return lds_get_seq<W, 5>(lds, addr); break;
+        case 6: if constexpr (W > 4) return lds_get_seq<W, 6>(lds, addr); break;
+        default: if constexpr (W > 4) return lds_get_seq<W, 7>(lds, addr); break;
         }
-    } else if (W == 8 && (addr & 3) == 0) {
-        return (uint64_t)lds_at<uint32_t>(lds, addr) | ((uint64_t)lds_at<uint32_t>(lds, addr + 4) << 32);
-    } else if ((addr & 1) == 0) {
-        uint64_t v = 0;
-#pragma unroll
-        for (int i = 0; i < W / 2; ++i)
-            v |= (uint64_t)lds_at<uint16_t>(lds, addr + 2 * i) << (16 * i);
-        return v;
+        return 0;
     }
-    uint64_t v = 0;
-#pragma unroll
-    for (int i = 0; i < W; ++i)
-        v |= (uint64_t)lds[addr + i] << (8 * i);
-    return v;
 }
 
 // stream indices of the fields (make_streams order)
