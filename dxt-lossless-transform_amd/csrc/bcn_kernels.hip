@@ -36,6 +36,7 @@
 //     element-granular kernel: one lane per block, natural-width or byte accesses.
 #include <hip/hip_runtime.h>
 
+#include "bc1_normalize.h"
 #include "bcn_launch.h"
 #include "ycocg_swar.h"
 
@@ -245,7 +246,22 @@ __device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t 
 // stream base off*total_blocks + width*first_block is a multiple of 16; gridDim.x == number of FULL tiles
 // at the start of the range.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
+// BC1 block normalisation fused into the forward kernels (experimental module of the reference,
+// transform_bc1_with_normalize_blocks, experimental/normalize_blocks/transform.rs:65-166): the two blocks of the
+// lane's vector are normalised in registers right after the load, so the fused path moves the same 2*len bytes.
+template <int FMT, int NORM>
+__device__ __forceinline__ u32x4 normalize_vector(u32x4 q)
+{
+    if constexpr (FMT == kBc1 && NORM != kNormNone) {
+        uint32_t ca = q.x, xa = q.y, cb = q.z, xb = q.w;
+        normalize_bc1_block<NORM>(ca, xa);
+        normalize_bc1_block<NORM>(cb, xb);
+        q = u32x4{ca, xa, cb, xb};
+    }
+    return q;
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
 __global__ void __launch_bounds__(THREADS)
 fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
           int xcd_remap)
@@ -255,7 +271,7 @@ fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t t
     const int t = threadIdx.x;
     const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
 
-    const u32x4 q = gload16(aos + tile * (THREADS * 16) + t * 16);
+    const u32x4 q = normalize_vector<FMT, NORM>(gload16(aos + tile * (THREADS * 16) + t * 16));
     scatter_to_image<FMT, VARIANT, SA, SC, T>(lds, t, q);
     __syncthreads();
     const u32x4 v = lds_at<u32x4>(lds, t * 16);
@@ -543,7 +559,7 @@ __device__ __forceinline__ void shifted_segment(int o, uint64_t total_blocks, ui
     }
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone>
 __global__ void __launch_bounds__(256)
 fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
                 Shifts sh)
@@ -559,7 +575,7 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
     for (int s = 0; s < 6; ++s)
         base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
 
-    const u32x4 q = gload16(aos + tile * 4096 + t * 16);
+    const u32x4 q = normalize_vector<FMT, NORM>(gload16(aos + tile * 4096 + t * 16));
     scatter_shifted<FMT, VARIANT, SA, SC>(lds, t, q, base);
     __syncthreads();
 
@@ -681,7 +697,7 @@ __device__ __forceinline__ uint64_t load_bytes(const uint8_t* p, bool natural)
 
 __device__ __forceinline__ bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int NORM = kNormNone>
 __global__ void __launch_bounds__(kThreads)
 generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t total_blocks,
                uint64_t first_block, uint64_t local_first, uint64_t count)
@@ -724,8 +740,11 @@ generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint6
             i23 = (uint32_t)load_bytes<2>(aos_c + 4, aos2);
             i45 = (uint32_t)load_bytes<2>(aos_c + 6, aos2);
         }
-        colours = decorrelate2<VARIANT>((uint32_t)load_bytes<4>(aos_c + CO, aos4));
+        colours = (uint32_t)load_bytes<4>(aos_c + CO, aos4);
         indices = (uint32_t)load_bytes<4>(aos_c + CO + 4, aos4);
+        if constexpr (FMT == kBc1 && NORM != kNormNone)
+            normalize_bc1_block<NORM>(colours, indices);
+        colours = decorrelate2<VARIANT>(colours);
     }
 
     // stream addresses (byte offsets from the start of the transformed buffer)
@@ -890,6 +909,27 @@ KernelSet pick_variant(int variant, bool sa, bool sc, bool inverse)
     }
 }
 
+// BC1 forward with block normalisation fused in: one tile size (the BC1 default), shifted tiles, element kernel
+template <int VARIANT, bool SC, int NORM>
+KernelSet bc1_norm_kernels()
+{
+    constexpr int TH = default_tile_threads(kBc1, false);
+    TiledFn tiled = fwd_tiled<kBc1, VARIANT, false, SC, TH, NORM>;
+    return {{tiled, tiled, tiled, tiled}, fwd_tiled_shift<kBc1, VARIANT, false, SC, NORM>,
+            generic_kernel<kBc1, VARIANT, false, SC, false, NORM>};
+}
+
+template <int NORM>
+KernelSet pick_bc1_norm(int variant, bool sc)
+{
+    switch (variant) {
+    case kNone: return sc ? bc1_norm_kernels<kNone, true, NORM>() : bc1_norm_kernels<kNone, false, NORM>();
+    case kVar1: return sc ? bc1_norm_kernels<kVar1, true, NORM>() : bc1_norm_kernels<kVar1, false, NORM>();
+    case kVar2: return sc ? bc1_norm_kernels<kVar2, true, NORM>() : bc1_norm_kernels<kVar2, false, NORM>();
+    default: return sc ? bc1_norm_kernels<kVar3, true, NORM>() : bc1_norm_kernels<kVar3, false, NORM>();
+    }
+}
+
 int cached_cu_count()
 {
     static int cus[64] = {0};
@@ -914,12 +954,20 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         return hipSuccess;
     if (s.variant < 0 || s.variant > 3 || r.first_block + r.num_blocks > r.total_blocks)
         return hipErrorInvalidValue;
+    if (s.normalize != kNormNone && (fmt != kBc1 || inverse || s.normalize < 0 || s.normalize > kNormTransparentOnly))
+        return hipErrorInvalidValue;  // normalisation exists for the BC1 forward transform only
 
     const bool sa = (fmt == kBc3) && s.split_alpha;
     const bool sc = s.split_colour;
+    const bool normalizing = s.normalize != kNormNone;
     KernelSet ks;
     switch (fmt) {
-    case kBc1: ks = pick_variant<kBc1>(s.variant, false, sc, inverse); break;
+    case kBc1:
+        if (s.normalize == kNormColor0Only) ks = pick_bc1_norm<kNormColor0Only>(s.variant, sc);
+        else if (s.normalize == kNormReplicateColor) ks = pick_bc1_norm<kNormReplicateColor>(s.variant, sc);
+        else if (s.normalize == kNormTransparentOnly) ks = pick_bc1_norm<kNormTransparentOnly>(s.variant, sc);
+        else ks = pick_variant<kBc1>(s.variant, false, sc, inverse);
+        break;
     case kBc2: ks = pick_variant<kBc2>(s.variant, false, sc, inverse); break;
     case kBc3: ks = pick_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
@@ -957,6 +1005,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (tuning && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
                    tuning->tile_threads == 512))
         threads = tuning->tile_threads;
+    if (normalizing)
+        threads = default_tile_threads(fmt, inverse);  // the only tile size instantiated with normalisation
     if (use_shift)
         threads = 256;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);

@@ -12,6 +12,7 @@ struct Settings {
     int variant;        // core YCoCgVariant numbering: 0 None, 1..3
     bool split_alpha;   // BC3 only
     bool split_colour;
+    int normalize = 0;  // BC1 forward only: ColorNormalizationMode 0 None, 1 Color0Only, 2 ReplicateColor (fused)
 };
 
 // One contiguous range of blocks of a larger block array (the whole array when first_block == 0 and
@@ -37,6 +38,19 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
 // Deterministic synthetic data: qword i = splitmix64(seed, first_qword + i) (matches oracle_fill_splitmix64).
 hipError_t launch_fill_splitmix64(void* dst, size_t len_bytes, uint64_t seed, uint64_t first_qword,
                                   hipStream_t stream);
+
+// BC1 block normalisation (bc1_normalize.hip; reference experimental/normalize_blocks/normalize.rs).  `mode` is the
+// ColorNormalizationMode (0 None, 1 Color0Only, 2 ReplicateColor).  All enqueue on `stream`.
+//   blocks:     in -> out, AoS blocks; in == out allowed (in place), partial overlap is not
+//   split:      colours (4 bytes per block) and indices (4 bytes per block) in two separate arrays, in place
+//   all_modes:  in -> out[0..2], one output per mode in enum order; *d_any (device uint32) is set to 1 when any block
+//               was normalised (the caller zeroes it first)
+//   any:        only the flag
+hipError_t launch_normalize_bc1_blocks(const void* in, void* out, uint64_t num_blocks, int mode, hipStream_t stream);
+hipError_t launch_normalize_bc1_split(void* colours, void* indices, uint64_t num_blocks, int mode, hipStream_t stream);
+hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], uint64_t num_blocks, uint32_t* d_any,
+                                          hipStream_t stream);
+hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint32_t* d_any, hipStream_t stream);
 
 inline int block_bytes(Format f) { return f == kBc1 ? 8 : 16; }
 

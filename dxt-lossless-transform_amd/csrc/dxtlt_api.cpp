@@ -76,7 +76,7 @@ int32_t check_common(int32_t format, size_t len, uint8_t mode, const void* a, co
 }
 
 int32_t device_range(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t total, uint64_t first,
-                     uint64_t num, uint8_t mode, bool sa, bool sc, hipStream_t stream)
+                     uint64_t num, uint8_t mode, bool sa, bool sc, hipStream_t stream, uint8_t normalize = 0)
 {
     if (format < 1 || format > 3)
         return fail(DXTLT_E_INVALID_ARGUMENT, "format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
@@ -88,7 +88,11 @@ int32_t device_range(int32_t format, bool inverse, const void* d_src, void* d_ds
         return DXTLT_OK;
     if (d_src == nullptr || d_dst == nullptr)
         return fail(DXTLT_E_INVALID_ARGUMENT, "NULL device buffer with a non-empty range");
-    Settings s{(int)mode, sa, sc};
+    // 3 = transparent blocks only: internal, used by the auto transform (bc1_normalize.h); the public entry points
+    // check color_mode <= 2 before they get here
+    if (normalize != 0 && (format != 1 || inverse || normalize > 3))
+        return fail(DXTLT_E_INVALID_ARGUMENT, "block normalisation: BC1 forward only, color_mode 0..2");
+    Settings s{(int)mode, sa, sc, (int)normalize};
     Range r{total, first, num};
     dxtlt::LaunchTuning t = current_tuning();
     HIP_TRY(dxtlt::launch_transform((Format)format, inverse, s, d_src, d_dst, r, stream, &t), "kernel launch");
@@ -196,7 +200,7 @@ struct PipeShared {
 };
 
 int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint8_t* in, uint8_t* out, uint64_t blocks,
-                            uint8_t mode, bool sa, bool sc)
+                            uint8_t mode, bool sa, bool sc, uint8_t normalize)
 {
     const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
     const dxtlt::Streams S = dxtlt::make_streams(format, format == 3 && sa, sc);
@@ -256,7 +260,7 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
                                     hipMemcpyHostToDevice, c.stream);
             if (up_err == hipSuccess)
                 rc = device_range(format, false, (const uint8_t*)c.d_in + first * B, c.d_out, blocks, first, count, mode,
-                                  sa, sc, c.stream);
+                                  sa, sc, c.stream, normalize);
         } else {
             for (int s = 0; s < S.n && up_err == hipSuccess; ++s) {
                 const uint64_t o = (uint64_t)S.off[s] * blocks + (uint64_t)S.width[s] * first;
@@ -309,13 +313,13 @@ int32_t dxtlt_host::acquire_staging(size_t bytes, void** d_in, void** d_out, hip
 }
 
 int32_t dxtlt_host::enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
-                            bool sa, bool sc, hipStream_t stream)
+                            bool sa, bool sc, hipStream_t stream, uint8_t normalize)
 {
-    return device_range(format, inverse, d_src, d_dst, blocks, 0, blocks, mode, sa, sc, stream);
+    return device_range(format, inverse, d_src, d_dst, blocks, 0, blocks, mode, sa, sc, stream, normalize);
 }
 
 int32_t dxtlt_host::transform(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode,
-                              bool sa, bool sc)
+                              bool sa, bool sc, uint8_t normalize)
 {
     int32_t rc = check_common(format, len, mode, in, out);
     if (rc != DXTLT_OK)
@@ -328,9 +332,9 @@ int32_t dxtlt_host::transform(int32_t format, bool inverse, const uint8_t* in, u
         return rc;
     const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
     if (len >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0)
-        return pipelined_transform(c, format, inverse, in, out, blocks, mode, sa, sc);
+        return pipelined_transform(c, format, inverse, in, out, blocks, mode, sa, sc, normalize);
     HIP_TRY(hipMemcpyAsync(c.d_in, in, len, hipMemcpyHostToDevice, c.stream), "H2D copy");
-    rc = device_range(format, inverse, c.d_in, c.d_out, blocks, 0, blocks, mode, sa, sc, c.stream);
+    rc = device_range(format, inverse, c.d_in, c.d_out, blocks, 0, blocks, mode, sa, sc, c.stream, normalize);
     if (rc != DXTLT_OK)
         return rc;
     HIP_TRY(hipMemcpyAsync(out, c.d_out, len, hipMemcpyDeviceToHost, c.stream), "D2H copy");

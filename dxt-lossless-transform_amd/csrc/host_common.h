@@ -24,15 +24,16 @@ enum : int32_t {
 int32_t fail(int32_t code, const char* what, hipError_t e = hipSuccess);
 
 // Host pointers in/out, whole buffer, synchronous (H2D + kernel + D2H on the current device).
+// `normalize` (BC1 forward only): ColorNormalizationMode fused into the transform, 0 = none.
 int32_t transform(int32_t format, bool inverse, const uint8_t* in, uint8_t* out, size_t len, uint8_t mode,
-                  bool split_alpha, bool split_colour);
+                  bool split_alpha, bool split_colour, uint8_t normalize = 0);
 
 // This thread's staging context on the current device: two device buffers of at least `bytes` and a stream.
 int32_t acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream);
 
 // Enqueue one whole-buffer transform on device pointers.
 int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
-                bool split_alpha, bool split_colour, hipStream_t stream);
+                bool split_alpha, bool split_colour, hipStream_t stream, uint8_t normalize = 0);
 
 struct AutoChoice {
     uint8_t mode;  // core numbering

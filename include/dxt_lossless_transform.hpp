@@ -9,6 +9,7 @@
 //   core::transform_bcN_with_settings  core/.../transform/transform_with_settings.rs:31,92 (bc2 :30,93; bc3 :32,162)
 //   core::*_safe + BcNValidationError  core/.../transform/safe/transform_with_settings.rs:18-31,88,192
 //   core::transform_bcN_auto           core/.../transform/transform_auto.rs:200 (bc2/bc3 :196)
+//   core::experimental::*              core/dxt-lossless-transform-bc1/src/experimental/normalize_blocks/{mod,normalize,transform}.rs
 //   api::YCoCgVariant (renumbered)     api/dxt-lossless-transform-api-common/src/reexports/color_565.rs:65-91
 //   api::Bc{1,2}ManualTransformBuilder api/dxt-lossless-transform-bc1-api/src/transform/manual_transform_builder.rs:18-150
 //   api::Bc{1,2}AutoTransformBuilder   api/dxt-lossless-transform-bc1-api/src/transform/auto_transform_builder.rs:15-130
@@ -25,6 +26,7 @@
 #include <string>
 #include <utility>
 
+#include "dxtlt_bc1_normalize.h"
 #include "dxtlt_gfx950.h"
 
 namespace dxt_lossless_transform {
@@ -248,6 +250,72 @@ std::pair<Bc3TransformSettings, DetermineBestTransformError> transform_bc3_auto(
     int32_t rc = dxtlt_transform_bc3_auto(input_ptr, output_ptr, len, &v, options.use_all_decorrelation_modes, &mode, &sa, &sc, nullptr);
     return {Bc3TransformSettings{static_cast<YCoCgVariant>(mode), sa, sc}, detail_auto::map(rc)};
 }
+
+// ---- dxt_lossless_transform_bc1::experimental::normalize_blocks (normalize.rs, transform.rs, mod.rs) ------------
+namespace experimental {
+
+enum class ColorNormalizationMode : uint8_t { None = 0, Color0Only = 1, ReplicateColor = 2 };  // normalize.rs:487-500
+
+struct Bc1TransformDetailsWithNormalization {  // mod.rs:98-135
+    ColorNormalizationMode color_normalization_mode = ColorNormalizationMode::None;
+    YCoCgVariant decorrelation_mode = YCoCgVariant::Variant1;
+    bool split_colour_endpoints = true;
+
+    Bc1TransformDetailsWithNormalization() = default;
+    Bc1TransformDetailsWithNormalization(ColorNormalizationMode m, YCoCgVariant v, bool s)
+        : color_normalization_mode(m), decorrelation_mode(v), split_colour_endpoints(s) {}
+    Bc1TransformDetailsWithNormalization(Bc1TransformSettings s)  // impl From<Bc1TransformSettings>
+        : decorrelation_mode(s.decorrelation_mode), split_colour_endpoints(s.split_colour_endpoints) {}
+    operator Bc1UntransformSettings() const { return {decorrelation_mode, split_colour_endpoints}; }  // impl From<...>
+    bool operator==(const Bc1TransformDetailsWithNormalization& o) const
+    {
+        return color_normalization_mode == o.color_normalization_mode && decorrelation_mode == o.decorrelation_mode &&
+               split_colour_endpoints == o.split_colour_endpoints;
+    }
+};
+
+// normalize.rs:38; input_ptr == output_ptr is allowed
+inline void normalize_blocks(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, ColorNormalizationMode color_mode)
+{
+    detail::check_device(dxtlt_bc1_normalize_blocks(input_ptr, output_ptr, len, static_cast<uint8_t>(color_mode)));
+}
+// normalize.rs:286
+inline void normalize_split_blocks_in_place(uint8_t* colors_ptr, uint8_t* indices_ptr, size_t num_blocks,
+                                            ColorNormalizationMode color_mode)
+{
+    detail::check_device(dxtlt_bc1_normalize_split_blocks_in_place(colors_ptr, indices_ptr, num_blocks,
+                                                                   static_cast<uint8_t>(color_mode)));
+}
+// normalize.rs:417; returns whether any block was normalised
+inline bool normalize_blocks_all_modes(const uint8_t* input_ptr, const std::array<uint8_t*, 3>& output_ptrs, size_t len)
+{
+    bool any = false;
+    detail::check_device(dxtlt_bc1_normalize_blocks_all_modes(input_ptr, output_ptrs.data(), len, &any));
+    return any;
+}
+// transform.rs:65; work_ptr is accepted for signature parity and not used
+inline void transform_bc1_with_normalize_blocks(const uint8_t* input_ptr, uint8_t* output_ptr, uint8_t* work_ptr, size_t len,
+                                                Bc1TransformDetailsWithNormalization o)
+{
+    detail::check_device(dxtlt_transform_bc1_with_normalize_blocks(
+        input_ptr, output_ptr, work_ptr, len, static_cast<uint8_t>(o.color_normalization_mode),
+        static_cast<uint8_t>(o.decorrelation_mode), o.split_colour_endpoints));
+}
+// transform.rs:222
+template <class E>
+std::pair<Bc1TransformDetailsWithNormalization, DetermineBestTransformError> transform_bc1_auto_with_normalization(
+    const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, EstimateSettings<E>& options)
+{
+    DltSizeEstimator v = detail_auto::make_vtable(options.size_estimator);
+    uint8_t norm = 0, mode = 1;
+    bool sc = true;
+    int32_t rc = dxtlt_transform_bc1_auto_with_normalization(input_ptr, output_ptr, len, &v, options.use_all_decorrelation_modes,
+                                                             &norm, &mode, &sc, nullptr);
+    return {Bc1TransformDetailsWithNormalization{static_cast<ColorNormalizationMode>(norm), static_cast<YCoCgVariant>(mode), sc},
+            detail_auto::map(rc)};
+}
+
+}  // namespace experimental
 
 }  // namespace core
 

@@ -116,6 +116,22 @@ void oracle_untransform_bc7(const uint8_t *in, uint8_t *out, size_t len);
 /* force a valid mode marker into byte 0 of every block: mode = (byte 15 & 7) */
 void oracle_bc7_force_modes(uint8_t *blocks, size_t len);
 
+/* BC1 block normalisation, the reference's experimental module (dxtlt_oracle_norm.c; PINNED by the reference's unit
+ * tests, normalize.rs:505-1076).  mode = ColorNormalizationMode, normalize.rs:487-500. */
+enum {
+    ORACLE_NORMALIZE_NONE = 0,
+    ORACLE_NORMALIZE_COLOR0_ONLY = 1,
+    ORACLE_NORMALIZE_REPLICATE_COLOR = 2
+};
+/* 16 RGBA8888 pixels (64 bytes), row-major: util/bc1_decode.rs:42 */
+void oracle_decode_bc1_block(const uint8_t *src, uint8_t *rgba_out);
+void oracle_normalize_bc1_blocks(const uint8_t *in, uint8_t *out, size_t len, int mode);            /* in == out allowed */
+void oracle_normalize_bc1_split_blocks_in_place(uint8_t *colors, uint8_t *indices, size_t num_blocks, int mode);
+int oracle_normalize_bc1_blocks_all_modes(const uint8_t *in, uint8_t *out_none, uint8_t *out_color0,
+                                          uint8_t *out_replicate, size_t len);                          /* 1 = any normalised */
+int oracle_transform_bc1_with_normalize_blocks(const uint8_t *in, uint8_t *out, size_t len, int mode, int variant,
+                                               int split_colour);                                       /* 0 = ok */
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,3 +50,28 @@ def transform_auto(fmt: str, data, estimate, use_all: bool):
     if best != last:
         out = oracle_c.transform(fmt, data, best[0], best[2], best[1])
     return best, out, calls
+
+
+def transform_bc1_auto_with_normalization(data, estimate, use_all: bool):
+    """experimental/normalize_blocks/transform.rs:222-333.  estimate(bytes_like) -> int, or raises to signal an
+    estimator error (the candidate is then skipped, transform.rs:403).  Returns ((norm, variant, split), output, calls)
+    with calls = the estimator call lengths in order; when no block can be normalised the plain auto transform runs
+    (its calls are (offset, length) pairs, see transform_auto)."""
+    n = len(data)
+    outs, any_normalized = oracle_c.normalize_bc1_blocks_all_modes(data)
+    if not any_normalized:
+        (v, _sa, sc), out, calls = transform_auto("bc1", data, estimate, use_all)
+        return (0, v, sc), out, calls
+    best, best_size, calls = (0, 1, 1), None, []
+    for norm in range(3):
+        for v, _sa, sc in test_order("bc1", use_all):
+            cand = oracle_c.transform("bc1", outs[norm], v, sc)
+            calls.append(n // 2)
+            try:
+                size = estimate(cand[: n // 2])
+            except Exception:
+                continue
+            if best_size is None or size < best_size:
+                best_size, best = size, (norm, v, sc)
+    out = oracle_c.transform_bc1_with_normalize_blocks(data, best[0], best[1], bool(best[2]))
+    return best, out, calls

@@ -21,7 +21,7 @@ OK, INVALID_LENGTH, OUTPUT_TOO_SMALL = 0, 1, 2
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (``make -C oracle``) if the .so is missing or stale."""
     srcs = [os.path.join(_HERE, f) for f in ("dxtlt_oracle.c", "dxtlt_oracle_bc7.c", "dxtlt_oracle_avx2.c",
-                                             "dxtlt_oracle.h")]
+                                             "dxtlt_oracle_norm.c", "dxtlt_oracle.h")]
     stale = (
         force
         or not os.path.exists(_SO)
@@ -79,6 +79,14 @@ def lib() -> C.CDLL:
         l.oracle_simd_available.argtypes, l.oracle_simd_available.restype = [], i
         l.oracle_bc1_default_simd_mt.argtypes = [i, u8p, u8p, sz, i]
         l.oracle_bc1_default_simd_mt.restype = None
+        l.oracle_decode_bc1_block.argtypes, l.oracle_decode_bc1_block.restype = [u8p, u8p], None
+        l.oracle_normalize_bc1_blocks.argtypes, l.oracle_normalize_bc1_blocks.restype = [u8p, u8p, sz, i], None
+        l.oracle_normalize_bc1_split_blocks_in_place.argtypes = [u8p, u8p, sz, i]
+        l.oracle_normalize_bc1_split_blocks_in_place.restype = None
+        l.oracle_normalize_bc1_blocks_all_modes.argtypes = [u8p, u8p, u8p, u8p, sz]
+        l.oracle_normalize_bc1_blocks_all_modes.restype = i
+        l.oracle_transform_bc1_with_normalize_blocks.argtypes = [u8p, u8p, sz, i, i, i]
+        l.oracle_transform_bc1_with_normalize_blocks.restype = i
         _lib = l
     return _lib
 
@@ -187,3 +195,51 @@ def bc7_force_modes(data: np.ndarray) -> np.ndarray:
     assert data.dtype == np.uint8 and data.size % 16 == 0 and data.flags.c_contiguous
     lib().oracle_bc7_force_modes(_ptr(data), data.size)
     return data
+
+
+# ---- BC1 block normalisation (reference experimental module; dxtlt_oracle_norm.c) --------------------------
+NORMALIZE_NONE, NORMALIZE_COLOR0_ONLY, NORMALIZE_REPLICATE_COLOR = 0, 1, 2
+
+
+def decode_bc1_block(block) -> np.ndarray:
+    """16 RGBA8888 pixels, shape (16, 4), row-major (util/bc1_decode.rs:42)."""
+    a = np.ascontiguousarray(_as_u8(block))
+    assert a.size == 8
+    out = np.empty(64, dtype=np.uint8)
+    lib().oracle_decode_bc1_block(_ptr(a), _ptr(out))
+    return out.reshape(16, 4)
+
+
+def normalize_bc1_blocks(data, mode: int) -> np.ndarray:
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % 8 == 0
+    out = np.empty_like(a)
+    lib().oracle_normalize_bc1_blocks(_ptr(a), _ptr(out), a.size, int(mode))
+    return out
+
+
+def normalize_bc1_split_blocks(colors, indices, mode: int):
+    """Returns normalised copies of the two arrays (the C function works in place on the copies)."""
+    c = np.array(_as_u8(colors), dtype=np.uint8, copy=True)
+    x = np.array(_as_u8(indices), dtype=np.uint8, copy=True)
+    assert c.size == x.size and c.size % 4 == 0
+    lib().oracle_normalize_bc1_split_blocks_in_place(_ptr(c), _ptr(x), c.size // 4, int(mode))
+    return c, x
+
+
+def normalize_bc1_blocks_all_modes(data):
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % 8 == 0
+    outs = [np.empty_like(a) for _ in range(3)]
+    any_n = lib().oracle_normalize_bc1_blocks_all_modes(_ptr(a), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), a.size)
+    return outs, bool(any_n)
+
+
+def transform_bc1_with_normalize_blocks(data, mode: int, variant: int = VAR1, split_colour: bool = True) -> np.ndarray:
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % 8 == 0
+    out = np.empty_like(a)
+    rc = lib().oracle_transform_bc1_with_normalize_blocks(_ptr(a), _ptr(out), a.size, int(mode), int(variant),
+                                                          int(split_colour))
+    assert rc == 0
+    return out

@@ -225,3 +225,58 @@ def untransform_bc7(data) -> np.ndarray:
         out[idx, 1 + h:] = a[pos:pos + c * (15 - h)].reshape(c, 15 - h)
         pos += c * (15 - h)
     return out.reshape(-1)
+
+
+# ---- BC1 block normalisation (reference experimental module), second statement: all 16 pixels, vectorised -------------
+def decode_bc1_pixels(data) -> np.ndarray:
+    """(N, 16) uint32 pixels r | g << 8 | b << 16 | a << 24 (util/bc1_decode.rs:42-100)."""
+    b = _u8(data).reshape(-1, 8).astype(np.uint32)
+    c0 = b[:, 0] | (b[:, 1] << 8)
+    c1 = b[:, 2] | (b[:, 3] << 8)
+    idx = b[:, 4] | (b[:, 5] << 8) | (b[:, 6] << 16) | (b[:, 7] << 24)
+
+    def chan(c):
+        r, g, bl = (c >> 11) & 31, (c >> 5) & 63, c & 31
+        return (r << 3) | (r >> 2), (g << 2) | (g >> 4), (bl << 3) | (bl >> 2)
+
+    r0, g0, b0 = chan(c0)
+    r1, g1, b1 = chan(c1)
+    four = c0 > c1
+    opaque = np.uint32(0xFF000000)
+
+    def pack(r, g, bl):
+        return r | (g << 8) | (bl << 16) | opaque
+
+    pal = np.empty((b.shape[0], 4), dtype=np.uint32)
+    pal[:, 0] = pack(r0, g0, b0)
+    pal[:, 1] = pack(r1, g1, b1)
+    pal[:, 2] = np.where(four, pack((2 * r0 + r1) // 3, (2 * g0 + g1) // 3, (2 * b0 + b1) // 3),
+                         pack((r0 + r1) // 2, (g0 + g1) // 2, (b0 + b1) // 2))
+    pal[:, 3] = np.where(four, pack((r0 + 2 * r1) // 3, (g0 + 2 * g1) // 3, (b0 + 2 * b1) // 3), np.uint32(0))
+    sel = (idx[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3
+    return np.take_along_axis(pal, sel.astype(np.int64), axis=1)
+
+
+def normalize_bc1_blocks(data, mode: int) -> np.ndarray:
+    """normalize.rs:38-188, 214-258.  mode: 0 None, 1 Color0Only, 2 ReplicateColor."""
+    src = _u8(data)
+    out = src.copy()
+    if mode == 0 or src.size == 0:
+        return out
+    px = decode_bc1_pixels(src)
+    same = (px == px[:, :1]).all(axis=1)
+    first = px[:, 0]
+    transparent = same & ((first >> 24) == 0)
+    r, g, b = first & 255, (first >> 8) & 255, (first >> 16) & 255
+    c565 = ((r & 0xF8) << 8) | ((g & 0xFC) << 3) | (b >> 3)
+    rr, gg, bb = (c565 >> 11) & 31, (c565 >> 5) & 63, c565 & 31
+    back = ((rr << 3) | (rr >> 2)) | (((gg << 2) | (gg >> 4)) << 8) | (((bb << 3) | (bb >> 2)) << 16)
+    solid = same & ~transparent & (back == (first & 0xFFFFFF))
+    o = out.reshape(-1, 8)
+    o[transparent] = 0xFF
+    lo, hi = (c565 & 255).astype(np.uint8), (c565 >> 8).astype(np.uint8)
+    o[solid, 0], o[solid, 1] = lo[solid], hi[solid]
+    o[solid, 2] = lo[solid] if mode == 2 else 0
+    o[solid, 3] = hi[solid] if mode == 2 else 0
+    o[solid, 4:] = 0
+    return out

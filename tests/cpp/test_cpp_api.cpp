@@ -136,6 +136,37 @@ static void gpu_tests()
     core::EstimateSettings<DummyEstimator> es{DummyEstimator{}, true};
     auto r3 = core::transform_bc3_auto(w.data(), w2.data(), w.size(), es);
     CHECK(r3.second.is_ok() && es.size_estimator.calls == 32);  // 16 candidates x (alpha + colour endpoints)
+
+    // experimental block normalisation: the reference's unit vectors (normalize.rs:508-598, 750-848)
+    namespace ex = core::experimental;
+    const uint8_t solid[8] = {0x00, 0xF8, 0x01, 0x01, 0, 0, 0, 0}, clear[8] = {0x00, 0x80, 0x00, 0xF8, 0xFF, 0xFF, 0xFF, 0xFF};
+    uint8_t two[16], n0[16], n1[16], n2[16];
+    std::memcpy(two, solid, 8);
+    std::memcpy(two + 8, clear, 8);
+    ex::normalize_blocks(two, n1, 16, ex::ColorNormalizationMode::Color0Only);
+    const uint8_t want_c0[16] = {0x00, 0xF8, 0, 0, 0, 0, 0, 0, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+    CHECK(std::memcmp(n1, want_c0, 16) == 0);
+    CHECK(ex::normalize_blocks_all_modes(two, {n0, n1, n2}, 16));
+    const uint8_t want_rep[8] = {0x00, 0xF8, 0x00, 0xF8, 0, 0, 0, 0};
+    CHECK(std::memcmp(n0, solid, 8) == 0 && std::memcmp(n1, want_c0, 8) == 0 && std::memcmp(n2, want_rep, 8) == 0);
+    CHECK(std::memcmp(n0 + 8, want_c0 + 8, 8) == 0 && std::memcmp(n2 + 8, want_c0 + 8, 8) == 0);
+    ex::normalize_blocks(two, two, 16, ex::ColorNormalizationMode::ReplicateColor);   // in place
+    CHECK(std::memcmp(two, want_rep, 8) == 0);
+    // fused normalise + transform == transform of the normalised blocks; the details convert to untransform settings
+    ex::Bc1TransformDetailsWithNormalization det{ex::ColorNormalizationMode::Color0Only, core::YCoCgVariant::Variant2, true};
+    std::vector<uint8_t> xs = gen_bc1(2049), xn(xs.size()), f1(xs.size()), f2(xs.size()), back(xs.size());
+    for (size_t b = 0; b < 2049; b += 3) std::memset(&xs[8 * b + 4], 0, 4);   // every third block solid
+    ex::normalize_blocks(xs.data(), xn.data(), xs.size(), det.color_normalization_mode);
+    CHECK(xn != xs);
+    ex::transform_bc1_with_normalize_blocks(xs.data(), f1.data(), nullptr, xs.size(), det);
+    core::transform_bc1_with_settings(xn.data(), f2.data(), xn.size(), det);
+    CHECK(f1 == f2);
+    core::untransform_bc1_with_settings(f1.data(), back.data(), f1.size(), det);
+    CHECK(back == xn);
+    core::EstimateSettings<DummyEstimator> en{DummyEstimator{}, false};
+    auto rn = ex::transform_bc1_auto_with_normalization(xs.data(), f1.data(), xs.size(), en);
+    CHECK(rn.second.is_ok() && en.size_estimator.calls == 12);   // 3 modes x 4 candidates
+    CHECK(rn.first == ex::Bc1TransformDetailsWithNormalization(ex::ColorNormalizationMode::None, core::YCoCgVariant::None, false));
 }
 
 int main(int argc, char** argv)
