@@ -644,5 +644,32 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
     return hipGetLastError();
 }
 
+// Only the counting part of the inverse pipeline: from the `first` stream of n_blocks blocks to the nine per-mode
+// totals at the start of the workspace (multi-GPU sharding needs every shard's counts before it can place pieces).
+hipError_t launch_counts(const void* first, uint64_t n_blocks, void* workspace, size_t ws_bytes, hipStream_t stream)
+{
+    if (n_blocks == 0)
+        return hipSuccess;
+    if (ws_bytes < workspace_bytes(n_blocks) || workspace == nullptr)
+        return hipErrorInvalidValue;
+    if (((reinterpret_cast<uintptr_t>(first) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
+        return hipErrorInvalidValue;
+    const uint64_t tiles = tiles_for(n_blocks), groups = groups_for(tiles);
+    if (tiles > 0x7FFFFFFFull || groups > 65535ull * 1024)
+        return hipErrorInvalidValue;
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    uint64_t* totals = reinterpret_cast<uint64_t*>(ws);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 256);
+    uint32_t* prefix = hist + 9 * tiles;
+    uint32_t* gsum = prefix + 9 * tiles;
+    hipLaunchKernelGGL(bc7_hist_inv, dim3((unsigned)((tiles + kInvTilesPerWave * 4 - 1) / (kInvTilesPerWave * 4))), dim3(kThreads), 0,
+                       stream, static_cast<const uint8_t*>(first), hist, n_blocks, tiles);
+    hipLaunchKernelGGL(bc7_group_sums, dim3((unsigned)groups, 9), dim3(kThreads), 0, stream, hist, gsum, tiles,
+                       (uint32_t)groups);
+    hipLaunchKernelGGL(bc7_scan, dim3((unsigned)groups, 9), dim3(1024), 0, stream, hist, gsum, prefix, totals, tiles,
+                       (uint32_t)groups);
+    return hipGetLastError();
+}
+
 }  // namespace bc7
 }  // namespace dxtlt

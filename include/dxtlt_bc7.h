@@ -30,6 +30,23 @@ int32_t dxtlt_transform_bc7_device(const void *d_input, void *d_output, size_t l
 int32_t dxtlt_untransform_bc7_device(const void *d_input, void *d_output, size_t len, void *d_workspace,
                                      size_t workspace_bytes, void *hip_stream);
 
+/* ---- single-process multi-GPU: contiguous block ranges over the node's GPUs, no collective -----
+ * Output placement depends on the data of earlier shards, so every shard first reports its nine per-mode block counts;
+ * the host turns them into the placement table below; then each shard's 19 stream pieces are copied to / from their
+ * final places.  num_shards <= 0: one shard per visible device; more shards than devices are spread round robin (that
+ * is how a single-GPU machine exercises the placement).  At most 64 shards.  Same result as the unsharded call. */
+int32_t dxtlt_transform_bc7_sharded(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len, int32_t num_shards);
+int32_t dxtlt_untransform_bc7_sharded(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len, int32_t num_shards);
+
+/* The placement table on its own (host code, no device).  counts[s * 9 + m] = blocks of mode class m (0..7, 8 = the
+ * reserved byte-0 == 0 encoding) in shard s; the shards are the contiguous ranges [shard_first_block[s],
+ * + shard_num_blocks[s]) covering [0, total_blocks).  For piece p of shard `shard` (p = 0: `first`, 1 + m: head_m,
+ * 10 + m: tail_m): global_off[p] = byte offset in the whole transformed buffer, local_off[p] = byte offset in the
+ * shard's own transformed buffer, bytes[p] = length.  Arrays of 19. */
+int32_t dxtlt_bc7_shard_pieces(const uint64_t *counts, int32_t num_shards, int32_t shard,
+                               const uint64_t *shard_first_block, const uint64_t *shard_num_blocks,
+                               uint64_t total_blocks, uint64_t *global_off, uint64_t *local_off, uint64_t *bytes);
+
 #ifdef __cplusplus
 }
 #endif
