@@ -84,8 +84,8 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
                   f"scalar C oracle (gcc -O3)",
         "all_cores_value": round(allc, 3), "all_cores": cores,
     }
-    # A vectorised port of the reference's AVX2 strategy exists for the headline settings (BC1, Variant1 + split): when
-    # the host has AVX2 it becomes the quoted figure (closest analogue of "the reference's SIMD path on one core").
+    # Vectorised ports of the reference's AVX2 / AVX-512BW strategy exist for the headline settings (BC1, Variant1 +
+    # split): when the host has AVX2 the widest one becomes the quoted figure (closest analogue of "the reference's SIMD path on one core").
     if fmt == "bc1" and (v, bool(sc)) == (1, True) and oracle_c.simd_available():
         def run_simd(threads, reps):
             best = None
@@ -104,9 +104,17 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
         out.update({
             "scalar_value": out["value"], "scalar_all_cores_value": out["all_cores_value"],
             "value": round(simd_one, 3), "all_cores_value": round(simd_all, 3),
-            "sample": f"{sample_mib} MiB of the same BC1 splitmix64 workload, forward+inverse, best of 3, AVX2 port of "
-                      f"the reference's SIMD strategy (oracle/dxtlt_oracle_avx2.c, gcc -O3); scalar_* = scalar C oracle",
+            "isa": oracle_c.SIMD_NAMES[oracle_c.simd_level()],
+            "sample": f"{sample_mib} MiB of the same BC1 splitmix64 workload, forward+inverse, best of 3, "
+                      f"{oracle_c.SIMD_NAMES[oracle_c.simd_level()]} port of the reference's SIMD strategy "
+                      f"(oracle/dxtlt_oracle_avx2.c, gcc -O3; the widest level this host has); scalar_* = scalar C oracle",
         })
+        if oracle_c.simd_level() == 5:   # also quote the AVX2 port on the same host
+            oracle_c.simd_set_cap(2)
+            try:
+                out["avx2_value"] = round(run_simd(1, 3), 3)
+            finally:
+                oracle_c.simd_set_cap(5)
     return out
 
 

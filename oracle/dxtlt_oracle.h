@@ -105,6 +105,9 @@ void oracle_run_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_
 /* AVX2 port of the reference's SIMD strategy, BC1 default settings only (Variant1 + split colours), with a scalar
  * tail; equals oracle_{un,}transform_bc1(..., VAR1, 1) byte for byte.  cpu_baseline leg only.  (dxtlt_oracle_avx2.c) */
 int oracle_simd_available(void);
+/* 0 = scalar, 2 = AVX2, 5 = AVX-512BW: the widest level the CPU has (and the cap allows); set_cap returns the level now in effect */
+int oracle_simd_level(void);
+int oracle_simd_set_cap(int cap);
 void oracle_bc1_default_simd_range(int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first,
                                    size_t count);
 void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads);

@@ -1,5 +1,5 @@
 /*
- * dxtlt_oracle_avx2.c -- AVX2 port of the reference's SIMD strategy for BC1 default settings (YCoCg Variant1 + split
+ * dxtlt_oracle_avx2.c -- AVX2 and AVX-512BW ports of the reference's SIMD strategy for BC1 default settings (YCoCg Variant1 + split
  * colour endpoints), forward and inverse.  TEST INFRASTRUCTURE ONLY: it exists so that bench.py's cpu_baseline can also
  * quote a vectorised CPU figure ("the reference's own SIMD path timed on the GPU box's host cores", BASELINE.json);
  * tests/test_oracle.py requires it to equal the scalar oracle byte for byte.
@@ -30,6 +30,25 @@ int oracle_simd_available(void)
 #else
     return 0;
 #endif
+}
+
+/* 0 = scalar only, 2 = AVX2, 5 = AVX-512BW (what oracle_bc1_default_simd_range will use unless capped) */
+static int g_simd_cap = 5;
+int oracle_simd_level(void)
+{
+#if HAVE_X86
+    if (g_simd_cap >= 5 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw"))
+        return 5;
+    if (g_simd_cap >= 2 && __builtin_cpu_supports("avx2"))
+        return 2;
+#endif
+    return 0;
+}
+/* tests and the bench's ISA comparison: cap the level (0, 2 or 5); returns the level now in effect */
+int oracle_simd_set_cap(int cap)
+{
+    g_simd_cap = cap;
+    return oracle_simd_level();
 }
 
 #if HAVE_X86
@@ -121,6 +140,92 @@ TGT static void bc1_default_inv_avx2(const uint8_t *in, uint8_t *out, size_t n_t
     }
 }
 
+/* ---- AVX-512BW: 32 blocks (256 B) per iteration.  Strategy followed (not code): .../with_split_colour_and_recorr/
+ * transform/avx512bw.rs and untransform/avx512bw.rs -- two-source dword permutes separate colours from indices,
+ * YCoCg-R on 32 16-bit lanes, one word permute splits c0 / c1.  Index vectors are this file's own. ---- */
+#define TGT512 __attribute__((target("avx512f,avx512bw")))
+
+TGT512 static inline __m512i decorrelate_var1_epi16_512(__m512i v)
+{
+    const __m512i m5 = _mm512_set1_epi16(0x1F);
+    const __m512i r = _mm512_srli_epi16(v, 11);
+    const __m512i g = _mm512_and_si512(_mm512_srli_epi16(v, 6), m5);
+    const __m512i gl = _mm512_and_si512(v, _mm512_set1_epi16(0x20));
+    const __m512i b = _mm512_and_si512(v, m5);
+    const __m512i co = _mm512_and_si512(_mm512_sub_epi16(r, b), m5);
+    const __m512i t = _mm512_and_si512(_mm512_add_epi16(b, _mm512_srli_epi16(co, 1)), m5);
+    const __m512i cg = _mm512_and_si512(_mm512_sub_epi16(g, t), m5);
+    const __m512i y = _mm512_and_si512(_mm512_add_epi16(t, _mm512_srli_epi16(cg, 1)), m5);
+    return _mm512_or_si512(_mm512_or_si512(_mm512_slli_epi16(y, 11), _mm512_slli_epi16(co, 6)), _mm512_or_si512(gl, cg));
+}
+
+TGT512 static inline __m512i recorrelate_var1_epi16_512(__m512i v)
+{
+    const __m512i m5 = _mm512_set1_epi16(0x1F);
+    const __m512i y = _mm512_srli_epi16(v, 11);
+    const __m512i co = _mm512_and_si512(_mm512_srli_epi16(v, 6), m5);
+    const __m512i gl = _mm512_and_si512(v, _mm512_set1_epi16(0x20));
+    const __m512i cg = _mm512_and_si512(v, m5);
+    const __m512i t = _mm512_and_si512(_mm512_sub_epi16(y, _mm512_srli_epi16(cg, 1)), m5);
+    const __m512i g = _mm512_and_si512(_mm512_add_epi16(cg, t), m5);
+    const __m512i b = _mm512_and_si512(_mm512_sub_epi16(t, _mm512_srli_epi16(co, 1)), m5);
+    const __m512i r = _mm512_and_si512(_mm512_add_epi16(b, co), m5);
+    return _mm512_or_si512(_mm512_or_si512(_mm512_slli_epi16(r, 11), _mm512_slli_epi16(g, 6)), _mm512_or_si512(gl, b));
+}
+
+/* count is a multiple of 32 */
+TGT512 static void bc1_default_fwd_avx512(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    uint8_t *c0 = out + 2 * first, *c1 = out + 2 * n_total + 2 * first, *idx = out + 4 * n_total + 4 * first;
+    const uint8_t *p = in + 8 * first;
+    /* dword i of (a, b): even dwords are colours, odd dwords indices */
+    const __m512i even = _mm512_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30);
+    const __m512i odd = _mm512_setr_epi32(1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31);
+    /* word i of (lo, hi): even words are c0, odd words c1 */
+    const __m512i w_even = _mm512_set_epi16(62, 60, 58, 56, 54, 52, 50, 48, 46, 44, 42, 40, 38, 36, 34, 32, 30, 28, 26, 24, 22,
+                                            20, 18, 16, 14, 12, 10, 8, 6, 4, 2, 0);
+    const __m512i w_odd = _mm512_set_epi16(63, 61, 59, 57, 55, 53, 51, 49, 47, 45, 43, 41, 39, 37, 35, 33, 31, 29, 27, 25, 23,
+                                           21, 19, 17, 15, 13, 11, 9, 7, 5, 3, 1);
+    for (size_t i = 0; i < count; i += 32, p += 256, c0 += 64, c1 += 64, idx += 128) {
+        const __m512i a = _mm512_loadu_si512((const void *)(p + 0));     /* blocks 0-7 */
+        const __m512i b = _mm512_loadu_si512((const void *)(p + 64));    /* blocks 8-15 */
+        const __m512i c = _mm512_loadu_si512((const void *)(p + 128));
+        const __m512i d = _mm512_loadu_si512((const void *)(p + 192));
+        const __m512i col_lo = decorrelate_var1_epi16_512(_mm512_permutex2var_epi32(a, even, b));   /* blocks 0-15 */
+        const __m512i col_hi = decorrelate_var1_epi16_512(_mm512_permutex2var_epi32(c, even, d));   /* blocks 16-31 */
+        _mm512_storeu_si512((void *)c0, _mm512_permutex2var_epi16(col_lo, w_even, col_hi));
+        _mm512_storeu_si512((void *)c1, _mm512_permutex2var_epi16(col_lo, w_odd, col_hi));
+        _mm512_storeu_si512((void *)idx, _mm512_permutex2var_epi32(a, odd, b));
+        _mm512_storeu_si512((void *)(idx + 64), _mm512_permutex2var_epi32(c, odd, d));
+    }
+}
+
+TGT512 static void bc1_default_inv_avx512(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    const uint8_t *c0 = in + 2 * first, *c1 = in + 2 * n_total + 2 * first, *idx = in + 4 * n_total + 4 * first;
+    uint8_t *p = out + 8 * first;
+    /* word interleave of (c0, c1): result word 2k = c0[k], 2k+1 = c1[k]; low half k = 0..15, high half k = 16..31 */
+    const __m512i il_lo = _mm512_set_epi16(47, 15, 46, 14, 45, 13, 44, 12, 43, 11, 42, 10, 41, 9, 40, 8, 39, 7, 38, 6, 37, 5,
+                                           36, 4, 35, 3, 34, 2, 33, 1, 32, 0);
+    const __m512i il_hi = _mm512_set_epi16(63, 31, 62, 30, 61, 29, 60, 28, 59, 27, 58, 26, 57, 25, 56, 24, 55, 23, 54, 22, 53,
+                                           21, 52, 20, 51, 19, 50, 18, 49, 17, 48, 16);
+    /* dword interleave of (colours, indices): blocks 0-7 then 8-15 of a 16-block group */
+    const __m512i dl_lo = _mm512_setr_epi32(0, 16, 1, 17, 2, 18, 3, 19, 4, 20, 5, 21, 6, 22, 7, 23);
+    const __m512i dl_hi = _mm512_setr_epi32(8, 24, 9, 25, 10, 26, 11, 27, 12, 28, 13, 29, 14, 30, 15, 31);
+    for (size_t i = 0; i < count; i += 32, p += 256, c0 += 64, c1 += 64, idx += 128) {
+        const __m512i v0 = _mm512_loadu_si512((const void *)c0);   /* c0 of 32 blocks */
+        const __m512i v1 = _mm512_loadu_si512((const void *)c1);
+        const __m512i col_a = recorrelate_var1_epi16_512(_mm512_permutex2var_epi16(v0, il_lo, v1));   /* blocks 0-15 */
+        const __m512i col_b = recorrelate_var1_epi16_512(_mm512_permutex2var_epi16(v0, il_hi, v1));   /* blocks 16-31 */
+        const __m512i ia = _mm512_loadu_si512((const void *)idx);
+        const __m512i ib = _mm512_loadu_si512((const void *)(idx + 64));
+        _mm512_storeu_si512((void *)(p + 0), _mm512_permutex2var_epi32(col_a, dl_lo, ia));
+        _mm512_storeu_si512((void *)(p + 64), _mm512_permutex2var_epi32(col_a, dl_hi, ia));
+        _mm512_storeu_si512((void *)(p + 128), _mm512_permutex2var_epi32(col_b, dl_lo, ib));
+        _mm512_storeu_si512((void *)(p + 192), _mm512_permutex2var_epi32(col_b, dl_hi, ib));
+    }
+}
+
 #endif /* HAVE_X86 */
 
 /* scalar range kernels live in dxtlt_oracle.c; re-stated minimally here for the tail */
@@ -157,7 +262,14 @@ void oracle_bc1_default_simd_range(int inverse, const uint8_t *in, uint8_t *out,
 {
     size_t body = 0;
 #if HAVE_X86
-    if (oracle_simd_available()) {
+    const int level = oracle_simd_level();
+    if (level == 5) {
+        body = count & ~(size_t)31;
+        if (inverse)
+            bc1_default_inv_avx512(in, out, n_total, first, body);
+        else
+            bc1_default_fwd_avx512(in, out, n_total, first, body);
+    } else if (level == 2) {
         body = count & ~(size_t)15;
         if (inverse)
             bc1_default_inv_avx2(in, out, n_total, first, body);
@@ -196,7 +308,7 @@ void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, si
     struct simd_job *jobs = (struct simd_job *)calloc((size_t)threads, sizeof *jobs);
     pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof *tids);
     size_t per = (n + (size_t)threads - 1) / (size_t)threads;
-    per = (per + 15) & ~(size_t)15; /* keep every range a multiple of the vector width */
+    per = (per + 31) & ~(size_t)31; /* keep every range a multiple of the widest vector loop */
     for (int t = 0; t < threads; ++t) {
         size_t first = per * (size_t)t;
         size_t count = first >= n ? 0 : (first + per > n ? n - first : per);

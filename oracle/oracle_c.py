@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
         l.oracle_bc7_force_modes.argtypes = [u8p, sz]
         l.oracle_bc7_force_modes.restype = None
         l.oracle_simd_available.argtypes, l.oracle_simd_available.restype = [], i
+        l.oracle_simd_level.argtypes, l.oracle_simd_level.restype = [], i
+        l.oracle_simd_set_cap.argtypes, l.oracle_simd_set_cap.restype = [i], i
         l.oracle_bc1_default_simd_mt.argtypes = [i, u8p, u8p, sz, i]
         l.oracle_bc1_default_simd_mt.restype = None
         l.oracle_decode_bc1_block.argtypes, l.oracle_decode_bc1_block.restype = [u8p, u8p], None
@@ -176,8 +178,21 @@ def simd_available() -> bool:
     return bool(lib().oracle_simd_available())
 
 
+def simd_level() -> int:
+    """0 = scalar, 2 = AVX2, 5 = AVX-512BW: what run_bc1_default_simd uses on this CPU (under the current cap)."""
+    return int(lib().oracle_simd_level())
+
+
+def simd_set_cap(cap: int) -> int:
+    """Cap the vector level (0, 2, 5); returns the level now in effect."""
+    return int(lib().oracle_simd_set_cap(int(cap)))
+
+
+SIMD_NAMES = {0: "scalar", 2: "AVX2", 5: "AVX-512BW"}
+
+
 def run_bc1_default_simd(src: np.ndarray, dst: np.ndarray, inverse: bool, threads: int) -> None:
-    """AVX2 port (scalar when the CPU has no AVX2) of BC1 {Variant1, split}; cpu_baseline leg and its test only."""
+    """AVX-512BW / AVX2 port (scalar when the CPU has neither) of BC1 {Variant1, split}; cpu_baseline leg and its test only."""
     lib().oracle_bc1_default_simd_mt(int(inverse), _ptr(src), _ptr(dst), src.size, int(threads))
 
 

@@ -187,19 +187,27 @@ def test_transform_helps_a_generic_compressor_on_real_textures(oracle):
         assert default < raw * 1.02, (fmt, raw, default)  # the default is near the best, never a big loss
 
 
-def test_avx2_port_equals_scalar_oracle(oracle):
-    """The vectorised CPU baseline (AVX2 port of the reference's SIMD strategy, BC1 default settings) must be the same
-    function as the scalar oracle: every block count around the 16-block vector width, several thread counts."""
-    for n in list(range(0, 50)) + [255, 256, 257, 100_003]:
-        x = oracle.fill_splitmix64(n * 8, 0xA7C2 + n)
-        want = oracle.transform("bc1", x, 1, True)
-        for threads in (1, 3):
-            got = np.full_like(x, 0xEE)
-            oracle.run_bc1_default_simd(x, got, False, threads)
-            assert np.array_equal(got, want), (n, threads)
-            back = np.full_like(x, 0xEE)
-            oracle.run_bc1_default_simd(want, back, True, threads)
-            assert np.array_equal(back, x), (n, threads, "inverse")
+def test_simd_ports_equal_scalar_oracle(oracle):
+    """The vectorised CPU baselines (AVX2 and AVX-512BW ports of the reference's SIMD strategy, BC1 default settings)
+    must be the same function as the scalar oracle: every block count around the 16- and 32-block vector widths,
+    several thread counts, every vector level this CPU has."""
+    top = oracle.simd_level()
+    try:
+        for cap in (0, 2, 5):
+            level = oracle.simd_set_cap(cap)
+            assert level <= min(cap, top)
+            for n in list(range(0, 70)) + [255, 256, 257, 100_003]:
+                x = oracle.fill_splitmix64(n * 8, 0xA7C2 + n)
+                want = oracle.transform("bc1", x, 1, True)
+                for threads in (1, 3):
+                    got = np.full_like(x, 0xEE)
+                    oracle.run_bc1_default_simd(x, got, False, threads)
+                    assert np.array_equal(got, want), (level, n, threads)
+                    back = np.full_like(x, 0xEE)
+                    oracle.run_bc1_default_simd(want, back, True, threads)
+                    assert np.array_equal(back, x), (level, n, threads, "inverse")
+    finally:
+        oracle.simd_set_cap(5)
 
 
 def test_mt_range_split_matches_single_thread(oracle):
