@@ -213,6 +213,55 @@ bc7_scan(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, u
         totals[m] = (uint64_t)gbase + wbase + incl;
 }
 
+// Inputs of up to 1024 tiles (16 MiB) are launch bound: five dependent launches cost ~27 us whatever the size.  For
+// them one workgroup does steps 2, 3 and 3b at once -- thread t owns tile t, the nine modes are scanned side by side --
+// and the pipeline is three launches.
+__global__ void __launch_bounds__(1024)
+bc7_scan_small(const uint32_t* __restrict__ hist, uint32_t* __restrict__ prefix, uint64_t* __restrict__ totals,
+               uint64_t* __restrict__ bases, uint64_t num_tiles, uint64_t n_blocks)
+{
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ uint32_t wsum[9][16];
+    __shared__ uint64_t tot[9];
+    uint32_t v[9], incl[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+        v[m] = t < num_tiles ? hist[(uint64_t)m * num_tiles + t] : 0;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+        incl[m] = v[m];
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl[m], o);
+            if ((int)lane >= o) incl[m] += up;
+        }
+        if (lane == 63)
+            wsum[m][wave] = incl[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+        uint32_t wbase = 0;
+        for (uint32_t i = 0; i < wave; ++i)
+            wbase += wsum[m][i];
+        if (t < num_tiles)
+            prefix[(uint64_t)m * num_tiles + t] = wbase + incl[m] - v[m];
+        if (t == 1023) {
+            tot[m] = (uint64_t)wbase + incl[m];
+            totals[m] = tot[m];
+        }
+    }
+    __syncthreads();
+    if (t < 18) {
+        const int m = t < 9 ? (int)t : (int)t - 9;
+        uint64_t base = n_blocks;
+        for (int mm = 0; mm < m; ++mm)
+            base += tot[mm] * 15;
+        if (t >= 9)
+            base += tot[m] * (uint64_t)head_bytes(m);
+        bases[t] = base;
+    }
+}
+
 // ---- piece movement ---------------------------------------------------------------------------------------
 // Bytes [lo, hi) of one 16-byte segment, both pointers 16-byte aligned at byte 0 of the segment: an ascending
 // ladder of naturally aligned 1/2/4/8-byte moves from lo, then a descending one for what is left.
@@ -630,11 +679,15 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
     else
         hipLaunchKernelGGL(bc7_hist_inv, dim3((unsigned)((tiles + kInvTilesPerWave * 4 - 1) / (kInvTilesPerWave * 4))), dim3(kThreads), 0,
                            stream, s8, hist, n_blocks, tiles);
-    hipLaunchKernelGGL(bc7_group_sums, dim3((unsigned)groups, 9), dim3(kThreads), 0, stream, hist, gsum, tiles,
-                       (uint32_t)groups);
-    hipLaunchKernelGGL(bc7_scan, dim3((unsigned)groups, 9), dim3(1024), 0, stream, hist, gsum, prefix, totals, tiles,
-                       (uint32_t)groups);
-    hipLaunchKernelGGL(bc7_stream_bases, dim3(1), dim3(64), 0, stream, totals, bases, n_blocks);
+    if (tiles <= 1024) {
+        hipLaunchKernelGGL(bc7_scan_small, dim3(1), dim3(1024), 0, stream, hist, prefix, totals, bases, tiles, n_blocks);
+    } else {
+        hipLaunchKernelGGL(bc7_group_sums, dim3((unsigned)groups, 9), dim3(kThreads), 0, stream, hist, gsum, tiles,
+                           (uint32_t)groups);
+        hipLaunchKernelGGL(bc7_scan, dim3((unsigned)groups, 9), dim3(1024), 0, stream, hist, gsum, prefix, totals, tiles,
+                           (uint32_t)groups);
+        hipLaunchKernelGGL(bc7_stream_bases, dim3(1), dim3(64), 0, stream, totals, bases, n_blocks);
+    }
     if (!inverse)
         hipLaunchKernelGGL(bc7_scatter_fwd, dim3((unsigned)tiles), dim3(kThreads), 0, stream, s8, d8, prefix, bases, n_blocks,
                            tiles);

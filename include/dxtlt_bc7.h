@@ -9,7 +9,7 @@
  *
  * Contract: len is a multiple of 16; output length == input length; buffers must not overlap; returns DXTLT_* status
  * codes of dxtlt_gfx950.h.  Device-pointer calls need 16-byte aligned buffers and a scratch buffer of
- * dxtlt_bc7_workspace_bytes(len) bytes; they enqueue 4 kernels on the stream and do not synchronise.
+ * dxtlt_bc7_workspace_bytes(len) bytes; they enqueue 3 kernels (inputs up to 16 MiB) or 5 on the stream and do not synchronise.
  */
 #ifndef DXTLT_BC7_H
 #define DXTLT_BC7_H
