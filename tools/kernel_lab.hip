@@ -514,6 +514,14 @@ __global__ void __launch_bounds__(128) fwd_policy(const uint8_t* __restrict__ in
     st16_policy<SP>(out + g, v);
 }
 
+// plain one-shot copy with the same load / store policies: the ceiling for "read len, write len" under that policy
+template <int LP, int SP, int THREADS>
+__global__ void __launch_bounds__(THREADS) copy_policy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    st16_policy<SP>(out + i * 16, ld16_policy<LP>(in + i * 16));
+}
+
 __global__ void fill_k(uint64_t* p, uint64_t n, uint64_t seed)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -571,6 +579,12 @@ int main(int argc, char** argv)
 
 
 
+#define ADD_COPY(LP, SP, TH) add("copy_policy T" #TH " load" #LP " store" #SP, 0, [=] { copy_policy<LP, SP, TH><<<(unsigned)(len / (16 * TH)), TH>>>(x, y); })
+    ADD_COPY(1, 1, 128);
+    ADD_COPY(1, 4, 128);
+    ADD_COPY(1, 4, 256);
+    ADD_COPY(1, 4, 64);
+    ADD_COPY(0, 0, 128);
 #define ADD_POL(LP, SP) add("fwd_policy T128 load" #LP " store" #SP, 1, [=] { fwd_policy<LP, SP><<<(unsigned)(len / 2048), 128>>>(x, y, len / 2048, N); })
     ADD_POL(1, 1); ADD_POL(0, 0); ADD_POL(1, 0); ADD_POL(0, 1); ADD_POL(1, 2); ADD_POL(1, 3); ADD_POL(1, 4); ADD_POL(1, 5);
     ADD_POL(2, 1); ADD_POL(4, 1); ADD_POL(3, 1); ADD_POL(5, 5);
