@@ -1,0 +1,48 @@
+"""Many device-resident buffers in one call (dxtlt_transform_batch_device, include/dxtlt_gfx950.h): one kernel launch per
+(format, direction) present in the batch, enqueued on torch's current stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence, Tuple
+
+from . import _lib
+
+
+class DxtltBatchItem(C.Structure):
+    _fields_ = [("d_input", C.c_void_p), ("d_output", C.c_void_p), ("len", C.c_uint64), ("format", C.c_uint8),
+                ("inverse", C.c_uint8), ("decorrelation_mode", C.c_uint8), ("split_alpha_endpoints", C.c_uint8),
+                ("split_colour_endpoints", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+def transform_batch(items: Sequence[Tuple[str, bool, object, object, object]]) -> None:
+    """items: (fmt, inverse, input tensor, output tensor, settings) with CUDA uint8 tensors on one device."""
+    import torch
+
+    from . import (_FMT_ID, BLOCK_BYTES, DeviceError, InvalidLength, OutputBufferTooSmall, _Buf, _settings_tuple)
+
+    if not items:
+        return
+    arr = (DxtltBatchItem * len(items))()
+    device = None
+    for k, (fmt, inverse, src, dst, settings) in enumerate(items):
+        s, d = _Buf(src, False), _Buf(dst, True)
+        if s.device is None or d.device is None:
+            raise TypeError("transform_batch takes device tensors")
+        device = s.device if device is None else device
+        if s.device != device or d.device != device:
+            raise ValueError("all tensors of a batch must live on one device")
+        if s.nbytes % BLOCK_BYTES[fmt] != 0:
+            raise InvalidLength(s.nbytes)
+        if d.nbytes < s.nbytes:
+            raise OutputBufferTooSmall(s.nbytes, d.nbytes)
+        mode, sa, sc = _settings_tuple(fmt, settings)
+        arr[k].d_input, arr[k].d_output, arr[k].len = s.ptr, d.ptr, s.nbytes
+        arr[k].format, arr[k].inverse, arr[k].decorrelation_mode = _FMT_ID[fmt], int(bool(inverse)), mode
+        arr[k].split_alpha_endpoints, arr[k].split_colour_endpoints = int(bool(sa)), int(bool(sc))
+    l = _lib.load()
+    l.dxtlt_transform_batch_device.argtypes = [C.POINTER(DxtltBatchItem), C.c_size_t, C.c_void_p]
+    l.dxtlt_transform_batch_device.restype = C.c_int32
+    with torch.cuda.device(device):
+        rc = l.dxtlt_transform_batch_device(arr, len(items), torch.cuda.current_stream().cuda_stream)
+    if rc != _lib.OK:
+        raise DeviceError(rc, _lib.last_error())

@@ -559,16 +559,17 @@ __device__ __forceinline__ void shifted_segment(int o, uint64_t total_blocks, ui
     }
 }
 
+constexpr int kShiftLdsBytes = 256 * 16 + 16 * 6;
+
+// one shifted tile, forward; `lds` is the workgroup's kShiftLdsBytes scratch (shared with the batch kernel)
 template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone>
-__global__ void __launch_bounds__(256)
-fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-                Shifts sh)
+__device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
+                                               uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
+                                               uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * 16 + 16 * 6];
     const int t = threadIdx.x;
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     const uint64_t blk0 = first_block + tile * T;
     int base[6];
 #pragma unroll
@@ -599,16 +600,25 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
     }
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone>
 __global__ void __launch_bounds__(256)
-inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
+fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
                 Shifts sh)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    fwd_shift_tile<FMT, VARIANT, SA, SC, NORM>(aos, soa, total_blocks, first_block, sh, tile, lds);
+}
+
+// one shifted tile, inverse
+template <int FMT, int VARIANT, bool SA, bool SC>
+__device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
+                                               uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
+                                               uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * 16 + 16 * 6];
     const int t = threadIdx.x;
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     const uint64_t blk0 = first_block + tile * T;
     int base[6];
 #pragma unroll
@@ -659,6 +669,16 @@ inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint
     gstore16(aos + tile * 4096 + t * 16, q);
 }
 
+template <int FMT, int VARIANT, bool SA, bool SC>
+__global__ void __launch_bounds__(256)
+inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
+                Shifts sh)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Element-granular kernels: one lane per block, any alignment, any block count.  Used for the tail of a
 // tiled range and for buffers whose pointers / stream bases are not 16-byte aligned.
@@ -697,15 +717,15 @@ __device__ __forceinline__ uint64_t load_bytes(const uint8_t* p, bool natural)
 
 __device__ __forceinline__ bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
+// block i (0 <= i < count) of the element-granular range; shared by generic_kernel and the batch kernel
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int NORM = kNormNone>
-__global__ void __launch_bounds__(kThreads)
-generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t total_blocks,
-               uint64_t first_block, uint64_t local_first, uint64_t count)
+__device__ __forceinline__ void generic_block(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                              uint64_t total_blocks, uint64_t first_block, uint64_t local_first,
+                                              uint64_t count, uint64_t i)
 {
     // AoS side: block (local_first + i) of the range lives at aos + (local_first + i) * BLOCK.
     // SoA side: global block index first_block + local_first + i.
     constexpr int B = fmt_block(FMT);
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     if (i >= count)
         return;
     const uint64_t lb = local_first + i;
@@ -827,6 +847,78 @@ generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint6
         }
         store_bytes<4>(aos_m + CO, colours, aos4);
         store_bytes<4>(aos_m + CO + 4, indices, aos4);
+    }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int NORM = kNormNone>
+__global__ void __launch_bounds__(kThreads)
+generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t total_blocks,
+               uint64_t first_block, uint64_t local_first, uint64_t count)
+{
+    generic_block<FMT, VARIANT, SA, SC, INVERSE, NORM>(src, dst, total_blocks, first_block, local_first, count,
+                                                       (uint64_t)blockIdx.x * kThreads + threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch kernel: many buffers of one format and direction in ONE launch (dxtlt_transform_batch_device).  A texture of
+// a few MiB cannot fill 256 CUs and launching them one by one is bound by the ~5 us a launch costs the host; here
+// every workgroup looks up which buffer it belongs to and runs one shifted tile of it (the shifted-tile body also
+// covers aligned stream bases: shift 0) or, past the buffer's last full tile, 256 blocks of the element path.
+// Settings are per buffer, so the variant / split combination is a run-time switch over the instantiated bodies;
+// workgroups of one buffer all take the same case.
+// ------------------------------------------------------------------------------------------------
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
+__device__ __forceinline__ void batch_unit(const BatchEntry& en, uint32_t local, uint8_t* lds)
+{
+    constexpr uint64_t T = tile_blocks(FMT, 256);
+    if (local < en.tile_wgs) {
+        Shifts sh;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            sh.d[i] = en.shift[i];
+        sh.xcd_remap = 0;
+        if constexpr (INVERSE)
+            inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+        else
+            fwd_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+    } else {
+        const uint64_t done = (uint64_t)en.tile_wgs * T;
+        generic_block<FMT, VARIANT, SA, SC, INVERSE>(en.src, en.dst, en.blocks, 0, done, en.blocks - done,
+                                                     (uint64_t)(local - en.tile_wgs) * 256 + threadIdx.x);
+    }
+}
+
+template <int FMT, int VARIANT, bool INVERSE>
+__device__ __forceinline__ void batch_splits(const BatchEntry& en, uint32_t local, uint8_t* lds)
+{
+    if constexpr (FMT == kBc3) {
+        if (en.split_alpha) {
+            if (en.split_colour) batch_unit<FMT, VARIANT, true, true, INVERSE>(en, local, lds);
+            else batch_unit<FMT, VARIANT, true, false, INVERSE>(en, local, lds);
+            return;
+        }
+    }
+    if (en.split_colour) batch_unit<FMT, VARIANT, false, true, INVERSE>(en, local, lds);
+    else batch_unit<FMT, VARIANT, false, false, INVERSE>(en, local, lds);
+}
+
+template <int FMT, bool INVERSE>
+__global__ void __launch_bounds__(256)
+batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    const uint32_t wg = blockIdx.x;
+    // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each
+    uint32_t e = coarse[wg >> 6];
+    while (e + 1 < n_entries && entries[e + 1].first_wg <= wg)
+        ++e;
+    const BatchEntry en = entries[e];
+    const uint32_t local = wg - en.first_wg;
+    switch (en.variant) {
+    case kNone: batch_splits<FMT, kNone, INVERSE>(en, local, lds); break;
+    case kVar1: batch_splits<FMT, kVar1, INVERSE>(en, local, lds); break;
+    case kVar2: batch_splits<FMT, kVar2, INVERSE>(en, local, lds); break;
+    default: batch_splits<FMT, kVar3, INVERSE>(en, local, lds); break;
     }
 }
 
@@ -1037,6 +1129,38 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             return e;
     }
     return hipSuccess;
+}
+
+uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)
+{
+    const bool sa = fmt == kBc3 && e.split_alpha;
+    const Streams S = make_streams(fmt, sa, e.split_colour != 0);
+    const void* aos = inverse ? (const void*)e.dst : (const void*)e.src;
+    const void* soa = inverse ? (const void*)e.src : (const void*)e.dst;
+    for (int i = 0; i < 6; ++i)
+        e.shift[i] = i < S.n ? (uint8_t)((reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * e.blocks) & 15) : 0;
+    const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
+    // tiles need a 16-byte aligned AoS pointer; anything else goes through the element path block by block
+    const uint64_t tiles = (reinterpret_cast<uintptr_t>(aos) & 15) == 0 ? e.blocks / T : 0;
+    const uint64_t tail_wgs = (e.blocks - tiles * T + 255) / 256;
+    e.tile_wgs = (uint32_t)tiles;
+    return (uint32_t)(tiles + tail_wgs);
+}
+
+hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
+                        uint32_t total_wgs, hipStream_t stream)
+{
+    if (n_entries == 0 || total_wgs == 0)
+        return hipSuccess;
+    void (*k)(const BatchEntry*, const uint32_t*, uint32_t) = nullptr;
+    switch (fmt) {
+    case kBc1: k = inverse ? batch_kernel<kBc1, true> : batch_kernel<kBc1, false>; break;
+    case kBc2: k = inverse ? batch_kernel<kBc2, true> : batch_kernel<kBc2, false>; break;
+    case kBc3: k = inverse ? batch_kernel<kBc3, true> : batch_kernel<kBc3, false>; break;
+    default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries);
+    return hipGetLastError();
 }
 
 hipError_t launch_fill_splitmix64(void* dst, size_t len_bytes, uint64_t seed, uint64_t first_qword,

@@ -52,6 +52,30 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
                                           hipStream_t stream);
 hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint32_t* d_any, hipStream_t stream);
 
+// ---- batch launch: many buffers of one format and direction in one kernel (bcn_kernels.hip, batch_kernel) --------
+// One entry per buffer, sorted by first_wg.  Workgroups [first_wg, first_wg + tile_wgs) run one 256-lane shifted tile
+// each; the workgroups after them (up to the next entry's first_wg) run 256 blocks of the element path each.
+struct BatchEntry {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint64_t blocks;
+    uint32_t first_wg;
+    uint32_t tile_wgs;
+    uint8_t variant, split_alpha, split_colour, reserved;
+    uint8_t shift[6];       // misalignment (mod 16) of every stream base
+    uint8_t reserved2[2];
+};
+static_assert(sizeof(BatchEntry) == 48, "BatchEntry layout is shared between host and device");
+
+// Fills tile_wgs and shift[] of `e` (src, dst, blocks, variant, split_* set by the caller) and returns the number of
+// workgroups the buffer needs (0 for an empty buffer).
+uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e);
+
+// d_entries / d_coarse: device copies of the entry table and of the coarse index (coarse[k] = index of the entry that
+// owns workgroup 64 * k), total_wgs = first_wg + workgroups of the last entry.
+hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
+                        uint32_t total_wgs, hipStream_t stream);
+
 inline int block_bytes(Format f) { return f == kBc1 ? 8 : 16; }
 
 // ------------------------------------------------------------------------------------------------

@@ -129,6 +129,26 @@ int32_t dxtlt_transform_range_device(int32_t format, bool inverse, const void *d
                                      uint8_t decorrelation_mode, bool split_alpha_endpoints,
                                      bool split_colour_endpoints, void *hip_stream);
 
+/* ---- device pointers, many buffers in one call -----------------------------------------------------
+ * Additive (the reference transforms one buffer per call and fans files out over CPU threads): a texture of a few
+ * MiB cannot fill 256 CUs and a launch costs the host longer than such a kernel runs, so a batch is ONE kernel launch
+ * per (format, direction) present in it -- every workgroup looks up the buffer it belongs to (a small table is copied
+ * to the device on `hip_stream` first).  Per-buffer settings, any block counts and alignments.  Asynchronous; ordered
+ * like a single call with respect to `hip_stream`; validated as a whole before anything is enqueued.  Items must not
+ * overlap one another. */
+typedef struct DxtltBatchItem {
+    const void *d_input;
+    void *d_output;
+    uint64_t len;                   /* bytes, a multiple of the block size */
+    uint8_t format;                 /* 1, 2, 3 = BC1, BC2, BC3 */
+    uint8_t inverse;                /* 0 = transform, 1 = untransform */
+    uint8_t decorrelation_mode;     /* core numbering */
+    uint8_t split_alpha_endpoints;  /* BC3 only */
+    uint8_t split_colour_endpoints;
+    uint8_t reserved[3];
+} DxtltBatchItem;
+int32_t dxtlt_transform_batch_device(const DxtltBatchItem *items, size_t count, void *hip_stream);
+
 /* ---- single-process multi-GPU: shard [0, N) by contiguous block range over `num_devices` GPUs -----
  * Host pointers.  Each device receives its slice of the input, runs the range kernel, and its slice of
  * every output stream is copied straight to its final place in `output_ptr` (no collective; see

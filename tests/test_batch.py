@@ -1,0 +1,90 @@
+"""dxtlt_transform_batch_device: many device-resident buffers in one call over a pool of internal streams (additive to
+the reference's one-buffer-per-call API).  Results must equal the oracle item by item and the call must stay ordered
+with the caller's stream on both sides."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+FORMATS = ("bc1", "bc2", "bc3")
+
+
+def settings_for(pkg, fmt, v, sa, sc):
+    if fmt == "bc3":
+        return pkg.Bc3TransformSettings(pkg.YCoCgVariant(v), bool(sa), bool(sc))
+    cls = pkg.Bc1TransformSettings if fmt == "bc1" else pkg.Bc2TransformSettings
+    return cls(pkg.YCoCgVariant(v), bool(sc))
+
+
+@pytest.mark.gpu
+def test_batch_equals_oracle_item_by_item(pkg, oracle):
+    from dxt_lossless_transform_amd import batch
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0xBA7C)
+    items, expect = [], []
+    for k in range(150):
+        fmt = FORMATS[k % 3]
+        blocks = int(rng.choice([0, 1, 3, 255, 256, 1025, 5463, 21845, 65536, 131073]))   # mip-chain-like odd counts too
+        v, sa, sc = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        x = oracle.fill_splitmix64(blocks * pkg.BLOCK_BYTES[fmt], 0xBA7C + k)
+        inverse = bool(k % 2)
+        want = oracle.transform(fmt, x, v, bool(sc), bool(sa), inverse=inverse)
+        xd = torch.from_numpy(x).to(dev)
+        yd = torch.full((x.size + 32,), 0x5A, dtype=torch.uint8, device=dev)
+        items.append((fmt, inverse, xd, yd[: x.size], settings_for(pkg, fmt, v, sa, sc)))
+        expect.append((want, yd, x.size))
+    batch.transform_batch(items)
+    torch.cuda.synchronize()
+    for k, (want, yd, n) in enumerate(expect):
+        got = yd.cpu().numpy()
+        assert np.array_equal(got[:n], want), k
+        assert (got[n:] == 0x5A).all(), k
+    batch.transform_batch([])   # empty batch is a no-op
+
+
+@pytest.mark.gpu
+def test_batch_is_ordered_with_the_callers_stream(pkg, oracle):
+    """The batch reads what earlier work on the stream produced and later work on the stream sees its output, without
+    any synchronisation by the caller."""
+    from dxt_lossless_transform_amd import batch
+
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    st = pkg.Bc1TransformSettings()
+    for _ in range(5):
+        xs = [torch.empty(n * 8, dtype=torch.uint8, device=dev) for _ in range(24)]
+        ys = [torch.empty_like(x) for x in xs]
+        zs = [torch.empty_like(x) for x in xs]
+        for k, x in enumerate(xs):
+            pkg.fill_splitmix64(x, 0x0D0E + k)                               # producer on the current stream
+        batch.transform_batch([("bc1", False, x, y, st) for x, y in zip(xs, ys)])
+        batch.transform_batch([("bc1", True, y, z, st) for y, z in zip(ys, zs)])   # consumes the first batch's output
+        assert all(torch.equal(z, x) for x, z in zip(xs, zs))
+    want = oracle.transform("bc1", xs[3][: 8 * 4096].cpu().numpy(), 1, True)
+    head = torch.cat([ys[3][: 2 * 4096], ys[3][2 * n: 2 * n + 2 * 4096], ys[3][4 * n: 4 * n + 4 * 4096]]).cpu().numpy()
+    assert np.array_equal(head, want)
+
+
+@pytest.mark.gpu
+def test_batch_validation_is_all_or_nothing(pkg):
+    from dxt_lossless_transform_amd.batch import DxtltBatchItem
+
+    l = pkg.load()
+    l.dxtlt_transform_batch_device.argtypes = [C.POINTER(DxtltBatchItem), C.c_size_t, C.c_void_p]
+    l.dxtlt_transform_batch_device.restype = C.c_int32
+    dev = torch.device("cuda:0")
+    x = torch.zeros(64, dtype=torch.uint8, device=dev)
+    y = torch.full((64,), 7, dtype=torch.uint8, device=dev)
+    arr = (DxtltBatchItem * 2)()
+    for it in arr:
+        it.d_input, it.d_output, it.len, it.format, it.decorrelation_mode = x.data_ptr(), y.data_ptr(), 64, 1, 1
+    arr[1].len = 12                                        # second item invalid: nothing may be enqueued
+    assert l.dxtlt_transform_batch_device(arr, 2, None) == 1
+    torch.cuda.synchronize()
+    assert bool((y == 7).all())
+    arr[1].len, arr[1].format = 64, 9
+    assert l.dxtlt_transform_batch_device(arr, 2, None) == 2
+    assert l.dxtlt_transform_batch_device(None, 0, None) == 0
+    assert l.dxtlt_transform_batch_device(None, 1, None) == 2
