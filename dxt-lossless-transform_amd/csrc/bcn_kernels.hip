@@ -36,6 +36,8 @@
 //     element-granular kernel: one lane per block, natural-width or byte accesses.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "bc1_normalize.h"
 #include "bcn_launch.h"
 #include "ycocg_swar.h"
@@ -867,15 +869,48 @@ generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint6
 // Settings are per buffer, so the variant / split combination is a run-time switch over the instantiated bodies;
 // workgroups of one buffer all take the same case.
 // ------------------------------------------------------------------------------------------------
+// A table entry as the workgroup sees it: everything arrives through scalar (dword) loads -- byte fields read one by
+// one would go through the vector memory path and add a second round trip before the tile's own load can start --
+// and the buffer pointers are tagged as global memory again (a pointer that was loaded from memory is a generic one
+// to the compiler, which would turn every access of the tile into a flat_* instruction).
+struct BatchView {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint64_t blocks;
+    uint32_t first_wg, tile_wgs;
+    uint32_t flags;       // variant | split_alpha << 8 | split_colour << 16
+    uint32_t shifts[2];   // shift[0..3], shift[4..5]
+};
+
+__device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
+{
+    typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
+    typedef __attribute__((address_space(1))) uint8_t* global_ptr;
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(entry);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(entry);
+    BatchView v;
+    v.src = (const uint8_t*)(global_cptr)q[0];
+    v.dst = (uint8_t*)(global_ptr)q[1];
+    v.blocks = q[2];
+    v.first_wg = w[6];
+    v.tile_wgs = w[7];
+    v.flags = w[8];
+    v.shifts[0] = w[9];
+    v.shifts[1] = w[10];
+    return v;
+}
+static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, variant) == 32 && offsetof(BatchEntry, shift) == 36,
+              "load_batch_entry reads BatchEntry by dword offsets");
+
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
-__device__ __forceinline__ void batch_unit(const BatchEntry& en, uint32_t local, uint8_t* lds)
+__device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, uint8_t* lds)
 {
     constexpr uint64_t T = tile_blocks(FMT, 256);
     if (local < en.tile_wgs) {
         Shifts sh;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            sh.d[i] = en.shift[i];
+            sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 15u);
         sh.xcd_remap = 0;
         if constexpr (INVERSE)
             inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, local, lds);
@@ -889,16 +924,17 @@ __device__ __forceinline__ void batch_unit(const BatchEntry& en, uint32_t local,
 }
 
 template <int FMT, int VARIANT, bool INVERSE>
-__device__ __forceinline__ void batch_splits(const BatchEntry& en, uint32_t local, uint8_t* lds)
+__device__ __forceinline__ void batch_splits(const BatchView& en, uint32_t local, uint8_t* lds)
 {
+    const bool split_alpha = ((en.flags >> 8) & 0xFF) != 0, split_colour = ((en.flags >> 16) & 0xFF) != 0;
     if constexpr (FMT == kBc3) {
-        if (en.split_alpha) {
-            if (en.split_colour) batch_unit<FMT, VARIANT, true, true, INVERSE>(en, local, lds);
+        if (split_alpha) {
+            if (split_colour) batch_unit<FMT, VARIANT, true, true, INVERSE>(en, local, lds);
             else batch_unit<FMT, VARIANT, true, false, INVERSE>(en, local, lds);
             return;
         }
     }
-    if (en.split_colour) batch_unit<FMT, VARIANT, false, true, INVERSE>(en, local, lds);
+    if (split_colour) batch_unit<FMT, VARIANT, false, true, INVERSE>(en, local, lds);
     else batch_unit<FMT, VARIANT, false, false, INVERSE>(en, local, lds);
 }
 
@@ -912,9 +948,9 @@ batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict_
     uint32_t e = coarse[wg >> 6];
     while (e + 1 < n_entries && entries[e + 1].first_wg <= wg)
         ++e;
-    const BatchEntry en = entries[e];
+    const BatchView en = load_batch_entry(entries + e);
     const uint32_t local = wg - en.first_wg;
-    switch (en.variant) {
+    switch (en.flags & 0xFF) {
     case kNone: batch_splits<FMT, kNone, INVERSE>(en, local, lds); break;
     case kVar1: batch_splits<FMT, kVar1, INVERSE>(en, local, lds); break;
     case kVar2: batch_splits<FMT, kVar2, INVERSE>(en, local, lds); break;
