@@ -101,3 +101,34 @@ def test_stream_table_and_shard_plan(pkg):
     assert all(a + n == b for (a, n), (b, _) in zip(plan, plan[1:]))
     assert all(first % 2048 == 0 for first, _ in plan)
     assert pkg.plan_shards(5, 8)[-1] == (0, 5)
+
+
+@pytest.mark.parametrize("header", sorted(os.path.basename(h) for h in glob.glob(os.path.join(ROOT, "include", "*.h"))))
+def test_public_headers_are_valid_c_and_cxx(header):
+    """Every public C header compiles on its own as C11 and as C++17 (the cbindgen `style = "both"` contract)."""
+    import subprocess
+
+    path = os.path.join(ROOT, "include", header)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c", path])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-fsyntax-only", "-x", "c++", path])
+
+
+def test_new_entry_points_validate_without_a_device(pkg):
+    """Normalisation, batch and BC7 sharding entry points: argument errors and empty inputs need no device."""
+    import ctypes
+
+    l = pkg.load()
+    buf = np.zeros(64, dtype=np.uint8)
+    p = buf.ctypes.data
+    assert l.dxtlt_bc1_normalize_blocks(p, p, 12, 1) == 1
+    assert l.dxtlt_bc1_normalize_blocks(p, p, 16, 7) == 2
+    assert l.dxtlt_bc1_normalize_blocks(p, p, 0, 1) == 0
+    assert l.dxtlt_bc1_normalize_blocks(p, p, 16, 0) == 0          # mode None in place: nothing to do
+    assert l.dxtlt_bc1_normalize_split_blocks_in_place(p, p, 0, 1) == 0
+    assert l.dxtlt_transform_bc1_with_normalize_blocks(p, p, None, 12, 1, 1, True) == 1
+    assert l.dxtlt_transform_bc1_with_normalize_blocks(p, p, None, 16, 3, 1, True) == 2
+    assert l.dxtlt_transform_batch_device(None, 0, None) == 0
+    assert l.dxtlt_transform_batch_device(None, 3, None) == 2
+    l.dxtlt_transform_bc7_sharded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32]
+    assert l.dxtlt_transform_bc7_sharded(p, p, 24, 2) == 1
+    assert l.dxtlt_transform_bc7_sharded(p, p, 0, 2) == 0
