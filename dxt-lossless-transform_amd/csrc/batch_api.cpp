@@ -136,6 +136,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         e.variant = it.decorrelation_mode;
         e.split_alpha = it.format == 3 && it.split_alpha_endpoints ? 1 : 0;
         e.split_colour = it.split_colour_endpoints ? 1 : 0;
+        g.wgs = (g.wgs + 7u) & ~7u;   // first workgroup on XCD 0: the kernel orders each buffer's tiles per XCD
         e.first_wg = g.wgs;
         const uint32_t wgs = dxtlt::plan_batch_entry((dxtlt::Format)it.format, it.inverse != 0, e);
         if ((uint64_t)g.wgs + wgs > 0x7FFFFFFFull)

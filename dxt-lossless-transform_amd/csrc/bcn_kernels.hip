@@ -912,10 +912,13 @@ __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, 
         for (int i = 0; i < 6; ++i)
             sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 15u);
         sh.xcd_remap = 0;
+        // every buffer's first workgroup is a multiple of 8 (the host pads), so local % 8 is the XCD this workgroup
+        // runs on and the XCD-contiguous tile order of the single-buffer shifted kernels applies per buffer
+        const uint64_t tile = xcd_contiguous_tile(local, en.tile_wgs);
         if constexpr (INVERSE)
-            inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+            inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
         else
-            fwd_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+            fwd_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
     } else {
         const uint64_t done = (uint64_t)en.tile_wgs * T;
         generic_block<FMT, VARIANT, SA, SC, INVERSE>(en.src, en.dst, en.blocks, 0, done, en.blocks - done,

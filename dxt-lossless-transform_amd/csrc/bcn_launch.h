@@ -53,8 +53,9 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
 hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint32_t* d_any, hipStream_t stream);
 
 // ---- batch launch: many buffers of one format and direction in one kernel (bcn_kernels.hip, batch_kernel) --------
-// One entry per buffer, sorted by first_wg.  Workgroups [first_wg, first_wg + tile_wgs) run one 256-lane shifted tile
-// each; the workgroups after them (up to the next entry's first_wg) run 256 blocks of the element path each.
+// One entry per buffer, sorted by first_wg (a multiple of 8).  Workgroups [first_wg, first_wg + tile_wgs) run one
+// 256-lane shifted tile each; the workgroups after them (up to the next entry's first_wg) run 256 blocks of the element
+// path each, or nothing once the buffer's blocks are exhausted (padding up to the next multiple of 8).
 struct BatchEntry {
     const uint8_t* src;
     uint8_t* dst;

@@ -15,8 +15,9 @@ from dxt_lossless_transform_amd import batch  # noqa: E402
 dev = torch.device("cuda:0")
 st = pkg.Bc1TransformSettings()
 rows = []
+extra = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # extra blocks per buffer (1 -> odd, mip-chain-like counts)
 for kib, count in ((256, 1024), (1024, 1024), (4096, 512), (16384, 128)):
-    n = kib << 10
+    n = (kib << 10) + 8 * extra
     xs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(count)]
     ys = [torch.empty_like(x) for x in xs]
     for k, x in enumerate(xs):
@@ -55,5 +56,5 @@ for kib, count in ((256, 1024), (1024, 1024), (4096, 512), (16384, 128)):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         res[name] = {"ms": round(dt * 1e3, 3), "GiBps": round(n * count / dt / 2**30, 1), "us_per_item": round(dt / count * 1e6, 2)}
-    rows.append({"KiB": kib, "count": count, **res})
+    rows.append({"KiB": kib, "extra_blocks": extra, "count": count, **res})
 print(json.dumps(rows))
