@@ -52,6 +52,18 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
                                           hipStream_t stream);
 hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint32_t* d_any, hipStream_t stream);
 
+// BC2 / BC3 block normalisation (bc23_normalize.hip; reference bc2/bc3 experimental/normalize_blocks/normalize.rs).
+// fmt 2 or 3; alpha_mode = AlphaNormalizationMode (BC3 only, 0 for BC2), color_mode = ColorNormalizationMode.
+//   all_modes: outs[3] for BC2 (colour modes), outs[12] for BC3 ([alpha_mode * 3 + colour_mode])
+//   split:     the reference's section layout -- BC2 colours / indices (4 + 4 bytes per block; alpha untouched),
+//              BC3 alpha endpoints (2), alpha indices (6), colour endpoints (4), colour indices (4) -- in place
+hipError_t launch_normalize_bc23_blocks(int fmt, const void* in, void* out, uint64_t num_blocks, int alpha_mode, int color_mode,
+                                        hipStream_t stream);
+hipError_t launch_normalize_bc23_all_modes(int fmt, const void* in, void* const* outs, uint64_t num_blocks, hipStream_t stream);
+hipError_t launch_normalize_bc2_split(void* colours, void* indices, uint64_t num_blocks, int color_mode, hipStream_t stream);
+hipError_t launch_normalize_bc3_split(void* alpha_endpoints, void* alpha_indices, void* color_endpoints, void* color_indices,
+                                      uint64_t num_blocks, int alpha_mode, int color_mode, hipStream_t stream);
+
 // ---- batch launch: many buffers of one format and direction in one kernel (bcn_kernels.hip, batch_kernel) --------
 // One entry per buffer, sorted by first_wg (a multiple of 8).  Workgroups [first_wg, first_wg + tile_wgs) run one
 // 256-lane shifted tile each; the workgroups after them (up to the next entry's first_wg) run 256 blocks of the element

@@ -27,6 +27,7 @@
 #include <utility>
 
 #include "dxtlt_bc1_normalize.h"
+#include "dxtlt_bc23_normalize.h"
 #include "dxtlt_gfx950.h"
 
 namespace dxt_lossless_transform {
@@ -314,6 +315,57 @@ std::pair<Bc1TransformDetailsWithNormalization, DetermineBestTransformError> tra
     return {Bc1TransformDetailsWithNormalization{static_cast<ColorNormalizationMode>(norm), static_cast<YCoCgVariant>(mode), sc},
             detail_auto::map(rc)};
 }
+
+// ---- dxt_lossless_transform_bc2 / _bc3 ::experimental::normalize_blocks (normalize.rs of those crates) ----------
+namespace bc2 {
+using ColorNormalizationMode = experimental::ColorNormalizationMode;   // bc2 normalize.rs:339-352
+inline void normalize_blocks(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, ColorNormalizationMode color_mode)
+{
+    detail::check_device(dxtlt_bc2_normalize_blocks(input_ptr, output_ptr, len, static_cast<uint8_t>(color_mode)));
+}
+inline void normalize_blocks_all_modes(const uint8_t* input_ptr, const std::array<uint8_t*, 3>& output_ptrs, size_t len)
+{
+    detail::check_device(dxtlt_bc2_normalize_blocks_all_modes(input_ptr, output_ptrs.data(), len));
+}
+inline void normalize_split_blocks_in_place(const uint8_t* alpha_ptr, uint8_t* colors_ptr, uint8_t* indices_ptr,
+                                            size_t num_blocks, ColorNormalizationMode color_mode)
+{
+    detail::check_device(dxtlt_bc2_normalize_split_blocks_in_place(alpha_ptr, colors_ptr, indices_ptr, num_blocks,
+                                                                   static_cast<uint8_t>(color_mode)));
+}
+}  // namespace bc2
+
+namespace bc3 {
+using ColorNormalizationMode = experimental::ColorNormalizationMode;   // bc3 normalize.rs:143-156
+enum class AlphaNormalizationMode : uint8_t {                           // bc3 normalize.rs:117-139
+    None = 0, UniformAlphaZeroIndices = 1, OpaqueFillAll = 2, OpaqueZeroAlphaMaxIndices = 3
+};
+inline void normalize_blocks(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len, AlphaNormalizationMode alpha_mode,
+                             ColorNormalizationMode color_mode)
+{
+    detail::check_device(dxtlt_bc3_normalize_blocks(input_ptr, output_ptr, len, static_cast<uint8_t>(alpha_mode),
+                                                    static_cast<uint8_t>(color_mode)));
+}
+// output_ptrs[alpha_mode][color_mode], like the reference's 2-D array
+inline void normalize_blocks_all_modes(const uint8_t* input_ptr, const std::array<std::array<uint8_t*, 3>, 4>& output_ptrs,
+                                       size_t len)
+{
+    uint8_t* flat[12];
+    for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 3; ++c)
+            flat[a * 3 + c] = output_ptrs[a][c];
+    detail::check_device(dxtlt_bc3_normalize_blocks_all_modes(input_ptr, flat, len));
+}
+inline void normalize_split_blocks_in_place(uint8_t* alpha_endpoints_ptr, uint8_t* alpha_indices_ptr,
+                                            uint8_t* color_endpoints_ptr, uint8_t* color_indices_ptr, size_t num_blocks,
+                                            AlphaNormalizationMode alpha_mode, ColorNormalizationMode color_mode)
+{
+    detail::check_device(dxtlt_bc3_normalize_split_blocks_in_place(alpha_endpoints_ptr, alpha_indices_ptr, color_endpoints_ptr,
+                                                                   color_indices_ptr, num_blocks,
+                                                                   static_cast<uint8_t>(alpha_mode),
+                                                                   static_cast<uint8_t>(color_mode)));
+}
+}  // namespace bc3
 
 }  // namespace experimental
 

@@ -135,6 +135,26 @@ int oracle_normalize_bc1_blocks_all_modes(const uint8_t *in, uint8_t *out_none, 
 int oracle_transform_bc1_with_normalize_blocks(const uint8_t *in, uint8_t *out, size_t len, int mode, int variant,
                                                int split_colour);                                       /* 0 = ok */
 
+/* BC2 / BC3 block normalisation (dxtlt_oracle_norm.c; PINNED by the unit tests of the reference's bc2/bc3
+ * experimental/normalize_blocks/normalize.rs).  BC3 AlphaNormalizationMode, bc3 normalize.rs:117-139: */
+enum {
+    ORACLE_ALPHA_NONE = 0,
+    ORACLE_ALPHA_UNIFORM_ALPHA_ZERO_INDICES = 1,
+    ORACLE_ALPHA_OPAQUE_FILL_ALL = 2,
+    ORACLE_ALPHA_OPAQUE_ZERO_ALPHA_MAX_INDICES = 3
+};
+void oracle_decode_bc2_block(const uint8_t *src, uint8_t *rgba_out);
+void oracle_decode_bc3_block(const uint8_t *src, uint8_t *rgba_out);
+void oracle_normalize_bc2_blocks(const uint8_t *in, uint8_t *out, size_t len, int color_mode);
+void oracle_normalize_bc2_split_blocks_in_place(const uint8_t *alpha, uint8_t *colors, uint8_t *indices, size_t num_blocks,
+                                                int color_mode);
+void oracle_normalize_bc2_blocks_all_modes(const uint8_t *in, uint8_t *out_none, uint8_t *out_color0, uint8_t *out_replicate,
+                                           size_t len);
+void oracle_normalize_bc3_blocks(const uint8_t *in, uint8_t *out, size_t len, int alpha_mode, int color_mode);
+void oracle_normalize_bc3_split_blocks_in_place(uint8_t *alpha_endpoints, uint8_t *alpha_indices, uint8_t *color_endpoints,
+                                                uint8_t *color_indices, size_t num_blocks, int alpha_mode, int color_mode);
+void oracle_normalize_bc3_blocks_all_modes(const uint8_t *in, uint8_t *const outs[12], size_t len);   /* [alpha * 3 + colour] */
+
 #ifdef __cplusplus
 }
 #endif

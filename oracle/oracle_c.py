@@ -89,6 +89,18 @@ def lib() -> C.CDLL:
         l.oracle_normalize_bc1_blocks_all_modes.restype = i
         l.oracle_transform_bc1_with_normalize_blocks.argtypes = [u8p, u8p, sz, i, i, i]
         l.oracle_transform_bc1_with_normalize_blocks.restype = i
+        l.oracle_decode_bc2_block.argtypes, l.oracle_decode_bc2_block.restype = [u8p, u8p], None
+        l.oracle_decode_bc3_block.argtypes, l.oracle_decode_bc3_block.restype = [u8p, u8p], None
+        l.oracle_normalize_bc2_blocks.argtypes, l.oracle_normalize_bc2_blocks.restype = [u8p, u8p, sz, i], None
+        l.oracle_normalize_bc2_split_blocks_in_place.argtypes = [u8p, u8p, u8p, sz, i]
+        l.oracle_normalize_bc2_split_blocks_in_place.restype = None
+        l.oracle_normalize_bc2_blocks_all_modes.argtypes = [u8p, u8p, u8p, u8p, sz]
+        l.oracle_normalize_bc2_blocks_all_modes.restype = None
+        l.oracle_normalize_bc3_blocks.argtypes, l.oracle_normalize_bc3_blocks.restype = [u8p, u8p, sz, i, i], None
+        l.oracle_normalize_bc3_split_blocks_in_place.argtypes = [u8p, u8p, u8p, u8p, sz, i, i]
+        l.oracle_normalize_bc3_split_blocks_in_place.restype = None
+        l.oracle_normalize_bc3_blocks_all_modes.argtypes = [u8p, C.POINTER(u8p), sz]
+        l.oracle_normalize_bc3_blocks_all_modes.restype = None
         _lib = l
     return _lib
 
@@ -258,3 +270,62 @@ def transform_bc1_with_normalize_blocks(data, mode: int, variant: int = VAR1, sp
                                                           int(split_colour))
     assert rc == 0
     return out
+
+
+# ---- BC2 / BC3 block normalisation (reference experimental modules; dxtlt_oracle_norm.c) ---------------------
+ALPHA_NONE, ALPHA_UNIFORM_ZERO_INDICES, ALPHA_OPAQUE_FILL_ALL, ALPHA_OPAQUE_ZERO_ALPHA_MAX_INDICES = 0, 1, 2, 3
+
+
+def decode_block(fmt: str, block) -> np.ndarray:
+    """16 RGBA8888 pixels, shape (16, 4) (bc1/bc2/bc3 util decoders of the reference)."""
+    a = np.ascontiguousarray(_as_u8(block))
+    assert a.size == BLOCK[fmt]
+    out = np.empty(64, dtype=np.uint8)
+    getattr(lib(), f"oracle_decode_{fmt}_block")(_ptr(a), _ptr(out))
+    return out.reshape(16, 4)
+
+
+def normalize_bc2_blocks(data, color_mode: int) -> np.ndarray:
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % 16 == 0
+    out = np.empty_like(a)
+    lib().oracle_normalize_bc2_blocks(_ptr(a), _ptr(out), a.size, int(color_mode))
+    return out
+
+
+def normalize_bc3_blocks(data, alpha_mode: int, color_mode: int) -> np.ndarray:
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % 16 == 0
+    out = np.empty_like(a)
+    lib().oracle_normalize_bc3_blocks(_ptr(a), _ptr(out), a.size, int(alpha_mode), int(color_mode))
+    return out
+
+
+def normalize_bc2_split_blocks(alpha, colors, indices, color_mode: int):
+    al = np.ascontiguousarray(_as_u8(alpha))
+    c = np.array(_as_u8(colors), dtype=np.uint8, copy=True)
+    x = np.array(_as_u8(indices), dtype=np.uint8, copy=True)
+    lib().oracle_normalize_bc2_split_blocks_in_place(_ptr(al), _ptr(c), _ptr(x), c.size // 4, int(color_mode))
+    return c, x
+
+
+def normalize_bc3_split_blocks(aep, aidx, cep, cidx, alpha_mode: int, color_mode: int):
+    arrs = [np.array(_as_u8(v), dtype=np.uint8, copy=True) for v in (aep, aidx, cep, cidx)]
+    lib().oracle_normalize_bc3_split_blocks_in_place(*[_ptr(v) for v in arrs], arrs[0].size // 2, int(alpha_mode),
+                                                     int(color_mode))
+    return arrs
+
+
+def normalize_bc2_blocks_all_modes(data):
+    a = np.ascontiguousarray(_as_u8(data))
+    outs = [np.empty_like(a) for _ in range(3)]
+    lib().oracle_normalize_bc2_blocks_all_modes(_ptr(a), *[_ptr(o) for o in outs], a.size)
+    return outs
+
+
+def normalize_bc3_blocks_all_modes(data):
+    a = np.ascontiguousarray(_as_u8(data))
+    outs = [np.empty_like(a) for _ in range(12)]
+    ptrs = (C.c_void_p * 12)(*[o.ctypes.data for o in outs])
+    lib().oracle_normalize_bc3_blocks_all_modes(_ptr(a), ptrs, a.size)
+    return outs

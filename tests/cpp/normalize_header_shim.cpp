@@ -6,6 +6,7 @@
 #define __host__
 #define __device__
 #include "../../dxt-lossless-transform_amd/csrc/bc1_normalize.h"
+#include "../../dxt-lossless-transform_amd/csrc/bc23_normalize.h"
 
 extern "C" void shim_normalize_blocks(const uint8_t* in, uint8_t* out, size_t num_blocks, int mode)
 {
@@ -16,5 +17,19 @@ extern "C" void shim_normalize_blocks(const uint8_t* in, uint8_t* out, size_t nu
         dxtlt::normalize_bc1_block_rt(mode, c, x);
         std::memcpy(out + 8 * b, &c, 4);
         std::memcpy(out + 8 * b + 4, &x, 4);
+    }
+}
+
+extern "C" void shim_normalize_bc23_blocks(int fmt, const uint8_t* in, uint8_t* out, size_t num_blocks, int alpha_mode,
+                                           int color_mode)
+{
+    for (size_t b = 0; b < num_blocks; ++b) {
+        uint32_t q[4];
+        std::memcpy(q, in + 16 * b, 16);
+        if (fmt == 2)
+            dxtlt::normalize_block_bc23<2>(alpha_mode, color_mode, q);
+        else
+            dxtlt::normalize_block_bc23<3>(alpha_mode, color_mode, q);
+        std::memcpy(out + 16 * b, q, 16);
     }
 }

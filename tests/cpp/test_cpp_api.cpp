@@ -167,6 +167,26 @@ static void gpu_tests()
     auto rn = ex::transform_bc1_auto_with_normalization(xs.data(), f1.data(), xs.size(), en);
     CHECK(rn.second.is_ok() && en.size_estimator.calls == 12);   // 3 modes x 4 candidates
     CHECK(rn.first == ex::Bc1TransformDetailsWithNormalization(ex::ColorNormalizationMode::None, core::YCoCgVariant::None, false));
+
+    // BC2 / BC3 normalisation: the reference's unit vectors (bc2 / bc3 normalize.rs tests)
+    const uint8_t b2[16] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0xF8, 0x01, 0x01, 0, 0, 0, 0};
+    uint8_t o2[16];
+    ex::bc2::normalize_blocks(b2, o2, 16, ex::bc2::ColorNormalizationMode::ReplicateColor);
+    const uint8_t want2[16] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0xF8, 0x00, 0xF8, 0, 0, 0, 0};
+    CHECK(std::memcmp(o2, want2, 16) == 0);
+    const uint8_t b3[16] = {0xFF, 0xFF, 0, 0, 0, 0, 0, 0, 0x00, 0xF8, 0x12, 0x34, 0, 0, 0, 0};
+    uint8_t o3[16];
+    ex::bc3::normalize_blocks(b3, o3, 16, ex::bc3::AlphaNormalizationMode::OpaqueZeroAlphaMaxIndices,
+                              ex::bc3::ColorNormalizationMode::Color0Only);
+    const uint8_t want3[16] = {0, 0, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x00, 0xF8, 0, 0, 0, 0, 0, 0};
+    CHECK(std::memcmp(o3, want3, 16) == 0);
+    std::vector<std::vector<uint8_t>> outs(12, std::vector<uint8_t>(16));
+    std::array<std::array<uint8_t*, 3>, 4> ptrs{};
+    for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 3; ++c)
+            ptrs[a][c] = outs[a * 3 + c].data();
+    ex::bc3::normalize_blocks_all_modes(b3, ptrs, 16);
+    CHECK(std::memcmp(outs[3 * 3 + 1].data(), want3, 16) == 0 && std::memcmp(outs[0].data(), b3, 16) == 0);
 }
 
 int main(int argc, char** argv)
