@@ -311,7 +311,8 @@ inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t t
 // ------------------------------------------------------------------------------------------------
 struct Shifts {
     int d[6];
-    int xcd_remap;  // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
+    int xcd_remap;    // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
+    int line_policy;  // 1: forward stores of lines written whole by one wave instruction are write-through (sc1 nt)
 };
 
 
@@ -585,11 +586,27 @@ __device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, 
     int s, k, la, shift;
     uint64_t g;
     shifted_segment<FMT, SA, SC, T>(t * 16, total_blocks, blk0, sh, s, k, la, g, shift);
-    if (k == 0 && shift > 0)
+    if (k == 0 && shift > 0) {
         copy_partial_segment<true>(soa + g, lds + la, shift, 16);
-    else  // plain `nt`, not the write-through store: the first/last 128-byte line of a slice is completed by the
-          // neighbouring tile and must stay in L2 until then (with sc1: 0.39-0.50 of peak instead of 0.72-0.76)
-        __builtin_nontemporal_store(lds_at<u32x4>(lds, la), reinterpret_cast<u32x4*>(soa + g));
+    } else {
+        // A 128-byte line that this wave instruction writes completely may use the write-through streaming store of the
+        // aligned kernels.  A line that is completed by another wave or by the neighbouring tile must stay in L2 until
+        // then: plain `nt` (write-through on those: 0.39-0.50 of peak instead of 0.72-0.76).
+        int slice_bytes = 0;
+#pragma unroll
+        for (int ss = 0; ss < S.n; ++ss)
+            if (ss == s)
+                slice_bytes = S.width[ss] * T;
+        const uintptr_t seg = reinterpret_cast<uintptr_t>(soa) + g;
+        const uintptr_t slice_lo = seg + (uintptr_t)shift - (uintptr_t)(16 * k), slice_hi = slice_lo + (uintptr_t)slice_bytes;
+        const uintptr_t line = seg & ~(uintptr_t)127;
+        const int first_lane = t - (int)((seg - line) >> 4);   // lane that writes the line's first segment
+        const bool whole_line = line >= slice_lo && line + 128 <= slice_hi && first_lane >= 0 && (first_lane & 63) <= 56;
+        if (sh.line_policy && whole_line)
+            gstore16(soa + g, lds_at<u32x4>(lds, la));
+        else
+            __builtin_nontemporal_store(lds_at<u32x4>(lds, la), reinterpret_cast<u32x4*>(soa + g));
+    }
     if (t < S.n) {  // the extra, partial last segment of stream t
 #pragma unroll
         for (int ss = 0; ss < S.n; ++ss) {
@@ -912,6 +929,7 @@ __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, 
         for (int i = 0; i < 6; ++i)
             sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 15u);
         sh.xcd_remap = 0;
+        sh.line_policy = 1;
         // every buffer's first workgroup is a multiple of 8 (the host pads), so local % 8 is the XCD this workgroup
         // runs on and the XCD-contiguous tile order of the single-buffer shifted kernels applies per buffer
         const uint64_t tile = xcd_contiguous_tile(local, en.tile_wgs);
@@ -1128,7 +1146,9 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     const int remap_override = tuning ? tuning->xcd_remap : -1;
     sh.xcd_remap = remap_override >= 0 ? remap_override : 1;
     const int aligned_remap = remap_override >= 0 ? remap_override : 0;
-    const int force = tuning ? tuning->force_generic : 0;  // 1 = element kernel, 2 = shifted tiles
+    const int force_bits = tuning ? tuning->force_generic : 0;
+    const int force = force_bits & 3;  // 1 = element kernel, 2 = shifted tiles
+    sh.line_policy = (force_bits & 0x40) ? 0 : 1;  // experiment switch: 0x40 = plain nt stores on every shifted line
     const bool use_tiles = aos_ok && force != 1;
     const bool use_shift = use_tiles && (any_shift || force == 2);
 
