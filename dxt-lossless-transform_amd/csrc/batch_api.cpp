@@ -98,6 +98,8 @@ thread_local TableRing g_ring;
 
 }  // namespace
 
+void dxtlt_host::release_batch_thread_tables() { g_ring.release(); }
+
 extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, size_t count, void* hip_stream)
 {
     if (count == 0)

@@ -81,6 +81,14 @@ int32_t device_call(bool inverse, const void* d_in, void* d_out, size_t len, voi
 
 }  // namespace
 
+void dxtlt_host::release_bc7_thread_scratch()
+{
+    if (g_scratch.ptr) (void)hipFree(g_scratch.ptr);
+    g_scratch.ptr = nullptr;
+    g_scratch.cap = 0;
+    g_scratch.device = -1;
+}
+
 extern "C" {
 
 int32_t dxtlt_transform_bc7(const uint8_t* input_ptr, uint8_t* output_ptr, size_t len)

@@ -580,6 +580,12 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 
 const char* dxtlt_version(void) { return "dxtlt-gfx950 0.1.0"; }
 
-void dxtlt_release_thread_resources(void) { g_host_ctx.release(); }
+void dxtlt_release_thread_resources(void)
+{
+    g_host_ctx.release();
+    dxtlt_host::release_bc7_thread_scratch();
+    dxtlt_host::release_normalize_thread_flag();
+    dxtlt_host::release_batch_thread_tables();
+}
 
 }  // extern "C"

@@ -35,6 +35,11 @@ int32_t acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* st
 int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
                 bool split_alpha, bool split_colour, hipStream_t stream, uint8_t normalize = 0);
 
+// Per-thread device resources of the other translation units, freed by dxtlt_release_thread_resources().
+void release_bc7_thread_scratch();      // bc7_api.cpp
+void release_normalize_thread_flag();   // normalize_api.cpp
+void release_batch_thread_tables();     // batch_api.cpp
+
 struct AutoChoice {
     uint8_t mode;  // core numbering
     bool split_alpha;

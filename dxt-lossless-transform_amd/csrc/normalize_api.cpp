@@ -80,6 +80,13 @@ thread_local FlagWord g_flag;
 
 }  // namespace
 
+void dxtlt_host::release_normalize_thread_flag()
+{
+    if (g_flag.d) (void)hipFree(g_flag.d);
+    g_flag.d = nullptr;
+    g_flag.device = -1;
+}
+
 extern "C" {
 
 int32_t dxtlt_bc1_normalize_blocks_device(const void* d_input, void* d_output, size_t len, uint8_t color_mode,
