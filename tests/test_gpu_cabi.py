@@ -148,3 +148,34 @@ def test_stable_auto_builder(lib, oracle, n):
     r = getattr(lib, p + "AutoTransformBuilder_Transform")(ab, x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(mb))
     assert r.ErrorCode == 4 and mb.value is None  # SizeEstimationFailed, output builder NULL
     getattr(lib, p + "free_AutoTransformBuilder")(ab)
+
+
+@pytest.mark.gpu
+def test_release_thread_resources_between_calls(pkg, oracle):
+    """dxtlt_release_thread_resources frees every per-thread device resource (staging buffers, BC7 scratch,
+    normalisation flag, batch tables); the next call of each family allocates again and still computes the same."""
+    import torch
+
+    from dxt_lossless_transform_amd import batch, bc7, normalize
+
+    l = pkg.load()
+    l.dxtlt_release_thread_resources.argtypes, l.dxtlt_release_thread_resources.restype = [], None
+    x1 = oracle.fill_splitmix64(8 * 5001, 1)
+    x7 = oracle.fill_splitmix64(16 * 3001, 7)
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(x1).to(dev)
+    for _ in range(3):
+        y = np.zeros_like(x1)
+        pkg.transform_bc1_with_settings(x1, y)
+        assert np.array_equal(y, oracle.transform("bc1", x1, 1, True))
+        y7 = np.zeros_like(x7)
+        bc7.transform_bc7(x7, y7)
+        assert np.array_equal(y7, oracle.transform_bc7(x7))
+        outs = [np.zeros_like(x1) for _ in range(3)]
+        normalize.normalize_blocks_all_modes(x1, outs)
+        assert np.array_equal(outs[1], oracle.normalize_bc1_blocks(x1, 1))
+        yd = torch.empty_like(xd)
+        batch.transform_batch([("bc1", False, xd, yd, pkg.Bc1TransformSettings())] * 2)
+        assert np.array_equal(yd.cpu().numpy(), oracle.transform("bc1", x1, 1, True))
+        torch.cuda.synchronize()
+        l.dxtlt_release_thread_resources()
