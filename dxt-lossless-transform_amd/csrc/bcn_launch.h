@@ -52,6 +52,13 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
                                           hipStream_t stream);
 hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint32_t* d_any, hipStream_t stream);
 
+// Array-level colour operations of the reference's common crate (color565_ops.hip): YCoCg-R over `num_items` RGB565
+// colours (in == out allowed), recorrelation with interleave of two half arrays, and the (c0, c1) endpoint split.
+hipError_t launch_color565_ycocg(bool inverse, const void* in, void* out, uint64_t num_items, int variant, hipStream_t stream);
+hipError_t launch_color565_recorrelate_split(const void* src0, const void* src1, void* dst, uint64_t num_items, int variant,
+                                             hipStream_t stream);
+hipError_t launch_split_565_color_endpoints(const void* in, void* out, uint64_t len_bytes, hipStream_t stream);
+
 // BC2 / BC3 block normalisation (bc23_normalize.hip; reference bc2/bc3 experimental/normalize_blocks/normalize.rs).
 // fmt 2 or 3; alpha_mode = AlphaNormalizationMode (BC3 only, 0 for BC2), color_mode = ColorNormalizationMode.
 //   all_modes: outs[3] for BC2 (colour modes), outs[12] for BC3 ([alpha_mode * 3 + colour_mode])
