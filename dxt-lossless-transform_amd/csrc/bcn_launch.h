@@ -52,6 +52,12 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
                                           hipStream_t stream);
 hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint32_t* d_any, hipStream_t stream);
 
+// bcn_decode.hip: fmt = 1, 2, 3.  `out` = num_blocks * 64 bytes (sixteen r, g, b, a per block, row-major);
+// `d_count` = one device uint64_t, zeroed by the call
+hipError_t launch_decode_blocks(int fmt, const void* in, void* out, uint64_t num_blocks, hipStream_t stream);
+hipError_t launch_count_pixel_differences(int fmt, const void* a, const void* b, uint64_t num_blocks, uint64_t* d_count,
+                                          hipStream_t stream);
+
 // Array-level colour operations of the reference's common crate (color565_ops.hip): YCoCg-R over `num_items` RGB565
 // colours (in == out allowed), recorrelation with interleave of two half arrays, and the (c0, c1) endpoint split.
 hipError_t launch_color565_ycocg(bool inverse, const void* in, void* out, uint64_t num_items, int variant, hipStream_t stream);

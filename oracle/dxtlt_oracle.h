@@ -145,6 +145,9 @@ enum {
 };
 void oracle_decode_bc2_block(const uint8_t *src, uint8_t *rgba_out);
 void oracle_decode_bc3_block(const uint8_t *src, uint8_t *rgba_out);
+/* array forms: kind = 1, 2, 3; 64 bytes of pixels per block */
+void oracle_decode_blocks(int kind, const uint8_t *in, uint8_t *rgba_out, size_t num_blocks);
+uint64_t oracle_count_pixel_differences(int kind, const uint8_t *a, const uint8_t *b, size_t num_blocks);
 void oracle_normalize_bc2_blocks(const uint8_t *in, uint8_t *out, size_t len, int color_mode);
 void oracle_normalize_bc2_split_blocks_in_place(const uint8_t *alpha, uint8_t *colors, uint8_t *indices, size_t num_blocks,
                                                 int color_mode);

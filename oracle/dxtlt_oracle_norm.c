@@ -382,3 +382,37 @@ void oracle_normalize_bc3_blocks_all_modes(const uint8_t *in, uint8_t *const out
         for (int c = 0; c < 3; ++c)
             oracle_normalize_bc3_blocks(in, outs[a * 3 + c], len, a, c);
 }
+
+/* =====================================================================================================
+ * Array form of the block decoders above (the reference decodes one block per call: bc1_decode.rs:42,
+ * bc2_decode.rs:44, bc3_decode.rs:43): `num_blocks` blocks -> num_blocks * 64 bytes, one Decoded4x4Block
+ * (decoded_4x4_block.rs:56: sixteen {r, g, b, a}, row-major) per block.  kind = 1, 2, 3.
+ * Pin status: PINNED by the reference's decoder unit tests (tests/test_decode.py replays them).
+ * ===================================================================================================== */
+void oracle_decode_blocks(int kind, const uint8_t *in, uint8_t *rgba_out, size_t num_blocks)
+{
+    const size_t bs = kind == 1 ? 8 : 16;
+    for (size_t i = 0; i < num_blocks; ++i) {
+        if (kind == 1)
+            oracle_decode_bc1_block(in + bs * i, rgba_out + 64 * i);
+        else if (kind == 2)
+            oracle_decode_bc2_block(in + bs * i, rgba_out + 64 * i);
+        else
+            oracle_decode_bc3_block(in + bs * i, rgba_out + 64 * i);
+    }
+}
+
+/* number of blocks whose sixteen decoded pixels differ between the two arrays (what the reference's normalisation
+ * tests assert to be zero, e.g. bc1 normalize.rs tests: decode before == decode after) */
+uint64_t oracle_count_pixel_differences(int kind, const uint8_t *a, const uint8_t *b, size_t num_blocks)
+{
+    const size_t bs = kind == 1 ? 8 : 16;
+    uint64_t n = 0;
+    for (size_t i = 0; i < num_blocks; ++i) {
+        uint8_t pa[64], pb[64];
+        oracle_decode_blocks(kind, a + bs * i, pa, 1);
+        oracle_decode_blocks(kind, b + bs * i, pb, 1);
+        n += memcmp(pa, pb, 64) != 0;
+    }
+    return n;
+}

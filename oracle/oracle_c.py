@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
         l.oracle_transform_bc1_with_normalize_blocks.restype = i
         l.oracle_decode_bc2_block.argtypes, l.oracle_decode_bc2_block.restype = [u8p, u8p], None
         l.oracle_decode_bc3_block.argtypes, l.oracle_decode_bc3_block.restype = [u8p, u8p], None
+        l.oracle_decode_blocks.argtypes, l.oracle_decode_blocks.restype = [C.c_int, u8p, u8p, C.c_size_t], None
+        l.oracle_count_pixel_differences.argtypes = [C.c_int, u8p, u8p, C.c_size_t]
+        l.oracle_count_pixel_differences.restype = C.c_uint64
         l.oracle_normalize_bc2_blocks.argtypes, l.oracle_normalize_bc2_blocks.restype = [u8p, u8p, sz, i], None
         l.oracle_normalize_bc2_split_blocks_in_place.argtypes = [u8p, u8p, u8p, sz, i]
         l.oracle_normalize_bc2_split_blocks_in_place.restype = None
@@ -329,3 +332,19 @@ def normalize_bc3_blocks_all_modes(data):
     ptrs = (C.c_void_p * 12)(*[o.ctypes.data for o in outs])
     lib().oracle_normalize_bc3_blocks_all_modes(_ptr(a), ptrs, a.size)
     return outs
+
+
+# ---- array decoders (dxtlt_oracle_norm.c) -------------------------------------------------------------------
+def decode_blocks(fmt: str, data) -> np.ndarray:
+    """One Decoded4x4Block (64 bytes: sixteen r, g, b, a, row-major) per block."""
+    a = np.ascontiguousarray(_as_u8(data))
+    assert a.size % BLOCK[fmt] == 0
+    out = np.empty(a.size // BLOCK[fmt] * 64, dtype=np.uint8)
+    lib().oracle_decode_blocks({"bc1": 1, "bc2": 2, "bc3": 3}[fmt], _ptr(a), _ptr(out), a.size // BLOCK[fmt])
+    return out
+
+
+def count_pixel_differences(fmt: str, a, b) -> int:
+    x, y = np.ascontiguousarray(_as_u8(a)), np.ascontiguousarray(_as_u8(b))
+    assert x.size == y.size and x.size % BLOCK[fmt] == 0
+    return int(lib().oracle_count_pixel_differences({"bc1": 1, "bc2": 2, "bc3": 3}[fmt], _ptr(x), _ptr(y), x.size // BLOCK[fmt]))
