@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Many small device-resident BC1 textures: one call per texture on one stream vs dxtlt_transform_batch_device.
+"""Many small device-resident BC1 textures: one call per texture on one stream, the same calls replayed from a HIP
+graph, and dxtlt_transform_batch_device.
 GiB/s of blocks transformed (forward only), Python call overhead included in both."""
 import json
 import os
@@ -46,8 +47,13 @@ for kib, count in ((256, 1024), (1024, 1024), (4096, 512), (16384, 128)):
     def batched_c():
         assert lib.dxtlt_transform_batch_device(arr, count, stream) == 0
 
+    # the same per-texture calls captured once into a HIP graph and replayed (fixed buffers: the per-frame case)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sequential()
+
     res = {}
-    for name, fn in (("sequential", sequential), ("batched", batched), ("batched_c_call", batched_c)):
+    for name, fn in (("sequential", sequential), ("graph_replay", graph.replay), ("batched", batched), ("batched_c_call", batched_c)):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
