@@ -28,6 +28,8 @@
 
 #include "dxtlt_bc1_normalize.h"
 #include "dxtlt_bc23_normalize.h"
+#include "dxtlt_color565.h"
+#include "dxtlt_decode.h"
 #include "dxtlt_gfx950.h"
 
 namespace dxt_lossless_transform {
@@ -368,6 +370,77 @@ inline void normalize_split_blocks_in_place(uint8_t* alpha_endpoints_ptr, uint8_
 }  // namespace bc3
 
 }  // namespace experimental
+
+// dxt_lossless_transform_common: array-level RGB565 operations (color_565/decorrelate_batch_ptr.rs:336,378,
+// decorrelate_batch_split_ptr.rs:324, transforms/split_565_color_endpoints/mod.rs:110)
+namespace common {
+struct Color565 {
+    static void decorrelate_ycocg_r_ptr(const uint16_t* src_ptr, uint16_t* dst_ptr, size_t num_items, YCoCgVariant variant)
+    {
+        detail::check_device(dxtlt_color565_decorrelate_ycocg_r(src_ptr, dst_ptr, num_items, static_cast<uint8_t>(variant)));
+    }
+    static void recorrelate_ycocg_r_ptr(const uint16_t* src_ptr, uint16_t* dst_ptr, size_t num_items, YCoCgVariant variant)
+    {
+        detail::check_device(dxtlt_color565_recorrelate_ycocg_r(src_ptr, dst_ptr, num_items, static_cast<uint8_t>(variant)));
+    }
+    static void recorrelate_ycocg_r_ptr_split(const uint16_t* src_ptr_0, const uint16_t* src_ptr_1, uint16_t* dst_ptr,
+                                              size_t num_items, YCoCgVariant variant)
+    {
+        detail::check_device(
+            dxtlt_color565_recorrelate_ycocg_r_split(src_ptr_0, src_ptr_1, dst_ptr, num_items, static_cast<uint8_t>(variant)));
+    }
+};
+inline void split_color_endpoints(const uint16_t* colors, uint16_t* colors_out, size_t colors_len_bytes)
+{
+    detail::check_device(dxtlt_split_565_color_endpoints(colors, colors_out, colors_len_bytes));
+}
+}  // namespace common
+
+// util modules of the three crates (bc1_decode.rs:42, bc2_decode.rs:44, bc3_decode.rs:43) as array operations
+namespace util {
+struct Color8888 {
+    uint8_t r, g, b, a;   // color_8888.rs:30
+    bool operator==(const Color8888& o) const { return r == o.r && g == o.g && b == o.b && a == o.a; }
+};
+struct Decoded4x4Block {
+    Color8888 pixels[16];   // row-major (decoded_4x4_block.rs:56)
+    Color8888 get_pixel_unchecked(size_t x, size_t y) const { return pixels[y * 4 + x]; }
+    bool has_identical_pixels() const   // decoded_4x4_block.rs:105
+    {
+        for (int i = 1; i < 16; ++i)
+            if (!(pixels[i] == pixels[0]))
+                return false;
+        return true;
+    }
+};
+static_assert(sizeof(Decoded4x4Block) == DXTLT_DECODED_BLOCK_BYTES, "Decoded4x4Block is sixteen 4-byte pixels");
+
+// `num_blocks` blocks at `src` -> `dst[0 .. num_blocks)`
+inline void decode_bc1_blocks(const uint8_t* src, Decoded4x4Block* dst, size_t num_blocks)
+{
+    detail::check_device(dxtlt_decode_bc1_blocks(src, num_blocks * 8, reinterpret_cast<uint8_t*>(dst), num_blocks * sizeof(Decoded4x4Block)));
+}
+inline void decode_bc2_blocks(const uint8_t* src, Decoded4x4Block* dst, size_t num_blocks)
+{
+    detail::check_device(dxtlt_decode_bc2_blocks(src, num_blocks * 16, reinterpret_cast<uint8_t*>(dst), num_blocks * sizeof(Decoded4x4Block)));
+}
+inline void decode_bc3_blocks(const uint8_t* src, Decoded4x4Block* dst, size_t num_blocks)
+{
+    detail::check_device(dxtlt_decode_bc3_blocks(src, num_blocks * 16, reinterpret_cast<uint8_t*>(dst), num_blocks * sizeof(Decoded4x4Block)));
+}
+// the one-block forms of the reference, for drop-in use (a PCIe round trip each: batch where you can)
+inline Decoded4x4Block decode_bc1_block(const uint8_t* src) { Decoded4x4Block d; decode_bc1_blocks(src, &d, 1); return d; }
+inline Decoded4x4Block decode_bc2_block(const uint8_t* src) { Decoded4x4Block d; decode_bc2_blocks(src, &d, 1); return d; }
+inline Decoded4x4Block decode_bc3_block(const uint8_t* src) { Decoded4x4Block d; decode_bc3_blocks(src, &d, 1); return d; }
+
+// blocks whose decoded pixels differ between two arrays; format = 1, 2, 3
+inline uint64_t count_pixel_differences(int32_t format, const uint8_t* a, const uint8_t* b, size_t len)
+{
+    uint64_t n = 0;
+    detail::check_device(dxtlt_count_pixel_differences(format, a, b, len, &n));
+    return n;
+}
+}  // namespace util
 
 }  // namespace core
 

@@ -187,6 +187,45 @@ static void gpu_tests()
             ptrs[a][c] = outs[a * 3 + c].data();
     ex::bc3::normalize_blocks_all_modes(b3, ptrs, 16);
     CHECK(std::memcmp(outs[3 * 3 + 1].data(), want3, 16) == 0 && std::memcmp(outs[0].data(), b3, 16) == 0);
+
+    // common crate: colour arrays (SURVEY.md 8(c) hand-derived vector 0xF800 -> 0xBFD1 / 0x5FF1 / 0xBFE2)
+    {
+        using core::common::Color565;
+        const uint16_t cols[4] = {0xF800, 0x07E0, 0x001F, 0xFFFF};
+        uint16_t dec[4], rec[4];
+        Color565::decorrelate_ycocg_r_ptr(cols, dec, 4, core::YCoCgVariant::Variant1);
+        CHECK(dec[0] == 0xBFD1 && dec[1] == 0x783F && dec[2] == 0xF841 && dec[3] == 0xF820);
+        Color565::recorrelate_ycocg_r_ptr(dec, rec, 4, core::YCoCgVariant::Variant1);
+        CHECK(std::memcmp(rec, cols, 8) == 0);
+        const uint16_t pairs[6] = {0x0100, 0x0302, 0x0504, 0x0706, 0x0908, 0x0B0A};
+        uint16_t split[6], joined[6];
+        core::common::split_color_endpoints(pairs, split, 12);
+        const uint16_t want_split[6] = {0x0100, 0x0504, 0x0908, 0x0302, 0x0706, 0x0B0A};
+        CHECK(std::memcmp(split, want_split, 12) == 0);
+        Color565::recorrelate_ycocg_r_ptr_split(split, split + 3, joined, 6, core::YCoCgVariant::None);
+        CHECK(std::memcmp(joined, pairs, 12) == 0);
+    }
+    // util: decoders (bc1_decode.rs / bc3_decode.rs unit vectors)
+    {
+        namespace ut = core::util;
+        const uint8_t red[8] = {0x00, 0xF8, 0x00, 0xF8, 0, 0, 0, 0};
+        const ut::Decoded4x4Block d = ut::decode_bc1_block(red);
+        CHECK(d.has_identical_pixels() && d.get_pixel_unchecked(2, 3) == (ut::Color8888{255, 0, 0, 255}));
+        const uint8_t bc3_block[16] = {0, 0, 0, 255, 255, 255, 255, 255, 255, 255, 18, 0, 0, 0, 0, 250};
+        const ut::Decoded4x4Block e = ut::decode_bc3_block(bc3_block);
+        CHECK(e.pixels[0] == (ut::Color8888{255, 255, 255, 0}) && e.pixels[3] == (ut::Color8888{255, 255, 255, 255}));
+        CHECK(e.pixels[12] == (ut::Color8888{170, 170, 219, 255}) && e.pixels[15] == (ut::Color8888{85, 85, 183, 255}));
+        std::vector<uint8_t> blocks = gen_bc1(1000), other = blocks;
+        other[8 * 17 + 4] ^= 0x03;   // one index of block 17
+        std::vector<ut::Decoded4x4Block> px(1000), px2(1000);
+        ut::decode_bc1_blocks(blocks.data(), px.data(), 1000);
+        ut::decode_bc1_blocks(other.data(), px2.data(), 1000);
+        size_t differing = 0;
+        for (size_t i = 0; i < 1000; ++i)
+            differing += std::memcmp(&px[i], &px2[i], sizeof px[i]) != 0;
+        CHECK(ut::count_pixel_differences(1, blocks.data(), other.data(), blocks.size()) == differing);
+        CHECK(ut::count_pixel_differences(1, blocks.data(), blocks.data(), blocks.size()) == 0);
+    }
 }
 
 int main(int argc, char** argv)
