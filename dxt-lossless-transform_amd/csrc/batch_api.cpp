@@ -130,6 +130,8 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         const DxtltBatchItem& it = items[i];
         if (it.len == 0)
             continue;
+        if (it.len >= (size_t(64) << 30))
+            return fail(kInvalidArgument, "batch item of 64 GiB or more: use the single-buffer entry point");
         Group& g = groups[(it.format - 1) * 2 + (it.inverse ? 1 : 0)];
         BatchEntry e{};
         e.src = static_cast<const uint8_t*>(it.d_input);
@@ -141,8 +143,9 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         g.wgs = (g.wgs + 7u) & ~7u;   // first workgroup on XCD 0: the kernel orders each buffer's tiles per XCD
         e.first_wg = g.wgs;
         const uint32_t wgs = dxtlt::plan_batch_entry((dxtlt::Format)it.format, it.inverse != 0, e);
-        if ((uint64_t)g.wgs + wgs > 0x7FFFFFFFull)
-            return fail(kInvalidArgument, "batch too large for one launch (more than 2^31 workgroups of one format)");
+        // one launch holds fewer than 2^32 threads = 2^24 workgroups of 256 (64 GiB of blocks per format and direction)
+        if ((uint64_t)g.wgs + wgs > 0xFFFFFFull)
+            return fail(kInvalidArgument, "batch too large for one launch (64 GiB or more of one format and direction)");
         g.wgs += wgs;
         g.entries.push_back(e);
     }

@@ -11,6 +11,7 @@
 
 #include "bc1_normalize.h"
 #include "bcn_launch.h"
+#include "launch_grid.h"
 
 namespace dxtlt {
 namespace {
@@ -53,7 +54,7 @@ __device__ __forceinline__ void flag_if_any(bool changed, uint32_t* d_any)
 __global__ void __launch_bounds__(kNormThreads)
 normalize_blocks_kernel(const uint8_t* in, uint8_t* out, uint64_t pairs, uint64_t singles, int mode)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kNormThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kNormThreads + threadIdx.x;
     if (i < pairs) {
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + 16 * i));
         uint32_t ca = q.x, xa = q.y, cb = q.z, xb = q.w;
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(kNormThreads)
 normalize_all_modes_kernel(const uint8_t* in, uint8_t* out0, uint8_t* out1, uint8_t* out2, uint64_t pairs, uint64_t singles,
                            uint32_t* d_any)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kNormThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kNormThreads + threadIdx.x;
     bool changed = false;
     if (i < pairs) {
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + 16 * i));
@@ -115,7 +116,7 @@ normalize_all_modes_kernel(const uint8_t* in, uint8_t* out0, uint8_t* out1, uint
 __global__ void __launch_bounds__(kNormThreads)
 any_normalizable_kernel(const uint8_t* in, uint64_t pairs, uint64_t singles, uint32_t* d_any)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kNormThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kNormThreads + threadIdx.x;
     bool changed = false;
     uint32_t s = 0;
     if (i < pairs) {
@@ -134,7 +135,7 @@ any_normalizable_kernel(const uint8_t* in, uint64_t pairs, uint64_t singles, uin
 __global__ void __launch_bounds__(kNormThreads)
 normalize_split_kernel(uint8_t* colours, uint8_t* indices, uint64_t quads, uint64_t singles, int mode)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kNormThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kNormThreads + threadIdx.x;
     if (i < quads) {
         const u32x4 cv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(colours + 16 * i));
         const u32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(indices + 16 * i));
@@ -160,14 +161,7 @@ normalize_split_kernel(uint8_t* colours, uint8_t* indices, uint64_t quads, uint6
 
 inline bool host_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-inline hipError_t grid_for(uint64_t lanes, unsigned& grid)
-{
-    const uint64_t g = (lanes + kNormThreads - 1) / kNormThreads;
-    if (g > 0x7FFFFFFFull)
-        return hipErrorInvalidValue;
-    grid = (unsigned)g;
-    return hipSuccess;
-}
+inline hipError_t grid_for(uint64_t lanes, dim3& grid) { return grid_rows(lanes, kNormThreads, grid); }
 
 }  // namespace
 
@@ -181,10 +175,10 @@ hipError_t launch_normalize_bc1_blocks(const void* in, void* out, uint64_t num_b
         return in == out ? hipSuccess : hipMemcpyAsync(out, in, num_blocks * 8, hipMemcpyDeviceToDevice, stream);
     const bool vec = host_aligned16(in) && host_aligned16(out);
     const uint64_t pairs = vec ? num_blocks / 2 : 0, singles = num_blocks - 2 * pairs;
-    unsigned grid = 0;
+    dim3 grid;
     if (hipError_t e = grid_for(pairs + singles, grid); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(normalize_blocks_kernel, dim3(grid), dim3(kNormThreads), 0, stream, static_cast<const uint8_t*>(in),
+    hipLaunchKernelGGL(normalize_blocks_kernel, grid, dim3(kNormThreads), 0, stream, static_cast<const uint8_t*>(in),
                        static_cast<uint8_t*>(out), pairs, singles, mode);
     return hipGetLastError();
 }
@@ -197,10 +191,10 @@ hipError_t launch_normalize_bc1_split(void* colours, void* indices, uint64_t num
         return hipSuccess;
     const bool vec = host_aligned16(colours) && host_aligned16(indices);
     const uint64_t quads = vec ? num_blocks / 4 : 0, singles = num_blocks - 4 * quads;
-    unsigned grid = 0;
+    dim3 grid;
     if (hipError_t e = grid_for(quads + singles, grid); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(normalize_split_kernel, dim3(grid), dim3(kNormThreads), 0, stream, static_cast<uint8_t*>(colours),
+    hipLaunchKernelGGL(normalize_split_kernel, grid, dim3(kNormThreads), 0, stream, static_cast<uint8_t*>(colours),
                        static_cast<uint8_t*>(indices), quads, singles, mode);
     return hipGetLastError();
 }
@@ -212,10 +206,10 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
         return hipSuccess;
     const bool vec = host_aligned16(in) && host_aligned16(out[0]) && host_aligned16(out[1]) && host_aligned16(out[2]);
     const uint64_t pairs = vec ? num_blocks / 2 : 0, singles = num_blocks - 2 * pairs;
-    unsigned grid = 0;
+    dim3 grid;
     if (hipError_t e = grid_for(pairs + singles, grid); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(normalize_all_modes_kernel, dim3(grid), dim3(kNormThreads), 0, stream,
+    hipLaunchKernelGGL(normalize_all_modes_kernel, grid, dim3(kNormThreads), 0, stream,
                        static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out[0]), static_cast<uint8_t*>(out[1]),
                        static_cast<uint8_t*>(out[2]), pairs, singles, d_any);
     return hipGetLastError();
@@ -227,10 +221,10 @@ hipError_t launch_bc1_any_normalizable(const void* in, uint64_t num_blocks, uint
         return hipSuccess;
     const bool vec = host_aligned16(in);
     const uint64_t pairs = vec ? num_blocks / 2 : 0, singles = num_blocks - 2 * pairs;
-    unsigned grid = 0;
+    dim3 grid;
     if (hipError_t e = grid_for(pairs + singles, grid); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(any_normalizable_kernel, dim3(grid), dim3(kNormThreads), 0, stream, static_cast<const uint8_t*>(in),
+    hipLaunchKernelGGL(any_normalizable_kernel, grid, dim3(kNormThreads), 0, stream, static_cast<const uint8_t*>(in),
                        pairs, singles, d_any);
     return hipGetLastError();
 }

@@ -8,6 +8,7 @@
 
 #include "bc23_normalize.h"
 #include "bcn_launch.h"
+#include "launch_grid.h"
 
 namespace dxtlt {
 namespace {
@@ -64,7 +65,7 @@ template <int FMT>
 __global__ void __launch_bounds__(kThreads23)
 normalize23_kernel(const uint8_t* in, uint8_t* out, uint64_t n, int alpha_mode, int color_mode, int vec)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads23 + threadIdx.x;
+    const uint64_t i = workgroup_index() * kThreads23 + threadIdx.x;
     if (i >= n)
         return;
     uint32_t q[4];
@@ -82,7 +83,7 @@ template <int FMT>
 __global__ void __launch_bounds__(kThreads23)
 normalize23_all_modes_kernel(const uint8_t* in, OutPtrs outs, uint64_t n, int vec)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads23 + threadIdx.x;
+    const uint64_t i = workgroup_index() * kThreads23 + threadIdx.x;
     if (i >= n)
         return;
     uint32_t q[4];
@@ -119,7 +120,7 @@ normalize23_all_modes_kernel(const uint8_t* in, OutPtrs outs, uint64_t n, int ve
 __global__ void __launch_bounds__(kThreads23)
 normalize2_split_kernel(uint8_t* colours, uint8_t* indices, uint64_t n, int color_mode)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads23 + threadIdx.x;
+    const uint64_t i = workgroup_index() * kThreads23 + threadIdx.x;
     if (i >= n)
         return;
     const bool a4 = ((reinterpret_cast<uintptr_t>(colours) | reinterpret_cast<uintptr_t>(indices)) & 3) == 0;
@@ -134,7 +135,7 @@ normalize2_split_kernel(uint8_t* colours, uint8_t* indices, uint64_t n, int colo
 __global__ void __launch_bounds__(kThreads23)
 normalize3_split_kernel(uint8_t* aep, uint8_t* aidx, uint8_t* cep, uint8_t* cidx, uint64_t n, int alpha_mode, int color_mode)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads23 + threadIdx.x;
+    const uint64_t i = workgroup_index() * kThreads23 + threadIdx.x;
     if (i >= n)
         return;
     const bool c4 = ((reinterpret_cast<uintptr_t>(cep) | reinterpret_cast<uintptr_t>(cidx)) & 3) == 0;
@@ -161,14 +162,7 @@ normalize3_split_kernel(uint8_t* aep, uint8_t* aidx, uint8_t* cep, uint8_t* cidx
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-inline hipError_t grid23(uint64_t n, unsigned& g)
-{
-    const uint64_t v = (n + kThreads23 - 1) / kThreads23;
-    if (v > 0x7FFFFFFFull)
-        return hipErrorInvalidValue;
-    g = (unsigned)v;
-    return hipSuccess;
-}
+inline hipError_t grid23(uint64_t n, dim3& g) { return grid_rows(n, kThreads23, g); }
 
 }  // namespace
 
@@ -182,12 +176,12 @@ hipError_t launch_normalize_bc23_blocks(int fmt, const void* in, void* out, uint
         return hipSuccess;
     if (alpha_mode == kAlphaNone && color_mode == kNormNone)   // bc2 normalize.rs:50-61, bc3 normalize.rs:52-62
         return in == out ? hipSuccess : hipMemcpyAsync(out, in, num_blocks * 16, hipMemcpyDeviceToDevice, stream);
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = grid23(num_blocks, g); e != hipSuccess)
         return e;
     const int vec = al16(in) && al16(out);
     auto k = fmt == 2 ? normalize23_kernel<2> : normalize23_kernel<3>;
-    hipLaunchKernelGGL(k, dim3(g), dim3(kThreads23), 0, stream, static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out),
+    hipLaunchKernelGGL(k, g, dim3(kThreads23), 0, stream, static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out),
                        num_blocks, alpha_mode, color_mode, vec);
     return hipGetLastError();
 }
@@ -205,11 +199,11 @@ hipError_t launch_normalize_bc23_all_modes(int fmt, const void* in, void* const*
         o.p[i] = static_cast<uint8_t*>(outs[i]);
         vec = vec && al16(outs[i]);
     }
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = grid23(num_blocks, g); e != hipSuccess)
         return e;
     auto k = fmt == 2 ? normalize23_all_modes_kernel<2> : normalize23_all_modes_kernel<3>;
-    hipLaunchKernelGGL(k, dim3(g), dim3(kThreads23), 0, stream, static_cast<const uint8_t*>(in), o, num_blocks, vec);
+    hipLaunchKernelGGL(k, g, dim3(kThreads23), 0, stream, static_cast<const uint8_t*>(in), o, num_blocks, vec);
     return hipGetLastError();
 }
 
@@ -219,10 +213,10 @@ hipError_t launch_normalize_bc2_split(void* colours, void* indices, uint64_t num
         return hipErrorInvalidValue;
     if (num_blocks == 0 || color_mode == kNormNone)
         return hipSuccess;
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = grid23(num_blocks, g); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(normalize2_split_kernel, dim3(g), dim3(kThreads23), 0, stream, static_cast<uint8_t*>(colours),
+    hipLaunchKernelGGL(normalize2_split_kernel, g, dim3(kThreads23), 0, stream, static_cast<uint8_t*>(colours),
                        static_cast<uint8_t*>(indices), num_blocks, color_mode);
     return hipGetLastError();
 }
@@ -234,10 +228,10 @@ hipError_t launch_normalize_bc3_split(void* alpha_endpoints, void* alpha_indices
         return hipErrorInvalidValue;
     if (num_blocks == 0 || (alpha_mode == kAlphaNone && color_mode == kNormNone))
         return hipSuccess;
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = grid23(num_blocks, g); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(normalize3_split_kernel, dim3(g), dim3(kThreads23), 0, stream, static_cast<uint8_t*>(alpha_endpoints),
+    hipLaunchKernelGGL(normalize3_split_kernel, g, dim3(kThreads23), 0, stream, static_cast<uint8_t*>(alpha_endpoints),
                        static_cast<uint8_t*>(alpha_indices), static_cast<uint8_t*>(color_endpoints),
                        static_cast<uint8_t*>(color_indices), num_blocks, alpha_mode, color_mode);
     return hipGetLastError();

@@ -663,7 +663,7 @@ hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, v
     if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
         return hipErrorInvalidValue;  // BC7 v0 takes 16-byte aligned device buffers only
     const uint64_t tiles = tiles_for(n_blocks), groups = groups_for(tiles);
-    if (tiles > 0x7FFFFFFFull || groups > 65535ull * 1024)
+    if (tiles * kThreads > 0xFFFFFFFFull || groups > 65535ull * 1024)   // a launch holds fewer than 2^32 threads: 256 GiB of blocks
         return hipErrorInvalidValue;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     uint64_t* totals = reinterpret_cast<uint64_t*>(ws);                    // 9 x u64: blocks per mode
@@ -708,7 +708,7 @@ hipError_t launch_counts(const void* first, uint64_t n_blocks, void* workspace, 
     if (((reinterpret_cast<uintptr_t>(first) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
         return hipErrorInvalidValue;
     const uint64_t tiles = tiles_for(n_blocks), groups = groups_for(tiles);
-    if (tiles > 0x7FFFFFFFull || groups > 65535ull * 1024)
+    if (tiles * kThreads > 0xFFFFFFFFull || groups > 65535ull * 1024)   // a launch holds fewer than 2^32 threads: 256 GiB of blocks
         return hipErrorInvalidValue;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     uint64_t* totals = reinterpret_cast<uint64_t*>(ws);

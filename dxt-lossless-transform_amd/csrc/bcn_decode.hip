@@ -17,6 +17,7 @@
 
 #include "bcn_decode.h"
 #include "bcn_launch.h"
+#include "launch_grid.h"
 
 namespace dxtlt {
 namespace {
@@ -62,7 +63,7 @@ decode_blocks_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, 
 {
     __shared__ u32x4 stage[(kDecThreads / 64) * kWaveStage];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t wave_first = (uint64_t)blockIdx.x * kDecThreads + 64 * wave;
+    const uint64_t wave_first = workgroup_index() * kDecThreads + 64 * wave;
     const uint64_t b = wave_first + lane;
     uint32_t q[4] = {0, 0, 0, 0}, px[16];
     if (b < num_blocks)
@@ -88,7 +89,7 @@ template <int FMT>
 __global__ void __launch_bounds__(kDecThreads)
 decode_blocks_unaligned_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t num_blocks)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * kDecThreads + threadIdx.x;
+    const uint64_t b = workgroup_index() * kDecThreads + threadIdx.x;
     if (b >= num_blocks)
         return;
     uint32_t q[4], px[16];
@@ -144,15 +145,15 @@ inline bool aligned_to(const void* p, uintptr_t a) { return (reinterpret_cast<ui
 template <int FMT>
 hipError_t decode_fmt(const void* in, void* out, uint64_t n, hipStream_t stream)
 {
-    const uint64_t wgs = (n + kDecThreads - 1) / kDecThreads;
-    if (wgs > 0x7FFFFFFFull)
-        return hipErrorInvalidValue;
+    dim3 grid;
+    if (hipError_t e = grid_rows(n, kDecThreads, grid); e != hipSuccess)
+        return e;
     const bool fast = aligned_to(in, FMT == 1 ? 8 : 16) && aligned_to(out, 16);
     if (fast)
-        hipLaunchKernelGGL(decode_blocks_kernel<FMT>, dim3((unsigned)wgs), dim3(kDecThreads), 0, stream,
+        hipLaunchKernelGGL(decode_blocks_kernel<FMT>, grid, dim3(kDecThreads), 0, stream,
                            static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), n);
     else
-        hipLaunchKernelGGL(decode_blocks_unaligned_kernel<FMT>, dim3((unsigned)wgs), dim3(kDecThreads), 0, stream,
+        hipLaunchKernelGGL(decode_blocks_unaligned_kernel<FMT>, grid, dim3(kDecThreads), 0, stream,
                            static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), n);
     return hipGetLastError();
 }

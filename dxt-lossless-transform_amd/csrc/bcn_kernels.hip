@@ -1106,6 +1106,24 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (s.normalize != kNormNone && (fmt != kBc1 || inverse || s.normalize < 0 || s.normalize > kNormTransparentOnly))
         return hipErrorInvalidValue;  // normalisation exists for the BC1 forward transform only
 
+    // HIP refuses a launch of 2^32 or more threads (grid x workgroup), which a 64 GiB buffer reaches at 16 bytes per
+    // lane.  Larger ranges go out as consecutive sub-ranges of 2^31 blocks (a multiple of every tile size, so stream
+    // alignment and tile boundaries are the same as in one launch): the AoS side advances, the SoA side is addressed
+    // through first_block as always.
+    constexpr uint64_t kMaxBlocksPerLaunch = 1ull << 31;
+    if (r.num_blocks > kMaxBlocksPerLaunch) {
+        const uint64_t block_bytes = fmt_block(fmt);
+        for (uint64_t off = 0; off < r.num_blocks; off += kMaxBlocksPerLaunch) {
+            const uint64_t n = r.num_blocks - off < kMaxBlocksPerLaunch ? r.num_blocks - off : kMaxBlocksPerLaunch;
+            const Range sub{r.total_blocks, r.first_block + off, n};
+            const void* sub_src = inverse ? src : static_cast<const void*>(static_cast<const uint8_t*>(src) + off * block_bytes);
+            void* sub_dst = inverse ? static_cast<void*>(static_cast<uint8_t*>(dst) + off * block_bytes) : dst;
+            if (hipError_t e = launch_transform(fmt, inverse, s, sub_src, sub_dst, sub, stream, tuning); e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+
     const bool sa = (fmt == kBc3) && s.split_alpha;
     const bool sc = s.split_colour;
     const bool normalizing = s.normalize != kNormNone;
@@ -1163,8 +1181,6 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
     const uint64_t num_tiles = use_tiles ? r.num_blocks / T : 0;
     if (num_tiles > 0) {
-        if (num_tiles > 0x7FFFFFFFull)
-            return hipErrorInvalidValue;  // > 8 TiB in one call
         if (use_shift)
             hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
                                r.first_block, sh);
@@ -1178,9 +1194,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     const uint64_t done = num_tiles * T;
     const uint64_t rest = r.num_blocks - done;
     if (rest > 0) {
-        const uint64_t grid = (rest + kThreads - 1) / kThreads;
-        if (grid > 0x7FFFFFFFull)
-            return hipErrorInvalidValue;
+        const uint64_t grid = (rest + kThreads - 1) / kThreads;   // rest <= 2^31 blocks, one per thread
         hipLaunchKernelGGL(ks.generic, dim3((unsigned)grid), dim3(kThreads), 0, stream, src8, dst8, r.total_blocks,
                            r.first_block, done, rest);
         hipError_t e = hipGetLastError();

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bcn_launch.h"
+#include "launch_grid.h"
 #include "ycocg_swar.h"
 
 namespace dxtlt {
@@ -47,7 +48,7 @@ template <bool INVERSE>
 __global__ void __launch_bounds__(kColThreads)
 ycocg_array_kernel(const uint8_t* in, uint8_t* out, uint64_t vecs, uint64_t singles, int variant)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kColThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kColThreads + threadIdx.x;
     if (i < vecs) {
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + 16 * i));
         const u32x4 r = {ycocg2_rt<INVERSE>(variant, q.x), ycocg2_rt<INVERSE>(variant, q.y), ycocg2_rt<INVERSE>(variant, q.z),
@@ -71,7 +72,7 @@ __device__ __forceinline__ u32x4 zip16(u32x2 a, u32x2 b)   // a = four c0, b = f
 __global__ void __launch_bounds__(kColThreads)
 recorrelate_split_kernel(const uint8_t* src0, const uint8_t* src1, uint8_t* dst, uint64_t vecs, uint64_t singles, int variant)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kColThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kColThreads + threadIdx.x;
     if (i < vecs) {
         const u32x2 a = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src0 + 8 * i));   // c0 of pairs 4i .. 4i+3
         const u32x2 b = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src1 + 8 * i));
@@ -91,7 +92,7 @@ recorrelate_split_kernel(const uint8_t* src0, const uint8_t* src1, uint8_t* dst,
 __global__ void __launch_bounds__(kColThreads)
 split_endpoints_kernel(const uint8_t* in, uint8_t* out, uint64_t num_pairs, uint64_t vecs, uint64_t singles)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kColThreads + threadIdx.x;
+    const uint64_t i = workgroup_index() * kColThreads + threadIdx.x;
     uint8_t* out1 = out + 2 * num_pairs;
     if (i < vecs) {
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + 32 * i));
@@ -111,14 +112,7 @@ split_endpoints_kernel(const uint8_t* in, uint8_t* out, uint64_t num_pairs, uint
 
 inline bool aligned(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(a - 1)) == 0; }
 
-inline hipError_t col_grid(uint64_t lanes, unsigned& g)
-{
-    const uint64_t v = (lanes + kColThreads - 1) / kColThreads;
-    if (v > 0x7FFFFFFFull)
-        return hipErrorInvalidValue;
-    g = (unsigned)v;
-    return hipSuccess;
-}
+inline hipError_t col_grid(uint64_t lanes, dim3& g) { return grid_rows(lanes, kColThreads, g); }
 
 }  // namespace
 
@@ -132,11 +126,11 @@ hipError_t launch_color565_ycocg(bool inverse, const void* in, void* out, uint64
         return in == out ? hipSuccess : hipMemcpyAsync(out, in, num_items * 2, hipMemcpyDeviceToDevice, stream);
     const bool vec = aligned(in, 16) && aligned(out, 16);
     const uint64_t vecs = vec ? num_items / 8 : 0, singles = num_items - 8 * vecs;
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = col_grid(vecs + singles, g); e != hipSuccess)
         return e;
     auto k = inverse ? ycocg_array_kernel<true> : ycocg_array_kernel<false>;
-    hipLaunchKernelGGL(k, dim3(g), dim3(kColThreads), 0, stream, static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), vecs,
+    hipLaunchKernelGGL(k, g, dim3(kColThreads), 0, stream, static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), vecs,
                        singles, variant);
     return hipGetLastError();
 }
@@ -151,10 +145,10 @@ hipError_t launch_color565_recorrelate_split(const void* src0, const void* src1,
     const uint64_t pairs = num_items / 2;
     const bool vec = aligned(src0, 8) && aligned(src1, 8) && aligned(dst, 16);
     const uint64_t vecs = vec ? pairs / 4 : 0, singles = pairs - 4 * vecs;
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = col_grid(vecs + singles, g); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(recorrelate_split_kernel, dim3(g), dim3(kColThreads), 0, stream, static_cast<const uint8_t*>(src0),
+    hipLaunchKernelGGL(recorrelate_split_kernel, g, dim3(kColThreads), 0, stream, static_cast<const uint8_t*>(src0),
                        static_cast<const uint8_t*>(src1), static_cast<uint8_t*>(dst), vecs, singles, variant);
     return hipGetLastError();
 }
@@ -169,10 +163,10 @@ hipError_t launch_split_565_color_endpoints(const void* in, void* out, uint64_t 
     // both halves of the output must be 16-byte aligned for the vector path: out and out + 2 * pairs
     const bool vec = aligned(in, 16) && aligned(out, 16) && (pairs % 8 == 0);
     const uint64_t vecs = vec ? pairs / 8 : 0, singles = pairs - 8 * vecs;
-    unsigned g = 0;
+    dim3 g;
     if (hipError_t e = col_grid(vecs + singles, g); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(split_endpoints_kernel, dim3(g), dim3(kColThreads), 0, stream, static_cast<const uint8_t*>(in),
+    hipLaunchKernelGGL(split_endpoints_kernel, g, dim3(kColThreads), 0, stream, static_cast<const uint8_t*>(in),
                        static_cast<uint8_t*>(out), pairs, vecs, singles);
     return hipGetLastError();
 }

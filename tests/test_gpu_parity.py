@@ -525,3 +525,77 @@ def test_eight_gib_properties(pkg, oracle, dev, fmt, seed):
     getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, st)
     torch.cuda.synchronize()
     assert torch.equal(z, x)
+
+
+@pytest.mark.parametrize("fmt,seed", [("bc1", 0x0BC10640), ("bc3", 0x0BC30640)])
+def test_sixty_four_gib_round_trip(pkg, oracle, dev, fmt, seed):
+    """Sized for the 288 GB of one MI355X rather than for a CPU's caches: one 64 GiB buffer (2^33 BC1 blocks, 32 M
+    workgroups in one launch; stream bases and block indices well past 2^32).  Sampled windows against the oracle at
+    both ends and across the 2^32-, 2^33-, 2^34- and 2^35-byte offsets, then an exact round trip."""
+    nbytes = 64 << 30
+    torch.cuda.empty_cache()   # memory cached from earlier tests counts as used in mem_get_info
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 3 * nbytes + (8 << 30):
+        pytest.skip(f"needs three 64 GiB buffers, {free >> 30} GiB free")
+    B = BLOCK[fmt]
+    total = nbytes // B
+    s = (1, 1, 1)
+    st = pkg_settings(pkg, fmt, s)
+    x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, seed)
+    y = torch.empty_like(x)
+    getattr(pkg, f"transform_{fmt}_with_settings")(x, y, st)
+    torch.cuda.synchronize()
+    win = 32 * 1024
+    firsts = [0, total - win, total // 2 - win // 2, total // 3 + 1, 5 * (total // 7)]
+    firsts += [(1 << p) // B - win // 2 for p in (32, 33, 34, 35)]
+    for f in firsts:
+        _window_check(pkg, oracle, fmt, s, x, y, total, f, win)
+    z = torch.empty_like(x)
+    getattr(pkg, f"untransform_{fmt}_with_settings")(y, z, st)
+    torch.cuda.synchronize()
+    step = 1 << 30   # torch.equal on the whole buffer would allocate another 64 GiB
+    for lo in range(0, nbytes, step):
+        assert torch.equal(z[lo:lo + step], x[lo:lo + step]), (fmt, lo)
+
+
+def test_element_wise_kernels_past_2_32_lanes(pkg, oracle, dev):
+    """72 GiB at 16 bytes per lane is 1.125 * 2^32 lanes: more threads than one HIP launch dimension holds, so the
+    element-wise kernels run on a two-dimensional grid (csrc/launch_grid.h).  BC1 normalisation: sampled windows
+    against the oracle around the 2^32-lane row boundary and at both ends, and no decoded pixel changes anywhere;
+    colour decorrelation in place and back gives the source."""
+    from dxt_lossless_transform_amd import color565, decode, normalize
+
+    nbytes = 72 << 30
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 2 * nbytes + (8 << 30):
+        pytest.skip(f"needs two 72 GiB buffers, {free >> 30} GiB free")
+    x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, 0x72)
+    # make a quarter of the blocks normalisable: one index value per block
+    v = x.view(-1, 8)
+    step = 1 << 27
+    for lo in range(0, v.shape[0], step):
+        v[lo:lo + step:4, 4:] = 0
+    y = torch.empty_like(x)
+    mode = normalize.ColorNormalizationMode.COLOR0_ONLY
+    normalize.normalize_blocks(x, y, mode)
+    torch.cuda.synchronize()
+    win = 1 << 20
+    for at in (0, nbytes - win, (64 << 30) - win // 2, (64 << 30) + (1 << 30), 36 << 30):
+        want = oracle.normalize_bc1_blocks(x[at:at + win].cpu().numpy(), int(mode))
+        assert np.array_equal(y[at:at + win].cpu().numpy(), want), at
+    assert decode.count_pixel_differences("bc1", x, y) == 0
+    changed = sum(int((x[lo:lo + (1 << 30)] != y[lo:lo + (1 << 30)]).any()) for lo in (0, 65 << 30, 71 << 30))
+    assert changed == 3          # the kernel did rewrite blocks in the first, a middle and the last GiB
+    # colour arrays: y <- decorrelate(x) (out of place), then recorrelate in place
+    color565.decorrelate_ycocg_r(x, y, 2)
+    for at in (0, nbytes - win, (64 << 30) - win // 2, (64 << 30) + 12345 * 16):
+        cols = x[at:at + win].cpu().numpy().view("<u2")
+        want = np.array([oracle.decorrelate(int(c), 2) for c in cols[:4096]], dtype="<u2")
+        assert np.array_equal(y[at:at + 8192].cpu().numpy().view("<u2"), want), at
+    color565.recorrelate_ycocg_r(y, y, 2)
+    torch.cuda.synchronize()
+    for lo in range(0, nbytes, 1 << 30):
+        assert torch.equal(y[lo:lo + (1 << 30)], x[lo:lo + (1 << 30)]), lo
