@@ -291,7 +291,7 @@ __device__ __forceinline__ void typed_move(uint8_t* dst, const uint8_t* src, int
 __device__ __forceinline__ void store_block(uint8_t* p, u32x4 v)
 {
     // AoS output: whole 1 KiB runs per wave instruction, nobody else touches these lines -> write-through streaming
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ constexpr uint64_t kDifferenceGrid = 256 * 16;    // workgroups of the differenc
 // write-through past L2, streaming: as gstore16 in bcn_kernels.hip
 __device__ __forceinline__ void store_streaming(void* p, u32x4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 template <int FMT>

@@ -79,10 +79,14 @@ __device__ __forceinline__ u32x4 gload16(const void* p)
 // `sc1` makes the store write-through and drops the line from the XCD's L2 (MI355X_MICROARCH.md, store flavours), which
 // is what a write-once stream wants; `nt` on top marks it streaming.  There is no builtin for that combination, so
 // the instruction is spelled out; it has no result, and the compiler still waits for the operands it produced.
+// The trailing `s_nop 1` is not optional: a 16-byte store reads its data registers a few cycles after issue, hipcc pads
+// that hazard for its own stores only, and without the two wait states the instruction after the asm may overwrite
+// them -- seen as stale dwords in lanes 12..15 of every 16 once a store sat inside an unrolled loop (the 4-sub-tile
+// shifted inverse).
 __device__ __forceinline__ void gstore16(void* p, u32x4 v)
 {
 #if DXTLT_NONTEMPORAL
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<u32x4*>(p) = v;
 #endif
@@ -242,6 +246,10 @@ __device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t 
     return start + (orig >> 3);
 }
 
+// Tried and dropped (profiles/r01_z/shift_probe_rotation_and_chunks.txt): handing each XCD chunks of 4 / 16 / 64
+// consecutive tiles in turn, so that the chip keeps one moving window -- slower than both this order and the identity
+// on every alignment class (BC3 forward, 128-byte aligned bases: 0.75 against 0.84 identity / 0.78 contiguous).
+
 // ------------------------------------------------------------------------------------------------
 // Tiled kernels: one tile per workgroup.  `aos` points at the range's first block, `soa` at byte 0 of the
 // whole transformed buffer.  Preconditions (checked on the host): both pointers 16-byte aligned; every
@@ -313,7 +321,22 @@ struct Shifts {
     int d[6];
     int xcd_remap;    // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
     int line_policy;  // 1: forward stores of lines written whole by one wave instruction are write-through (sc1 nt)
+    int skip_partial; // timing experiment only (wrong output): 1 = leave out the partial head / tail segments
+    int natural;      // 1: every d[s] is a multiple of stream s's element width (always so when the SoA pointer is 8-byte aligned)
 };
+
+// element width of a stream: its bytes per block, except the 6-byte alpha index records, which move as three halfwords
+__host__ __device__ constexpr int stream_element_width(int bytes_per_block) { return bytes_per_block == 6 ? 2 : bytes_per_block; }
+
+template <typename STREAMS>
+__host__ __device__ inline int shifts_are_natural(const STREAMS& S, const int (&d)[6])
+{
+    int ok = 1;
+    for (int i = 0; i < 6; ++i)
+        if (i < S.n && (d[i] & (stream_element_width(S.width[i]) - 1)) != 0)
+            ok = 0;
+    return ok;
+}
 
 
 // LDS accesses of the shifted tiles.  A field of W bytes sits at an address that is only known to be congruent to
@@ -375,11 +398,12 @@ __device__ __forceinline__ uint64_t lds_get_seq(uint8_t* lds, int addr)
     return 0;
 }
 
-template <int W>
+// NAT: the caller guarantees addr % W == 0 (every stream shift is a multiple of its field width: Shifts::natural)
+template <int W, bool NAT = false>
 __device__ __forceinline__ void lds_put(uint8_t* lds, int addr, uint64_t v)
 {
-    if constexpr (W == 1) {
-        lds_put_piece<1>(lds, addr, v);
+    if constexpr (W == 1 || NAT) {
+        lds_put_piece<W>(lds, addr, v);
     } else {
         switch (addr & (W - 1)) {
         case 0: lds_put_seq<W, 0>(lds, addr, v); break;
@@ -394,11 +418,11 @@ __device__ __forceinline__ void lds_put(uint8_t* lds, int addr, uint64_t v)
     }
 }
 
-template <int W>
+template <int W, bool NAT = false>
 __device__ __forceinline__ uint64_t lds_get(uint8_t* lds, int addr)
 {
-    if constexpr (W == 1) {
-        return lds_get_piece<1>(lds, addr);
+    if constexpr (W == 1 || NAT) {
+        return lds_get_piece<W>(lds, addr);
     } else {
         switch (addr & (W - 1)) {
         case 0: return lds_get_seq<W, 0>(lds, addr);
@@ -425,70 +449,100 @@ struct FieldStreams {
     static constexpr int idx = col + (SC ? 2 : 1);
 };
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+// NAT (Shifts::natural): every stream's shift is a multiple of its element width, so each element goes out as one aligned
+// DS instruction and the per-access alignment switch disappears.  BC1 then writes its two blocks' fields separately
+// (the pair is only element-aligned); the other formats' accesses are element-wide already.
+template <int FMT, int VARIANT, bool SA, bool SC, bool NAT>
 __device__ __forceinline__ void scatter_shifted(uint8_t* lds, int u, u32x4 q, const int (&base)[6])
 {
     using F = FieldStreams<FMT, SA, SC>;
     if constexpr (FMT == kBc1) {
         const uint32_t ca = decorrelate2<VARIANT>(q.x);
         const uint32_t cb = decorrelate2<VARIANT>(q.z);
-        if constexpr (SC) {
-            lds_put<4>(lds, base[F::col] + 4 * u, (ca & 0xFFFFu) | (cb << 16));
-            lds_put<4>(lds, base[F::c1] + 4 * u, (ca >> 16) | (cb & 0xFFFF0000u));
+        if constexpr (NAT) {
+            if constexpr (SC) {
+                lds_put<2, true>(lds, base[F::col] + 4 * u, ca & 0xFFFFu);
+                lds_put<2, true>(lds, base[F::col] + 4 * u + 2, cb & 0xFFFFu);
+                lds_put<2, true>(lds, base[F::c1] + 4 * u, ca >> 16);
+                lds_put<2, true>(lds, base[F::c1] + 4 * u + 2, cb >> 16);
+            } else {
+                lds_put<4, true>(lds, base[F::col] + 8 * u, ca);
+                lds_put<4, true>(lds, base[F::col] + 8 * u + 4, cb);
+            }
+            lds_put<4, true>(lds, base[F::idx] + 8 * u, q.y);
+            lds_put<4, true>(lds, base[F::idx] + 8 * u + 4, q.w);
         } else {
-            lds_put<8>(lds, base[F::col] + 8 * u, (uint64_t)ca | ((uint64_t)cb << 32));
+            if constexpr (SC) {
+                lds_put<4>(lds, base[F::col] + 4 * u, (ca & 0xFFFFu) | (cb << 16));
+                lds_put<4>(lds, base[F::c1] + 4 * u, (ca >> 16) | (cb & 0xFFFF0000u));
+            } else {
+                lds_put<8>(lds, base[F::col] + 8 * u, (uint64_t)ca | ((uint64_t)cb << 32));
+            }
+            lds_put<8>(lds, base[F::idx] + 8 * u, (uint64_t)q.y | ((uint64_t)q.w << 32));
         }
-        lds_put<8>(lds, base[F::idx] + 8 * u, (uint64_t)q.y | ((uint64_t)q.w << 32));
     } else {
         const uint32_t c = decorrelate2<VARIANT>(q.z);
         if constexpr (FMT == kBc2) {
-            lds_put<8>(lds, base[F::alpha] + 8 * u, (uint64_t)q.x | ((uint64_t)q.y << 32));
+            lds_put<8, NAT>(lds, base[F::alpha] + 8 * u, (uint64_t)q.x | ((uint64_t)q.y << 32));
         } else {
             if constexpr (SA) {
                 lds_put<1>(lds, base[F::alpha] + u, q.x & 0xFF);
                 lds_put<1>(lds, base[F::a1] + u, (q.x >> 8) & 0xFF);
             } else {
-                lds_put<2>(lds, base[F::alpha] + 2 * u, q.x & 0xFFFF);
+                lds_put<2, NAT>(lds, base[F::alpha] + 2 * u, q.x & 0xFFFF);
             }
-            lds_put<2>(lds, base[F::aidx] + 6 * u + 0, q.x >> 16);
-            lds_put<2>(lds, base[F::aidx] + 6 * u + 2, q.y & 0xFFFF);
-            lds_put<2>(lds, base[F::aidx] + 6 * u + 4, q.y >> 16);
+            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 0, q.x >> 16);
+            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 2, q.y & 0xFFFF);
+            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 4, q.y >> 16);
         }
         if constexpr (SC) {
-            lds_put<2>(lds, base[F::col] + 2 * u, c & 0xFFFF);
-            lds_put<2>(lds, base[F::c1] + 2 * u, c >> 16);
+            lds_put<2, NAT>(lds, base[F::col] + 2 * u, c & 0xFFFF);
+            lds_put<2, NAT>(lds, base[F::c1] + 2 * u, c >> 16);
         } else {
-            lds_put<4>(lds, base[F::col] + 4 * u, c);
+            lds_put<4, NAT>(lds, base[F::col] + 4 * u, c);
         }
-        lds_put<4>(lds, base[F::idx] + 4 * u, q.w);
+        lds_put<4, NAT>(lds, base[F::idx] + 4 * u, q.w);
     }
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, bool NAT>
 __device__ __forceinline__ u32x4 gather_shifted(uint8_t* lds, int u, const int (&base)[6])
 {
     using F = FieldStreams<FMT, SA, SC>;
     u32x4 q;
     if constexpr (FMT == kBc1) {
         uint32_t ca, cb;
-        if constexpr (SC) {
-            const uint32_t c0 = (uint32_t)lds_get<4>(lds, base[F::col] + 4 * u);
-            const uint32_t c1 = (uint32_t)lds_get<4>(lds, base[F::c1] + 4 * u);
-            ca = (c0 & 0xFFFFu) | (c1 << 16);
-            cb = (c0 >> 16) | (c1 & 0xFFFF0000u);
+        uint64_t idx;
+        if constexpr (NAT) {
+            if constexpr (SC) {
+                ca = (uint32_t)lds_get<2, true>(lds, base[F::col] + 4 * u) | ((uint32_t)lds_get<2, true>(lds, base[F::c1] + 4 * u) << 16);
+                cb = (uint32_t)lds_get<2, true>(lds, base[F::col] + 4 * u + 2) |
+                     ((uint32_t)lds_get<2, true>(lds, base[F::c1] + 4 * u + 2) << 16);
+            } else {
+                ca = (uint32_t)lds_get<4, true>(lds, base[F::col] + 8 * u);
+                cb = (uint32_t)lds_get<4, true>(lds, base[F::col] + 8 * u + 4);
+            }
+            idx = lds_get<4, true>(lds, base[F::idx] + 8 * u) | (lds_get<4, true>(lds, base[F::idx] + 8 * u + 4) << 32);
         } else {
-            const uint64_t p = lds_get<8>(lds, base[F::col] + 8 * u);
-            ca = (uint32_t)p;
-            cb = (uint32_t)(p >> 32);
+            if constexpr (SC) {
+                const uint32_t c0 = (uint32_t)lds_get<4>(lds, base[F::col] + 4 * u);
+                const uint32_t c1 = (uint32_t)lds_get<4>(lds, base[F::c1] + 4 * u);
+                ca = (c0 & 0xFFFFu) | (c1 << 16);
+                cb = (c0 >> 16) | (c1 & 0xFFFF0000u);
+            } else {
+                const uint64_t p = lds_get<8>(lds, base[F::col] + 8 * u);
+                ca = (uint32_t)p;
+                cb = (uint32_t)(p >> 32);
+            }
+            idx = lds_get<8>(lds, base[F::idx] + 8 * u);
         }
-        const uint64_t idx = lds_get<8>(lds, base[F::idx] + 8 * u);
         q.x = recorrelate2<VARIANT>(ca);
         q.y = (uint32_t)idx;
         q.z = recorrelate2<VARIANT>(cb);
         q.w = (uint32_t)(idx >> 32);
     } else {
         if constexpr (FMT == kBc2) {
-            const uint64_t a = lds_get<8>(lds, base[F::alpha] + 8 * u);
+            const uint64_t a = lds_get<8, NAT>(lds, base[F::alpha] + 8 * u);
             q.x = (uint32_t)a;
             q.y = (uint32_t)(a >> 32);
         } else {
@@ -496,20 +550,20 @@ __device__ __forceinline__ u32x4 gather_shifted(uint8_t* lds, int u, const int (
             if constexpr (SA)
                 a01 = (uint32_t)lds_get<1>(lds, base[F::alpha] + u) | ((uint32_t)lds_get<1>(lds, base[F::a1] + u) << 8);
             else
-                a01 = (uint32_t)lds_get<2>(lds, base[F::alpha] + 2 * u);
-            const uint32_t i01 = (uint32_t)lds_get<2>(lds, base[F::aidx] + 6 * u + 0);
-            const uint32_t i23 = (uint32_t)lds_get<2>(lds, base[F::aidx] + 6 * u + 2);
-            const uint32_t i45 = (uint32_t)lds_get<2>(lds, base[F::aidx] + 6 * u + 4);
+                a01 = (uint32_t)lds_get<2, NAT>(lds, base[F::alpha] + 2 * u);
+            const uint32_t i01 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 0);
+            const uint32_t i23 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 2);
+            const uint32_t i45 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 4);
             q.x = a01 | (i01 << 16);
             q.y = i23 | (i45 << 16);
         }
         uint32_t c;
         if constexpr (SC)
-            c = (uint32_t)lds_get<2>(lds, base[F::col] + 2 * u) | ((uint32_t)lds_get<2>(lds, base[F::c1] + 2 * u) << 16);
+            c = (uint32_t)lds_get<2, NAT>(lds, base[F::col] + 2 * u) | ((uint32_t)lds_get<2, NAT>(lds, base[F::c1] + 2 * u) << 16);
         else
-            c = (uint32_t)lds_get<4>(lds, base[F::col] + 4 * u);
+            c = (uint32_t)lds_get<4, NAT>(lds, base[F::col] + 4 * u);
         q.z = recorrelate2<VARIANT>(c);
-        q.w = (uint32_t)lds_get<4>(lds, base[F::idx] + 4 * u);
+        q.w = (uint32_t)lds_get<4, NAT>(lds, base[F::idx] + 4 * u);
     }
     return q;
 }
@@ -540,14 +594,32 @@ __device__ __forceinline__ void copy_partial_segment(uint8_t* dst, const uint8_t
     }
 }
 
-// For image byte o (a multiple of 16): stream index, LDS address of the segment, global offset of the segment
-// (aligned), and the stream's shift.
-template <int FMT, bool SA, bool SC, int T>
-__device__ __forceinline__ void shifted_segment(int o, uint64_t total_blocks, uint64_t blk0, const Shifts& sh, int& s_out,
-                                                int& k_out, int& lds_addr, uint64_t& g_off, int& shift)
+// 64-bit value that is the same in every lane, kept in SGPRs (the compiler otherwise sinks the per-stream base
+// computations into the per-lane branches and does them with quarter-rate v_mad_u64_u32)
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
+// global offset (from the SoA pointer) of segment 0 of every stream's slice of this tile: aligned, d[s] bytes before the slice
+template <int FMT, bool SA, bool SC>
+__device__ __forceinline__ void slice_bases(uint64_t total_blocks, uint64_t blk0, const Shifts& sh, uint64_t (&gb)[6])
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    s_out = 0; k_out = 0; lds_addr = 0; g_off = 0; shift = 0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+        gb[s] = s < S.n ? uniform64((uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 - (uint64_t)sh.d[s]) : 0;
+}
+
+// For image byte o (a multiple of 16): stream index, segment number within the slice, LDS address of the segment, global
+// offset of the segment (aligned), the stream's shift and the number of whole segments of the slice.
+template <int FMT, bool SA, bool SC, int T>
+__device__ __forceinline__ void shifted_segment(int o, const uint64_t (&gb)[6], const Shifts& sh, int& s_out, int& k_out,
+                                                int& lds_addr, uint64_t& g_off, int& shift, int& nseg)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    s_out = 0; k_out = 0; lds_addr = 0; g_off = 0; shift = 0; nseg = 0;
 #pragma unroll
     for (int s = 0; s < S.n; ++s) {
         const int lo = S.off[s] * T;
@@ -556,22 +628,30 @@ __device__ __forceinline__ void shifted_segment(int o, uint64_t total_blocks, ui
             s_out = s;
             k_out = (o - lo) >> 4;
             lds_addr = lo + 16 * s + (o - lo);
-            g_off = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 - (uint64_t)sh.d[s] + (uint64_t)(o - lo);
+            g_off = gb[s] + (uint64_t)(o - lo);
             shift = sh.d[s];
+            nseg = S.width[s] * T / 16;
         }
     }
 }
 
-constexpr int kShiftLdsBytes = 256 * 16 + 16 * 6;
+// LDS bytes of a shifted tile of R x 256 lanes' worth of blocks: the image plus 16 bytes of padding per stream
+constexpr int shift_lds_bytes(int r) { return r * 256 * 16 + 16 * 6; }
+constexpr int kShiftLdsBytes = shift_lds_bytes(1);
+// R = sub-tiles of 256 lanes per workgroup.  Only R = 1 is instantiated: with misaligned stream bases every slice shares
+// its first and last 128-byte line with the neighbouring tiles (BC3, 256 blocks per tile: 12 of 38 lines), and R = 4
+// cuts that to 12 of 134 -- but it measured slower, not faster (BC3 odd count 0.710 / 0.773 forward / inverse against
+// 0.702 / 0.797, BC1 0.755 / 0.777 against 0.775 / 0.818; profiles/r01_z/shift_probe_with_big_tiles.txt).  L2 merges the
+// shared lines either way: HBM traffic is 1.003 x the algorithmic bytes on odd counts (PMC).
 
-// one shifted tile, forward; `lds` is the workgroup's kShiftLdsBytes scratch (shared with the batch kernel)
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone>
+// one shifted tile, forward; `lds` is the workgroup's shift_lds_bytes(R) scratch (R = 1: shared with the batch kernel)
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone, int R = 1>
 __device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
                                                uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
                                                uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, 256) * R;
     const int t = threadIdx.x;
     const uint64_t blk0 = first_block + tile * T;
     int base[6];
@@ -579,64 +659,79 @@ __device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, 
     for (int s = 0; s < 6; ++s)
         base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
 
-    const u32x4 q = normalize_vector<FMT, NORM>(gload16(aos + tile * 4096 + t * 16));
-    scatter_shifted<FMT, VARIANT, SA, SC>(lds, t, q, base);
+    u32x4 q[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        q[j] = gload16(aos + tile * (4096 * R) + (t + 256 * j) * 16);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const u32x4 v = normalize_vector<FMT, NORM>(q[j]);
+        if (sh.natural)
+            scatter_shifted<FMT, VARIANT, SA, SC, true>(lds, t + 256 * j, v, base);
+        else
+            scatter_shifted<FMT, VARIANT, SA, SC, false>(lds, t + 256 * j, v, base);
+    }
     __syncthreads();
 
-    int s, k, la, shift;
-    uint64_t g;
-    shifted_segment<FMT, SA, SC, T>(t * 16, total_blocks, blk0, sh, s, k, la, g, shift);
-    if (k == 0 && shift > 0) {
-        copy_partial_segment<true>(soa + g, lds + la, shift, 16);
-    } else {
-        // A 128-byte line that this wave instruction writes completely may use the write-through streaming store of the
-        // aligned kernels.  A line that is completed by another wave or by the neighbouring tile must stay in L2 until
-        // then: plain `nt` (write-through on those: 0.39-0.50 of peak instead of 0.72-0.76).
-        int slice_bytes = 0;
+    uint64_t gb[6];
+    slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
 #pragma unroll
-        for (int ss = 0; ss < S.n; ++ss)
-            if (ss == s)
-                slice_bytes = S.width[ss] * T;
-        const uintptr_t seg = reinterpret_cast<uintptr_t>(soa) + g;
-        const uintptr_t slice_lo = seg + (uintptr_t)shift - (uintptr_t)(16 * k), slice_hi = slice_lo + (uintptr_t)slice_bytes;
-        const uintptr_t line = seg & ~(uintptr_t)127;
-        const int first_lane = t - (int)((seg - line) >> 4);   // lane that writes the line's first segment
-        const bool whole_line = line >= slice_lo && line + 128 <= slice_hi && first_lane >= 0 && (first_lane & 63) <= 56;
-        if (sh.line_policy && whole_line)
-            gstore16(soa + g, lds_at<u32x4>(lds, la));
-        else
-            __builtin_nontemporal_store(lds_at<u32x4>(lds, la), reinterpret_cast<u32x4*>(soa + g));
+    for (int j = 0; j < R; ++j) {
+        int s, k, la, shift, nseg;
+        uint64_t g;
+        shifted_segment<FMT, SA, SC, T>((t + 256 * j) * 16, gb, sh, s, k, la, g, shift, nseg);
+        if (k == 0 && shift > 0) {
+            if (!sh.skip_partial)
+                copy_partial_segment<true>(soa + g, lds + la, shift, 16);
+        } else {
+            // A 128-byte line that this wave instruction writes completely may use the write-through streaming store of
+            // the aligned kernels.  A line that is completed by another wave or by the neighbouring tile must stay in
+            // L2 until then: plain `nt` (write-through on those: 0.39-0.50 of peak instead of 0.72-0.76).
+            // In segment numbers of the slice: p = this segment's place in its line, kf = the line's first segment.
+            // The line lies inside the slice when kf is not the partial head and kf + 8 segments are whole ones; its
+            // eight lanes sit in one wave when the first of them is at most lane 56 of the wave.  (Rotating the lanes
+            // of a stream so that groups of eight coincide with lines, which makes nearly every line whole, changed
+            // nothing: 0.711 against 0.714, profiles/r01_z/shift_probe_rotation_and_chunks.txt.)
+            const int p = (int)(((uint32_t)(reinterpret_cast<uintptr_t>(soa) + g) >> 4) & 7u);   // low address bits are enough
+            const int kf = k - p;
+            const bool whole_line = kf >= (shift > 0 ? 1 : 0) && kf + 8 <= nseg && ((t - p) & 63) <= 56;
+            if (sh.line_policy && whole_line)
+                gstore16(soa + g, lds_at<u32x4>(lds, la));
+            else if (sh.line_policy == 2)
+                *reinterpret_cast<u32x4*>(soa + g) = lds_at<u32x4>(lds, la);
+            else
+                __builtin_nontemporal_store(lds_at<u32x4>(lds, la), reinterpret_cast<u32x4*>(soa + g));
+        }
     }
-    if (t < S.n) {  // the extra, partial last segment of stream t
+    if (t < S.n && !sh.skip_partial) {  // the extra, partial last segment of stream t
 #pragma unroll
         for (int ss = 0; ss < S.n; ++ss) {
             if (ss == t && sh.d[ss] > 0) {
                 const int bytes = S.width[ss] * T;
-                const uint64_t gt = (uint64_t)S.off[ss] * total_blocks + (uint64_t)S.width[ss] * blk0 - (uint64_t)sh.d[ss] + bytes;
-                copy_partial_segment<true>(soa + gt, lds + S.off[ss] * T + 16 * ss + bytes, 0, sh.d[ss]);
+                copy_partial_segment<true>(soa + gb[ss] + bytes, lds + S.off[ss] * T + 16 * ss + bytes, 0, sh.d[ss]);
             }
         }
     }
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone>
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone, int R = 1>
 __global__ void __launch_bounds__(256)
 fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
                 Shifts sh)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[shift_lds_bytes(R)];
     const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    fwd_shift_tile<FMT, VARIANT, SA, SC, NORM>(aos, soa, total_blocks, first_block, sh, tile, lds);
+    fwd_shift_tile<FMT, VARIANT, SA, SC, NORM, R>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
 
 // one shifted tile, inverse
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int R = 1>
 __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
                                                uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
                                                uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, 256) * R;
     const int t = threadIdx.x;
     const uint64_t blk0 = first_block + tile * T;
     int base[6];
@@ -649,9 +744,22 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
     // itself (first tile of the first stream, last tile of the last stream) is fetched piecewise.  All loads of the
     // tile are issued before the first wait.
     const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
-    int s, k, la, shift;
-    uint64_t g;
-    shifted_segment<FMT, SA, SC, T>(t * 16, total_blocks, blk0, sh, s, k, la, g, shift);
+    uint64_t gb[6];
+    slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
+    int k[R], la[R], shift[R];
+    uint64_t g[R];
+    bool main_inside[R];
+    u32x4 v_main[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        int s, nseg;
+        shifted_segment<FMT, SA, SC, T>((t + 256 * j) * 16, gb, sh, s, k[j], la[j], g[j], shift[j], nseg);
+        // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
+        main_inside[j] = g[j] + 16 <= total_bytes;
+        v_main[j] = u32x4{0, 0, 0, 0};
+        if (main_inside[j])
+            v_main[j] = gload16(soa + g[j]);
+    }
     // the extra, partial last segment of stream t (lanes 0..n-1), selected by data, not by control flow
     int la_t = 0, shift_t = 0;
     uint64_t g_t = 0;
@@ -661,22 +769,21 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
             const int bytes = S.width[ss] * T;
             la_t = S.off[ss] * T + 16 * ss + bytes;
             shift_t = sh.d[ss];
-            g_t = (uint64_t)S.off[ss] * total_blocks + (uint64_t)S.width[ss] * blk0 - (uint64_t)sh.d[ss] + bytes;
+            g_t = gb[ss] + bytes;
         }
     }
     const bool has_tail = t < S.n && shift_t > 0;
-    // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
-    const bool main_inside = g + 16 <= total_bytes;
     const bool tail_inside = g_t + 16 <= total_bytes;
-    u32x4 v_main = {0, 0, 0, 0}, v_tail = {0, 0, 0, 0};
-    if (main_inside)
-        v_main = gload16(soa + g);
+    u32x4 v_tail = {0, 0, 0, 0};
     if (has_tail && tail_inside)
         v_tail = gload16(soa + g_t);
-    if (main_inside)
-        lds_at<u32x4>(lds, la) = v_main;
-    else
-        copy_partial_segment<false>(lds + la, soa + g, (k == 0) ? shift : 0, (k == 0) ? 16 : shift);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (main_inside[j])
+            lds_at<u32x4>(lds, la[j]) = v_main[j];
+        else
+            copy_partial_segment<false>(lds + la[j], soa + g[j], (k[j] == 0) ? shift[j] : 0, (k[j] == 0) ? 16 : shift[j]);
+    }
     if (has_tail) {
         if (tail_inside)
             lds_at<u32x4>(lds, la_t) = v_tail;
@@ -684,18 +791,22 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
             copy_partial_segment<false>(lds + la_t, soa + g_t, 0, shift_t);
     }
     __syncthreads();
-    const u32x4 q = gather_shifted<FMT, VARIANT, SA, SC>(lds, t, base);
-    gstore16(aos + tile * 4096 + t * 16, q);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t + 256 * j, base)
+                                   : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t + 256 * j, base);
+        gstore16(aos + tile * (4096 * R) + (t + 256 * j) * 16, q);
+    }
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int R = 1>
 __global__ void __launch_bounds__(256)
 inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
                 Shifts sh)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[shift_lds_bytes(R)];
     const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
+    inv_shift_tile<FMT, VARIANT, SA, SC, R>(soa, aos, total_blocks, first_block, sh, tile, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -930,6 +1041,8 @@ __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, 
             sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 15u);
         sh.xcd_remap = 0;
         sh.line_policy = 1;
+        sh.skip_partial = 0;
+        sh.natural = shifts_are_natural(make_streams(FMT, SA, SC), sh.d);
         // every buffer's first workgroup is a multiple of 8 (the host pads), so local % 8 is the XCD this workgroup
         // runs on and the XCD-contiguous tile order of the single-buffer shifted kernels applies per buffer
         const uint64_t tile = xcd_contiguous_tile(local, en.tile_wgs);
@@ -1096,6 +1209,8 @@ int cached_cu_count()
 
 }  // namespace
 
+static inline int force_bits_early(const LaunchTuning* tuning) { return tuning ? tuning->force_generic : 0; }
+
 hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const void* src, void* dst,
                             const Range& r, hipStream_t stream, const LaunchTuning* tuning)
 {
@@ -1157,8 +1272,13 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
                               (uint64_t)S.width[i] * r.first_block;
         sh.d[i] = (int)(base & 15);
-        any_shift = any_shift || sh.d[i] != 0;
+        // The aligned tiles need 16-byte aligned stream bases to be correct and 128-byte aligned ones to be fast: with
+        // bases that are only 16-byte aligned every slice shares its first and last line with the neighbouring tiles,
+        // which the shifted tiles handle (XCD-contiguous tile order, no write-through on shared lines) and the aligned
+        // ones do not -- BC3 forward 0.65 against 0.77 of peak (tools/shift_probe.py, profiles/r01_z/shift_probe.txt).
+        any_shift = any_shift || (base & 127) != 0;
     }
+    sh.natural = (force_bits_early(tuning) & 0x20) ? 0 : shifts_are_natural(S, sh.d);   // experiment switch 0x20: generic LDS accesses
     // XCD-contiguous tile order: measured +2..+9 % on shifted tiles (neighbouring tiles share 128-byte lines), -1..-3 %
     // on aligned tiles (profiles/r01_i_*) -- so on for the former, off for the latter unless an experiment says so
     const int remap_override = tuning ? tuning->xcd_remap : -1;
@@ -1166,7 +1286,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     const int aligned_remap = remap_override >= 0 ? remap_override : 0;
     const int force_bits = tuning ? tuning->force_generic : 0;
     const int force = force_bits & 3;  // 1 = element kernel, 2 = shifted tiles
-    sh.line_policy = (force_bits & 0x40) ? 0 : 1;  // experiment switch: 0x40 = plain nt stores on every shifted line
+    sh.skip_partial = (force_bits & 0x10) ? 1 : 0;
+    sh.line_policy = (force_bits & 0x40) ? 0 : (force_bits & 0x80) ? 2 : 1;  // 0x80: shared lines with plain (temporal) stores  // experiment switch: 0x40 = plain nt stores on every shifted line
     const bool use_tiles = aos_ok && force != 1;
     const bool use_shift = use_tiles && (any_shift || force == 2);
 

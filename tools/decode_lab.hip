@@ -24,7 +24,7 @@ using namespace dxtlt;
 
 constexpr int T = 256, ROW = 64 + 4, WAVE = 4 * ROW;
 
-__device__ __forceinline__ void store_sc1nt(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_sc1nt(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_plain(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ void store_nt(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
 
