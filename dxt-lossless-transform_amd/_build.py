@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdxtlt_gfx950.so")
 SOURCES = ["bcn_kernels.hip", "dxtlt_api.cpp", "c_api_core.cpp", "c_api_stable.cpp", "auto_transform.cpp", "file_format.cpp",
            "bc7_kernels.hip", "bc7_api.cpp", "bc7_sharded.cpp", "bc1_normalize.hip", "normalize_api.cpp", "batch_api.cpp", "bc23_normalize.hip",
            "normalize23_api.cpp", "color565_ops.hip", "color565_api.cpp", "bcn_decode.hip", "decode_api.cpp"]
-HEADERS = ["bcn_launch.h", "ycocg_swar.h", "host_common.h", "bc7_launch.h", "bc1_normalize.h", "bc23_normalize.h", "bcn_decode.h", "launch_grid.h"]
+HEADERS = ["bcn_launch.h", "ycocg_swar.h", "host_common.h", "bc7_launch.h", "bc1_normalize.h", "bc23_normalize.h", "bcn_decode.h", "launch_grid.h", "streaming_store.h"]
 
 
 def _hipcc() -> str:

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bc7_launch.h"
+#include "streaming_store.h"
 
 namespace dxtlt {
 namespace bc7 {
@@ -291,7 +292,7 @@ __device__ __forceinline__ void typed_move(uint8_t* dst, const uint8_t* src, int
 __device__ __forceinline__ void store_block(uint8_t* p, u32x4 v)
 {
     // AoS output: whole 1 KiB runs per wave instruction, nobody else touches these lines -> write-through streaming
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    store_streaming16(p, v);   // streaming_store.h
 }
 
 // ---------------------------------------------------------------------------------------------------------

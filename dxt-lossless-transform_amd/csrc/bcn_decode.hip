@@ -18,6 +18,7 @@
 #include "bcn_decode.h"
 #include "bcn_launch.h"
 #include "launch_grid.h"
+#include "streaming_store.h"
 
 namespace dxtlt {
 namespace {
@@ -30,11 +31,7 @@ constexpr int kRowStride = 64 + 4;                 // u32x4 units: 64 lanes + 64
 constexpr int kWaveStage = 4 * kRowStride;         // four pixel rows per wave
 constexpr uint64_t kDifferenceGrid = 256 * 16;    // workgroups of the difference count: 16 per CU
 
-// write-through past L2, streaming: as gstore16 in bcn_kernels.hip
-__device__ __forceinline__ void store_streaming(void* p, u32x4 v)
-{
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
+__device__ __forceinline__ void store_streaming(void* p, u32x4 v) { store_streaming16(p, v); }   // streaming_store.h
 
 template <int FMT>
 __device__ __forceinline__ void load_block(const uint8_t* in, uint64_t b, uint32_t q[4])

@@ -40,6 +40,7 @@
 
 #include "bc1_normalize.h"
 #include "bcn_launch.h"
+#include "streaming_store.h"
 #include "ycocg_swar.h"
 
 namespace dxtlt {
@@ -73,20 +74,11 @@ __device__ __forceinline__ u32x4 gload16(const void* p)
 #endif
 }
 
-// Streaming 16-byte store.  Cache policy measured on the 8 GiB BC1 forward kernel (tools/kernel_lab.hip,
-// profiles/r01_p_kernel_lab_cache_policies.txt), loads `nt` in every row:
-//   store plain 0.805 | nt 0.827 | sc1 0.838 | sc0 sc1 0.829 | sc1 nt 0.841 | sc0 sc1 nt 0.842   (fraction of 8 TB/s)
-// `sc1` makes the store write-through and drops the line from the XCD's L2 (MI355X_MICROARCH.md, store flavours), which
-// is what a write-once stream wants; `nt` on top marks it streaming.  There is no builtin for that combination, so
-// the instruction is spelled out; it has no result, and the compiler still waits for the operands it produced.
-// The trailing `s_nop 1` is not optional: a 16-byte store reads its data registers a few cycles after issue, hipcc pads
-// that hazard for its own stores only, and without the two wait states the instruction after the asm may overwrite
-// them -- seen as stale dwords in lanes 12..15 of every 16 once a store sat inside an unrolled loop (the 4-sub-tile
-// shifted inverse).
+// Streaming 16-byte store: streaming_store.h (policy measurements and the wait states its inline asm needs)
 __device__ __forceinline__ void gstore16(void* p, u32x4 v)
 {
 #if DXTLT_NONTEMPORAL
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    store_streaming16(p, v);
 #else
     *reinterpret_cast<u32x4*>(p) = v;
 #endif

@@ -9,6 +9,7 @@
 
 #include "bcn_launch.h"
 #include "launch_grid.h"
+#include "streaming_store.h"
 #include "ycocg_swar.h"
 
 namespace dxtlt {
@@ -53,7 +54,7 @@ ycocg_array_kernel(const uint8_t* in, uint8_t* out, uint64_t vecs, uint64_t sing
         const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + 16 * i));
         const u32x4 r = {ycocg2_rt<INVERSE>(variant, q.x), ycocg2_rt<INVERSE>(variant, q.y), ycocg2_rt<INVERSE>(variant, q.z),
                          ycocg2_rt<INVERSE>(variant, q.w)};
-        __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(out + 16 * i));
+        store_streaming16(out + 16 * i, r);
     } else if (i < vecs + singles) {
         const uint64_t c = 8 * vecs + (i - vecs);
         st_u16(out + 2 * c, ycocg2_rt<INVERSE>(variant, ld_u16(in + 2 * c)) & 0xFFFFu);
@@ -79,7 +80,7 @@ recorrelate_split_kernel(const uint8_t* src0, const uint8_t* src1, uint8_t* dst,
         u32x4 r = zip16(a, b);
         r = u32x4{ycocg2_rt<true>(variant, r.x), ycocg2_rt<true>(variant, r.y), ycocg2_rt<true>(variant, r.z),
                   ycocg2_rt<true>(variant, r.w)};
-        __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(dst + 16 * i));
+        store_streaming16(dst + 16 * i, r);
     } else if (i < vecs + singles) {
         const uint64_t p = 4 * vecs + (i - vecs);
         const uint32_t v = ycocg2_rt<true>(variant, ld_u16(src0 + 2 * p) | (ld_u16(src1 + 2 * p) << 16));
@@ -101,6 +102,7 @@ split_endpoints_kernel(const uint8_t* in, uint8_t* out, uint64_t num_pairs, uint
                           (r.z & 0xFFFFu) | (r.w << 16)};
         const u32x4 c1 = {(q.x >> 16) | (q.y & 0xFFFF0000u), (q.z >> 16) | (q.w & 0xFFFF0000u), (r.x >> 16) | (r.y & 0xFFFF0000u),
                           (r.z >> 16) | (r.w & 0xFFFF0000u)};
+        // two output streams per lane: the plain nontemporal store measured 0.786 here, the write-through one 0.756
         __builtin_nontemporal_store(c0, reinterpret_cast<u32x4*>(out + 16 * i));
         __builtin_nontemporal_store(c1, reinterpret_cast<u32x4*>(out1 + 16 * i));
     } else if (i < vecs + singles) {
