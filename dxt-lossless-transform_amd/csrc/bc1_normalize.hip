@@ -12,6 +12,7 @@
 #include "bc1_normalize.h"
 #include "bcn_launch.h"
 #include "launch_grid.h"
+#include "streaming_store.h"
 
 namespace dxtlt {
 namespace {
@@ -60,7 +61,7 @@ normalize_blocks_kernel(const uint8_t* in, uint8_t* out, uint64_t pairs, uint64_
         uint32_t ca = q.x, xa = q.y, cb = q.z, xb = q.w;
         normalize_bc1_block_rt(mode, ca, xa);
         normalize_bc1_block_rt(mode, cb, xb);
-        __builtin_nontemporal_store(u32x4{ca, xa, cb, xb}, reinterpret_cast<u32x4*>(out + 16 * i));
+        store_streaming16(out + 16 * i, u32x4{ca, xa, cb, xb});
     } else if (i < pairs + singles) {
         const uint64_t b = 2 * pairs + (i - pairs);
         const bool a4 = is_aligned(in, 4) && is_aligned(out, 4);

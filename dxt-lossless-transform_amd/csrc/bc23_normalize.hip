@@ -9,6 +9,7 @@
 #include "bc23_normalize.h"
 #include "bcn_launch.h"
 #include "launch_grid.h"
+#include "streaming_store.h"
 
 namespace dxtlt {
 namespace {
@@ -52,7 +53,7 @@ __device__ __forceinline__ void load_block(const uint8_t* p, bool vec, uint32_t 
 __device__ __forceinline__ void store_block16(uint8_t* p, bool vec, const uint32_t (&q)[4])
 {
     if (vec) {
-        __builtin_nontemporal_store(u32x4{q[0], q[1], q[2], q[3]}, reinterpret_cast<u32x4*>(p));
+        store_streaming16(p, u32x4{q[0], q[1], q[2], q[3]});
     } else {
         const bool a4 = (reinterpret_cast<uintptr_t>(p) & 3) == 0;
 #pragma unroll
