@@ -106,32 +106,42 @@ __global__ void __launch_bounds__(kDecThreads)
 pixel_difference_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t num_blocks,
                         unsigned long long* __restrict__ count)
 {
+    // four blocks per lane and step, the eight loads issued before the first compare
+    constexpr int U = 4;
     unsigned long long mine = 0;   // wave-uniform
-    const uint64_t stride = (uint64_t)gridDim.x * kDecThreads;
-    for (uint64_t base = (uint64_t)blockIdx.x * kDecThreads; base < num_blocks; base += stride) {
-        const uint64_t i = base + threadIdx.x;
-        bool differs = false;
-        if (i < num_blocks) {
-            uint32_t qa[4], qb[4];
-            if (ALIGNED) {
-                load_block<FMT>(a, i, qa);
-                load_block<FMT>(b, i, qb);
-            } else {
-                load_block_bytes<FMT>(a, i, qa);
-                load_block_bytes<FMT>(b, i, qb);
+    const uint64_t stride = (uint64_t)gridDim.x * (kDecThreads * U);
+    for (uint64_t base = (uint64_t)blockIdx.x * (kDecThreads * U); base < num_blocks; base += stride) {
+        uint32_t qa[U][4], qb[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = base + (uint64_t)(u * kDecThreads) + threadIdx.x;
+            qa[u][0] = qa[u][1] = qa[u][2] = qa[u][3] = 0;
+            qb[u][0] = qb[u][1] = qb[u][2] = qb[u][3] = 0;
+            if (i < num_blocks) {
+                if (ALIGNED) {
+                    load_block<FMT>(a, i, qa[u]);
+                    load_block<FMT>(b, i, qb[u]);
+                } else {
+                    load_block_bytes<FMT>(a, i, qa[u]);
+                    load_block_bytes<FMT>(b, i, qb[u]);
+                }
             }
-            if (qa[0] != qb[0] || qa[1] != qb[1] || qa[2] != qb[2] || qa[3] != qb[3]) {
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool differs = false;   // blocks past the end were both read as zeros
+            if (qa[u][0] != qb[u][0] || qa[u][1] != qb[u][1] || qa[u][2] != qb[u][2] || qa[u][3] != qb[u][3]) {
                 uint32_t pa[16], pb[16];
-                decode_block_px<FMT>(qa, pa);
-                decode_block_px<FMT>(qb, pb);
+                decode_block_px<FMT>(qa[u], pa);
+                decode_block_px<FMT>(qb[u], pb);
                 uint32_t x = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                     x |= pa[k] ^ pb[k];
                 differs = x != 0;
             }
+            mine += (unsigned long long)__popcll(__ballot(differs));
         }
-        mine += (unsigned long long)__popcll(__ballot(differs));
     }
     if ((threadIdx.x & 63) == 0 && mine != 0)
         atomicAdd(count, mine);
@@ -158,7 +168,7 @@ hipError_t decode_fmt(const void* in, void* out, uint64_t n, hipStream_t stream)
 template <int FMT>
 hipError_t difference_fmt(const void* a, const void* b, uint64_t n, unsigned long long* count, hipStream_t stream)
 {
-    uint64_t wgs = (n + kDecThreads - 1) / kDecThreads;
+    uint64_t wgs = (n + kDecThreads * 4 - 1) / (kDecThreads * 4);   // four blocks per lane and step
     if (wgs > kDifferenceGrid)
         wgs = kDifferenceGrid;
     const uintptr_t al = FMT == 1 ? 8 : 16;
