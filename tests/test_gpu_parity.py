@@ -360,6 +360,89 @@ def test_concurrent_callers(pkg, oracle, dev):
     assert not errors, errors
 
 
+def test_concurrent_callers_of_every_family(pkg, oracle, dev):
+    """The same, across the families that share a thread's staging buffers and scratch: transforms, BC7, block
+    normalisation, decoders, colour arrays and the pixel difference count, each from its own thread and all at once."""
+    import threading
+
+    from dxt_lossless_transform_amd import bc7, color565, decode, normalize, normalize23
+
+    rng = np.random.default_rng(0xFA111E5)
+    n = 40_003
+    bc1 = rng.integers(0, 256, 8 * n, dtype=np.uint8)
+    bc1.reshape(n, 8)[::3, 4:] = 0                                   # normalisable blocks
+    bc3 = rng.integers(0, 256, 16 * n, dtype=np.uint8)
+    bc3.reshape(n, 16)[::4, 2:8] = 0
+    bc7_blocks = oracle.generate_bc7_mode_mixed(n, 0xB7) if hasattr(oracle, "generate_bc7_mode_mixed") else rng.integers(
+        0, 256, 16 * n, dtype=np.uint8)
+    cols = rng.integers(0, 256, 2 * 60_001, dtype=np.uint8)
+    want = {
+        "norm1": oracle.normalize_bc1_blocks(bc1, 1),
+        "norm3": oracle.normalize_bc3_blocks(bc3, 1, 2),
+        "dec1": oracle.decode_blocks("bc1", bc1),
+        "dec3": oracle.decode_blocks("bc3", bc3),
+        "fwd3": oracle.transform("bc3", bc3, 1, True, True),
+        "diff": oracle.count_pixel_differences("bc1", bc1, oracle.normalize_bc1_blocks(bc1, 2)),
+    }
+    errors = []
+
+    def guarded(fn):
+        def run():
+            try:
+                for _ in range(5):
+                    fn()
+            except Exception as e:  # noqa: BLE001 - collected and re-raised on the main thread
+                errors.append(e)
+        return run
+
+    def t_norm1():
+        out = np.zeros_like(bc1)
+        normalize.normalize_blocks(bc1, out, normalize.ColorNormalizationMode.COLOR0_ONLY)
+        assert np.array_equal(out, want["norm1"])
+
+    def t_norm3():
+        out = np.zeros_like(bc3)
+        normalize23.normalize_blocks("bc3", bc3, out, normalize.ColorNormalizationMode.REPLICATE_COLOR,
+                                     normalize23.AlphaNormalizationMode.UNIFORM_ALPHA_ZERO_INDICES)
+        assert np.array_equal(out, want["norm3"])
+
+    def t_dec():
+        out = np.zeros(64 * n, dtype=np.uint8)
+        decode.decode_blocks("bc1", bc1, out)
+        assert np.array_equal(out, want["dec1"])
+        decode.decode_blocks("bc3", bc3, out)
+        assert np.array_equal(out, want["dec3"])
+
+    def t_diff():
+        assert decode.count_pixel_differences("bc1", bc1, want["norm1"]) == 0
+        assert decode.count_pixel_differences("bc1", bc1, oracle.normalize_bc1_blocks(bc1, 2)) == want["diff"] == 0
+
+    def t_cols():
+        out = np.zeros_like(cols)
+        color565.decorrelate_ycocg_r(cols, out, 3)
+        back = np.zeros_like(cols)
+        color565.recorrelate_ycocg_r(out, back, 3)
+        assert np.array_equal(back, cols) and not np.array_equal(out, cols)
+
+    def t_bc7():
+        y, z = np.zeros_like(bc7_blocks), np.zeros_like(bc7_blocks)
+        bc7.transform_bc7(bc7_blocks, y)
+        bc7.untransform_bc7(y, z)
+        assert np.array_equal(z, bc7_blocks)
+
+    def t_fwd3():
+        y = np.zeros_like(bc3)
+        pkg.transform_bc3_with_settings(bc3, y)
+        assert np.array_equal(y, want["fwd3"])
+
+    threads = [threading.Thread(target=guarded(f)) for f in (t_norm1, t_norm3, t_dec, t_diff, t_cols, t_bc7, t_fwd3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
     n = 9 * 2048 + 123
