@@ -77,10 +77,12 @@ __global__ void __launch_bounds__(kThreads)
 bc7_hist_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ first_out, uint32_t* __restrict__ hist,
              uint64_t n_blocks, uint64_t num_tiles)
 {
-    // One tile per WAVE: lane l reads byte 0 (the low dword) of blocks i*64 + l, i = 0..15, all sixteen loads in
-    // flight; no workgroup barrier.  The tile's 1024 first bytes leave through the wave's 1 KiB of LDS as 64 lanes x
-    // 16 bytes.  History (4 GiB, tools/read_lab.hip for the ceiling): one tile per workgroup with a byte store per
+    // One tile per WAVE: lane l reads byte 0 (the low dword) of blocks i*64 + l, i = 0..15, no workgroup barrier.  The
+    // tile's 1024 first bytes leave through the wave's 1 KiB of LDS as 64 lanes x 16 bytes.  History (4 GiB, tools/read_lab.hip for the ceiling): one tile per workgroup with a byte store per
     // block 0.776 ms; the same with the first bytes through LDS 0.744 ms; a kernel that only reads these dwords 0.593 ms.
+    // hipcc gives each conditional load below its own branch and `s_waitcnt vmcnt(0)`, so a wave has ONE load in flight
+    // at a time -- and that is the fast form here: branch-free (clamped) loads with sixteen or with four in flight
+    // both took 0.80 ms against 0.69 ms (profiles/r01_z/bc7_hist_per_wave.txt).
     __shared__ __attribute__((aligned(16))) uint8_t firsts[kThreads / 64][kTileBlocks];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * (kThreads / 64) + wave;

@@ -111,26 +111,28 @@ pixel_difference_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict
     unsigned long long mine = 0;   // wave-uniform
     const uint64_t stride = (uint64_t)gridDim.x * (kDecThreads * U);
     for (uint64_t base = (uint64_t)blockIdx.x * (kDecThreads * U); base < num_blocks; base += stride) {
+        // branch-free loads (a load under a per-element condition gets its own branch and `s_waitcnt vmcnt(0)`): lanes
+        // past the end read the last block of both arrays, which compares equal to itself only if the arrays agree
+        // there -- so their result is masked below
         uint32_t qa[U][4], qb[U][4];
+        bool inside[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t i = base + (uint64_t)(u * kDecThreads) + threadIdx.x;
-            qa[u][0] = qa[u][1] = qa[u][2] = qa[u][3] = 0;
-            qb[u][0] = qb[u][1] = qb[u][2] = qb[u][3] = 0;
-            if (i < num_blocks) {
-                if (ALIGNED) {
-                    load_block<FMT>(a, i, qa[u]);
-                    load_block<FMT>(b, i, qb[u]);
-                } else {
-                    load_block_bytes<FMT>(a, i, qa[u]);
-                    load_block_bytes<FMT>(b, i, qb[u]);
-                }
+            inside[u] = i < num_blocks;
+            const uint64_t ic = inside[u] ? i : num_blocks - 1;
+            if (ALIGNED) {
+                load_block<FMT>(a, ic, qa[u]);
+                load_block<FMT>(b, ic, qb[u]);
+            } else {
+                load_block_bytes<FMT>(a, ic, qa[u]);
+                load_block_bytes<FMT>(b, ic, qb[u]);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            bool differs = false;   // blocks past the end were both read as zeros
-            if (qa[u][0] != qb[u][0] || qa[u][1] != qb[u][1] || qa[u][2] != qb[u][2] || qa[u][3] != qb[u][3]) {
+            bool differs = false;
+            if (inside[u] && (qa[u][0] != qb[u][0] || qa[u][1] != qb[u][1] || qa[u][2] != qb[u][2] || qa[u][3] != qb[u][3])) {
                 uint32_t pa[16], pb[16];
                 decode_block_px<FMT>(qa[u], pa);
                 decode_block_px<FMT>(qb[u], pb);

@@ -766,6 +766,8 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
     }
     const bool has_tail = t < S.n && shift_t > 0;
     const bool tail_inside = g_t + 16 <= total_bytes;
+    // (Making these two loads branch-free -- every lane also loading a "tail", lanes without one re-reading their main
+    // segment -- cost 0.08 of peak: the second load instruction is not free even when it hits L1.)
     u32x4 v_tail = {0, 0, 0, 0};
     if (has_tail && tail_inside)
         v_tail = gload16(soa + g_t);
