@@ -3,9 +3,11 @@
 // Reference citations for every rule are in the header.
 #include "../../include/dxtlt_file_formats.h"
 
+#include <atomic>
 #include <cstring>
 
 #include "host_common.h"
+#include "../../include/dxtlt_bc7.h"
 
 namespace {
 
@@ -171,6 +173,10 @@ int32_t map_device_status(int32_t st)
 // format_conversion.rs: only BC1/BC2 upstream; BC3 additive here
 int dds_to_bcn(uint8_t fmt) { return fmt == BC1 ? 1 : fmt == BC2 ? 2 : fmt == BC3 ? 3 : 0; }
 
+// BC7 payloads: refused as upstream (dispatch.rs knows no BC7 transform) unless the caller opts in to this build's own
+// mode-split format (include/dxtlt_bc7.h); TransformFormat::Bc7 = 3 exists upstream, its data bits are unassigned
+std::atomic<bool> g_bc7_enabled{false};
+
 int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len,
                              const DltSizeEstimator* estimator, bool use_all, uint8_t mode, bool sa, bool sc)
 {
@@ -184,6 +190,19 @@ int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* ou
     const size_t off = info.DataOffset, length = info.DataLength;
     if (input_len < off + length)
         return DXTLT_FF_INPUT_TOO_SHORT;
+    if (info.Format == BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
+        // no settings and nothing to estimate: version 0 of the mode-split format has one layout
+        if (length % 16 != 0)
+            return DXTLT_FF_INVALID_DATA_ALIGNMENT;
+        std::memcpy(output, input, off);
+        const int32_t st7 = dxtlt_transform_bc7(input + off, output + off, length);
+        if (st7 != dxtlt_host::kOk)
+            return map_device_status(st7);
+        if (input_len > off + length)
+            std::memcpy(output + off + length, input + off + length, input_len - off - length);
+        wr32(output, dxtlt_transform_header_pack(DXTLT_TF_BC7, 0, false, false));
+        return DXTLT_FF_OK;
+    }
     const int bcn = dds_to_bcn(info.Format);
     if (bcn == 0)
         return DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT;
@@ -255,6 +274,8 @@ int32_t dxtlt_transform_header_unpack(uint32_t header, int32_t* transform_format
     return DXTLT_FF_OK;
 }
 
+void dxtlt_file_formats_enable_bc7(bool enabled) { g_bc7_enabled.store(enabled, std::memory_order_relaxed); }
+
 bool is_dds(const uint8_t* ptr, size_t len)
 {
     if (ptr == nullptr || len == 0)
@@ -310,6 +331,20 @@ int32_t dxtlt_dds_untransform(const uint8_t* input, size_t input_len, uint8_t* o
     uint8_t mode = 0;
     bool sa = false, sc = false;
     // dispatch_untransform (handlers/dispatch.rs:39-): format first, then the details, then the alignment
+    if ((header & 0xF) == DXTLT_TF_BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
+        if ((header >> 4) != 0)
+            return DXTLT_FF_CORRUPTED_EMBEDDED_DATA;  // version 0 of the BC7 format has no data bits
+        if (length % 16 != 0)
+            return DXTLT_FF_INVALID_DATA_ALIGNMENT;
+        wr32(output, kDdsMagic);
+        std::memcpy(output + 4, input + 4, off - 4);
+        const int32_t st7 = dxtlt_untransform_bc7(input + off, output + off, length);
+        if (st7 != dxtlt_host::kOk)
+            return map_device_status(st7);
+        if (input_len > off + length)
+            std::memcpy(output + off + length, input + off + length, input_len - off - length);
+        return DXTLT_FF_OK;
+    }
     if ((header & 0xF) > DXTLT_TF_BC3)
         return DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT;
     int32_t rc = dxtlt_transform_header_unpack(header, &tf, &mode, &sa, &sc);

@@ -101,6 +101,14 @@ int32_t dxtlt_dds_transform_auto(const uint8_t *input, size_t input_len, uint8_t
 /* DdsHandler::untransform: read the TransformHeader from the first 4 bytes, restore the magic, untransform. */
 int32_t dxtlt_dds_untransform(const uint8_t *input, size_t input_len, uint8_t *output, size_t output_len);
 
+/* ADDITIVE, off by default.  Upstream knows no BC7 transform and its dispatch refuses BC7 payloads
+ * (handlers/dispatch.rs), which the three functions above reproduce (DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT).  With this
+ * switch on (process-wide), BC7 DDS payloads go through this build's own mode-split format (dxtlt_bc7.h,
+ * docs/BC7_FORMAT.md) and the header carries TransformFormat::Bc7 = 3 (embed/transform_format.rs:18) with all data
+ * bits zero (format version 0 has no settings); dxtlt_dds_untransform then accepts such files.  Only this build can
+ * read them back. */
+void dxtlt_file_formats_enable_bc7(bool enabled);
+
 #ifdef __cplusplus
 }
 #endif

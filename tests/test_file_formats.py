@@ -207,3 +207,40 @@ def test_dds_auto_transform(lib, oracle):
         r = np.zeros_like(d)
         assert lib.dxtlt_dds_untransform(t.ctypes.data, t.size, r.ctypes.data, r.size) == 0
         assert np.array_equal(r, d)
+
+
+def test_bc7_switch_is_off_by_default_and_needs_no_device(lib):
+    """Upstream's dispatch refuses BC7; so do the handler functions unless the caller opts in to this build's format."""
+    lib.dxtlt_file_formats_enable_bc7.argtypes, lib.dxtlt_file_formats_enable_bc7.restype = [C.c_bool], None
+    d = dds_file("bc7")
+    out = np.zeros_like(d)
+    assert lib.dxtlt_dds_transform(d.ctypes.data, d.size, out.ctypes.data, out.size, 1, False, True) == 4
+    hdr = np.concatenate([np.frombuffer(struct.pack("<I", 3), dtype=np.uint8), d[4:]])   # TransformFormat::Bc7, no data bits
+    assert lib.dxtlt_dds_untransform(hdr.ctypes.data, hdr.size, out.ctypes.data, out.size) == 4
+    lib.dxtlt_file_formats_enable_bc7(True)
+    try:
+        bad = np.concatenate([np.frombuffer(struct.pack("<I", 3 | (1 << 6)), dtype=np.uint8), d[4:]])
+        assert lib.dxtlt_dds_untransform(bad.ctypes.data, bad.size, out.ctypes.data, out.size) == 5   # corrupted data bits
+    finally:
+        lib.dxtlt_file_formats_enable_bc7(False)
+
+
+@pytest.mark.gpu
+def test_bc7_dds_roundtrip_when_enabled(lib, oracle):
+    lib.dxtlt_file_formats_enable_bc7.argtypes, lib.dxtlt_file_formats_enable_bc7.restype = [C.c_bool], None
+    d = np.concatenate([dds_file("bc7"), np.arange(21, dtype=np.uint8)])
+    info = lib.parse_dds(d.ctypes.data, d.size)
+    off, length = info.DataOffset, info.DataLength
+    assert info.Format == BC7 and off + length == d.size - 21
+    lib.dxtlt_file_formats_enable_bc7(True)
+    try:
+        t = np.zeros_like(d)
+        assert lib.dxtlt_dds_transform(d.ctypes.data, d.size, t.ctypes.data, t.size, 1, False, True) == 0
+        assert struct.unpack("<I", t[:4].tobytes())[0] == 3
+        assert np.array_equal(t[4:off], d[4:off]) and np.array_equal(t[-21:], d[-21:])
+        assert np.array_equal(t[off:off + length], oracle.transform_bc7(d[off:off + length]))
+        r = np.zeros_like(d)
+        assert lib.dxtlt_dds_untransform(t.ctypes.data, t.size, r.ctypes.data, r.size) == 0
+        assert np.array_equal(r, d)
+    finally:
+        lib.dxtlt_file_formats_enable_bc7(False)
