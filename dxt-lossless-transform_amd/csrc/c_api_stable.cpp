@@ -11,6 +11,7 @@
 #include <new>
 
 #include "host_common.h"
+#include "../../include/dxtlt_bc7.h"
 
 namespace {
 
@@ -217,6 +218,52 @@ const char* dltbc3_error_message(int32_t code)
                    "Null pointer provided for Dltbc3TransformSettings parameter",
                    "Null pointer provided for Dltbc3ManualTransformBuilder parameter",
                    "Null pointer provided for Dltbc3EstimateSettingsBuilder parameter");
+}
+
+// ---- BC7 (additive, include/dltbc7.h): the mode-split format has no settings, so the builder is an empty handle ----
+struct Bc7Builder {
+    uint8_t format_version = 0;
+};
+
+Bc7Builder* dltbc7_new_ManualTransformBuilder(void) { return new (std::nothrow) Bc7Builder; }
+void dltbc7_free_ManualTransformBuilder(Bc7Builder* b) { delete b; }
+Bc7Builder* dltbc7_clone_ManualTransformBuilder(const Bc7Builder* b) { return b ? new (std::nothrow) Bc7Builder(*b) : nullptr; }
+void dltbc7_ManualTransformBuilder_ResetToDefaults(Bc7Builder* b)
+{
+    if (b) *b = Bc7Builder{};
+}
+
+static StableResult bc7_run(bool inverse, const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len,
+                            const Bc7Builder* b)
+{
+    if (input == nullptr)
+        return {kNullDataPointer};
+    if (output == nullptr)
+        return {kNullOutputBufferPointer};
+    if (b == nullptr)
+        return {kNullManualTransformBuilderPointer};
+    if (input_len % 16 != 0)
+        return {kInvalidLength};
+    if (output_len < input_len)
+        return {kOutputBufferTooSmall};
+    return {map_status(inverse ? dxtlt_untransform_bc7(input, output, input_len) : dxtlt_transform_bc7(input, output, input_len))};
+}
+
+StableResult dltbc7_ManualTransformBuilder_Transform(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, Bc7Builder* b)
+{
+    return bc7_run(false, in, in_len, out, out_len, b);
+}
+StableResult dltbc7_ManualTransformBuilder_Untransform(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len, Bc7Builder* b)
+{
+    return bc7_run(true, in, in_len, out, out_len, b);
+}
+
+const char* dltbc7_error_message(int32_t code)
+{
+    return message(code, "Invalid input length: Length must be divisible by 16 (BC7 block size)",
+                   "Null pointer provided for Dltbc7TransformSettings parameter",
+                   "Null pointer provided for Dltbc7ManualTransformBuilder parameter",
+                   "Null pointer provided for Dltbc7EstimateSettingsBuilder parameter");
 }
 
 const char* dltbc2_error_message(int32_t code)

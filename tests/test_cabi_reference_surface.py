@@ -126,3 +126,59 @@ def test_struct_layouts_match_headers():
     assert C.sizeof(cabi.CoreSettings2) == 2 and C.sizeof(cabi.CoreSettings3) == 3
     assert C.sizeof(cabi.DltSizeEstimator) == 3 * C.sizeof(C.c_void_p)
     assert C.sizeof(cabi.Result) == 4
+
+
+class _StableResult(C.Structure):
+    _fields_ = [("ErrorCode", C.c_int32)]
+
+
+def _bind_bc7(pkg):
+    l = C.CDLL(pkg._lib.lib_path())
+    vp, sz = C.c_void_p, C.c_size_t
+    l.dltbc7_new_ManualTransformBuilder.restype = vp
+    l.dltbc7_free_ManualTransformBuilder.argtypes = [vp]
+    l.dltbc7_clone_ManualTransformBuilder.argtypes, l.dltbc7_clone_ManualTransformBuilder.restype = [vp], vp
+    l.dltbc7_ManualTransformBuilder_ResetToDefaults.argtypes = [vp]
+    for d in ("Transform", "Untransform"):
+        f = getattr(l, "dltbc7_ManualTransformBuilder_" + d)
+        f.argtypes, f.restype = [vp, sz, vp, sz, vp], _StableResult
+    l.dltbc7_error_message.argtypes, l.dltbc7_error_message.restype = [C.c_int32], C.c_char_p
+    return l
+
+
+def test_bc7_stable_style_builder_checks(pkg):
+    """include/dltbc7.h (additive): the BC1/BC2 builder shape, codes and check order for this build's BC7 format."""
+    l = _bind_bc7(pkg)
+    b = l.dltbc7_new_ManualTransformBuilder()
+    assert b
+    l.dltbc7_free_ManualTransformBuilder(None)
+    assert l.dltbc7_clone_ManualTransformBuilder(None) is None
+    c = l.dltbc7_clone_ManualTransformBuilder(b)
+    assert c and c != b
+    l.dltbc7_ManualTransformBuilder_ResetToDefaults(None)
+    x, y = np.frombuffer(DATA16 * 2, dtype=np.uint8).copy(), buf(32)
+    for d in ("Transform", "Untransform"):
+        f = getattr(l, "dltbc7_ManualTransformBuilder_" + d)
+        assert f(None, 32, y.ctypes.data, 32, b).ErrorCode == 5
+        assert f(x.ctypes.data, 32, None, 32, b).ErrorCode == 9
+        assert f(x.ctypes.data, 32, y.ctypes.data, 32, None).ErrorCode == 10
+        assert f(x.ctypes.data, 17, y.ctypes.data, 32, b).ErrorCode == 1
+        assert f(x.ctypes.data, 32, y.ctypes.data, 8, b).ErrorCode == 2
+        assert f(x.ctypes.data, 0, y.ctypes.data, 0, b).ErrorCode == 0      # nothing to do: no device needed
+    assert l.dltbc7_error_message(1) == b"Invalid input length: Length must be divisible by 16 (BC7 block size)"
+    assert l.dltbc7_error_message(10) == b"Null pointer provided for Dltbc7ManualTransformBuilder parameter"
+    l.dltbc7_free_ManualTransformBuilder(b)
+    l.dltbc7_free_ManualTransformBuilder(c)
+
+
+@pytest.mark.gpu
+def test_bc7_stable_style_builder_round_trip(pkg, oracle):
+    l = _bind_bc7(pkg)
+    b = l.dltbc7_new_ManualTransformBuilder()
+    x = np.fromfile(__import__("os").path.join(__import__("helpers").GOLDEN, "r2-256-bc7.payload.bin"), dtype=np.uint8)
+    y, z = np.zeros_like(x), np.zeros_like(x)
+    assert l.dltbc7_ManualTransformBuilder_Transform(x.ctypes.data, x.size, y.ctypes.data, y.size, b).ErrorCode == 0
+    assert np.array_equal(y, oracle.transform_bc7(x))
+    assert l.dltbc7_ManualTransformBuilder_Untransform(y.ctypes.data, y.size, z.ctypes.data, z.size, b).ErrorCode == 0
+    assert np.array_equal(z, x)
+    l.dltbc7_free_ManualTransformBuilder(b)
