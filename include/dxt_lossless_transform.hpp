@@ -28,6 +28,7 @@
 
 #include "dxtlt_bc1_normalize.h"
 #include "dxtlt_bc23_normalize.h"
+#include "dxtlt_bc7.h"
 #include "dxtlt_color565.h"
 #include "dxtlt_decode.h"
 #include "dxtlt_gfx950.h"
@@ -550,6 +551,30 @@ struct Error {  // Bc1Error<E> / Bc2Error<E> (error.rs:11-35)
 DXTLT_MANUAL_BUILDER(1)
 DXTLT_MANUAL_BUILDER(2)
 #undef DXTLT_MANUAL_BUILDER
+
+// ADDITIVE: the builder shape for this build's BC7 mode-split transform (docs/BC7_FORMAT.md; the reference has no BC7
+// transform).  Version 0 of the format has no settings, hence no setters and no auto builder.
+class Bc7ManualTransformBuilder {
+public:
+    Error transform(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len) const
+    {
+        return run(false, input, input_len, output, output_len);
+    }
+    Error untransform(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len) const
+    {
+        return run(true, input, input_len, output, output_len);
+    }
+
+private:
+    static Error run(bool inverse, const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len)
+    {
+        Error e = Error::from(core::detail_safe::validate(input_len, output_len, 16));
+        if (e.is_err())
+            return e;
+        detail::check_device(inverse ? dxtlt_untransform_bc7(input, output, input_len) : dxtlt_transform_bc7(input, output, input_len));
+        return e;
+    }
+};
 
 }  // namespace api
 }  // namespace dxt_lossless_transform

@@ -205,6 +205,16 @@ static void gpu_tests()
         Color565::recorrelate_ycocg_r_ptr_split(split, split + 3, joined, 6, core::YCoCgVariant::None);
         CHECK(std::memcmp(joined, pairs, 12) == 0);
     }
+    // BC7 builder (additive): validation as the other builders, exact round trip
+    {
+        std::vector<uint8_t> b7 = gen_bc1(2000), t7(b7.size()), r7(b7.size());   // any bytes are valid BC7 input
+        api::Bc7ManualTransformBuilder m7;
+        CHECK(m7.transform(b7.data(), b7.size() - 1, t7.data(), t7.size()).kind == api::Error::InvalidLength);
+        CHECK(m7.transform(b7.data(), b7.size(), t7.data(), 16).kind == api::Error::OutputBufferTooSmall);
+        CHECK(m7.transform(b7.data(), b7.size(), t7.data(), t7.size()).is_ok());
+        CHECK(m7.untransform(t7.data(), t7.size(), r7.data(), r7.size()).is_ok());
+        CHECK(r7 == b7 && t7 != b7);
+    }
     // util: decoders (bc1_decode.rs / bc3_decode.rs unit vectors)
     {
         namespace ut = core::util;
