@@ -38,8 +38,9 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--size-gib", type=float, default=8.0, help="block buffer per GPU (default: the 8 GiB config)")
-    p.add_argument("--format", default="bc1", choices=["bc1", "bc2", "bc3"])
+    p.add_argument("--size-gib", type=float, default=None,
+                   help="block buffer per GPU (default: 8 GiB, BASELINE.json configs[1]/[2]; 4 GiB for --format bc7, configs[3])")
+    p.add_argument("--format", default="bc1", choices=["bc1", "bc2", "bc3", "bc7"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
     p.add_argument("--settings", default="", help="variant,split_alpha,split_colour (e.g. 0,0,1) instead of the "
@@ -118,8 +119,145 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
     return out
 
 
+def bc7_main(args) -> None:
+    """BASELINE.json configs[3]: BC7 forward (+ inverse) on a synthetic mode-mixed buffer.  Same JSON contract; the
+    transform is this build's own format (docs/BC7_FORMAT.md; the reference has none), so parity is a round trip plus the
+    build's own CPU restatement.  The `roofline` entry is the whole forward pipeline (histogram + scans + scatter)
+    priced on the algorithmic 2 * len; the pipeline itself moves 3 * len."""
+    import torch
+
+    import dxt_lossless_transform_amd as pkg
+    from dxt_lossless_transform_amd import bc7
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
+    backend = os.environ.get("DXTLT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    pkg.load()
+    nbytes = int((args.size_gib if args.size_gib else 4.0) * (1 << 30))
+    nbytes -= nbytes % (16 * 2048)
+    blocks = nbytes // 16
+    seed = 0x0BC70004
+    x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, seed, rank * (nbytes // 8))
+    # mode-mixed (SURVEY.md 8(d) item 4): mode m uniform in 0..7, low m+1 bits of byte 0 = 1 << m
+    b = x.view(-1, 16)
+    for lo in range(0, blocks, 1 << 26):
+        v = b[lo:lo + (1 << 26)]
+        m = (v[:, 15] & 7).to(torch.int32)
+        low = ((2 << m) - 1).to(torch.uint8)
+        v[:, 0] = (v[:, 0] & ~low) | (1 << m).to(torch.uint8)
+        del m, low
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(bc7.workspace_bytes(nbytes), dtype=torch.uint8, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        bc7.transform_bc7(x, y, ws)
+        bc7.untransform_bc7(y, z, ws)
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        bc7.transform_bc7(x, y, ws)
+        ev[k][1].record()
+        bc7.untransform_bc7(y, z, ws)
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    ok = bool(torch.equal(z, x))
+    cpu = None
+    if rank == 0:
+        import numpy as np
+
+        from oracle import oracle_c
+
+        # the `first` stream is byte 0 of every block in order; and a 64 MiB prefix against the CPU restatement
+        ok = ok and bool(torch.equal(y[:blocks], x.view(-1, 16)[:, 0]))
+        sample = 64 << 20
+        small_y = torch.empty(sample, dtype=torch.uint8, device=dev)
+        bc7.transform_bc7(x[:sample], small_y)
+        xin = x[:sample].cpu().numpy()
+        t1 = time.perf_counter()
+        want = oracle_c.transform_bc7(xin)
+        t2 = time.perf_counter()
+        back = oracle_c.transform_bc7(want, inverse=True)
+        t3 = time.perf_counter()
+        ok = ok and bool(np.array_equal(small_y.cpu().numpy(), want)) and bool(np.array_equal(back, xin))
+        cpu = {"value": round(2 * sample / (t3 - t1) / 2**30, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+               "sample": "64 MiB of the same mode-mixed workload, forward+inverse, scalar C restatement of this build's "
+                         "own BC7 format (oracle/dxtlt_oracle_bc7.c; the reference has no BC7 transform to time)",
+               "fwd_value": round(sample / (t2 - t1) / 2**30, 3)}
+    assert ok, "GPU result differs from the oracle / round trip failed"
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    achieved = 2 * nbytes / (fwd_ms * 1e-3) / 1e9
+    achieved_inv = 2 * nbytes / (inv_ms * 1e-3) / 1e9
+    out = {
+        "metric": "GiB/s BC blocks transformed (fwd+inv)",
+        "value": round(2 * nbytes * args.steps * world / elapsed / 2**30, 2),
+        "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": f"BC7 mode-split forward+inverse (this build's own format, parity unpinned), {nbytes / 2**30:g} GiB "
+                        "synthetic mode-mixed buffer per GPU, modes 0-7 uniform (BASELINE.json configs[3])",
+            "format": "bc7", "blocks_per_gpu": blocks, "bytes_per_gpu": nbytes, "seed": hex(seed),
+            "sharding": "independent buffer per rank, no collective",
+            "bit_exact_roundtrip_and_oracle_prefix": ok,
+            "fwd_ms": round(fwd_ms, 4), "inv_ms": round(inv_ms, 4),
+            "fwd_GiBps": round(nbytes / (fwd_ms * 1e-3) / 2**30, 1), "inv_GiBps": round(nbytes / (inv_ms * 1e-3) / 2**30, 1),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "bc7 forward pipeline (bc7_hist_fwd + scans + bc7_scatter_fwd)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": 2 * nbytes, "pipeline_bytes": 3 * nbytes,
+            "inverse_kernel": {"kernel": "bc7 inverse pipeline (bc7_hist_inv + scans + bc7_gather_inv)",
+                               "achieved": round(achieved_inv, 1), "frac": round(achieved_inv / HBM_PEAK_GBPS, 4)},
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline and cpu is not None:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     args = parse_args()
+    if args.format == "bc7":
+        return bc7_main(args)
+    if args.size_gib is None:
+        args.size_gib = 8.0
     import torch
 
     import dxt_lossless_transform_amd as pkg
