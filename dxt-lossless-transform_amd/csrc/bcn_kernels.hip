@@ -241,6 +241,8 @@ __device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t 
 // Tried and dropped (profiles/r01_z/shift_probe_rotation_and_chunks.txt): handing each XCD chunks of 4 / 16 / 64
 // consecutive tiles in turn, so that the chip keeps one moving window -- slower than both this order and the identity
 // on every alignment class (BC3 forward, 128-byte aligned bases: 0.75 against 0.84 identity / 0.78 contiguous).
+// Neither did staggering the eight XCDs' starting points inside their eighths by 7 / 61 / 509 tiles (the idea: eighths of
+// a power-of-two buffer start on the same memory channel): no change (profiles/r01_z/shift_probe_xcd_stagger.txt).
 
 // ------------------------------------------------------------------------------------------------
 // Tiled kernels: one tile per workgroup.  `aos` points at the range's first block, `soa` at byte 0 of the
