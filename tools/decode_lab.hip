@@ -79,6 +79,41 @@ __global__ void __launch_bounds__(T) lab_kernel(const uint8_t* __restrict__ in, 
     }
 }
 
+// 16-byte blocks (BC2 / BC3 input rate): DEC 0 = BC1 decode of the colour half (isolates the extra 8 bytes read),
+// 2 = BC2, 3 = BC3.  WG = workgroup threads (256 or 128)
+template <int DEC, int WG>
+__global__ void __launch_bounds__(WG) lab16_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n)
+{
+    __shared__ u32x4 stage[(WG / 64) * WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t wave_first = (uint64_t)blockIdx.x * WG + 64 * wave;
+    const uint64_t b = wave_first + lane;
+    uint32_t q[4] = {0, 0, 0, 0}, px[16];
+    if (b < n) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + b);
+        q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
+    }
+    if (DEC == 0)
+        decode_bc1_block_px(q[2] ^ q[0], q[3] ^ q[1], px);
+    else if (DEC == 2)
+        decode_block_px<2>(q, px);
+    else
+        decode_block_px<3>(q, px);
+    u32x4* mine = stage + wave * WAVE;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        mine[r * ROW + lane] = u32x4{px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]};
+    __syncthreads();
+    u32x4* dst = reinterpret_cast<u32x4*>(out) + 4 * wave_first;
+    const uint64_t chunks = n > wave_first ? 4 * (n - wave_first) : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = 64 * k + lane;
+        if ((uint64_t)j < chunks)
+            store_sc1nt(dst + j, mine[(j & 3) * ROW + (j >> 2)]);
+    }
+}
+
 // store side only, no LDS: chunk j of the wave gets a value made from the lane's own block words
 template <int POLICY, int XCD>
 __global__ void __launch_bounds__(T) nolds_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n)
@@ -281,6 +316,22 @@ int main(int argc, char** argv)
         RUN(name, (walk_kernel<1, 1>), 256 * per_cu);
         std::snprintf(name, sizeof name, "walk, %u WGs per CU, plain, prefetch", per_cu);
         RUN(name, (walk_kernel<2, 1>), 256 * per_cu);
+    }
+    {
+        uint8_t* in16;
+        CHECK(hipMalloc(&in16, n * 16));
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, 0, (uint32_t*)in16, n * 4);
+        CHECK(hipDeviceSynchronize());
+        const double bytes16 = (double)n * 80;
+        auto report16 = [&](const char* name, double ms) { std::printf("%-44s %8.4f ms  %.4f of 8 TB/s\n", name, ms, bytes16 / (ms * 1e-3) / 8e12); };
+#define RUN16(name, kern, wg) report16(name, time_ms([&] { hipLaunchKernelGGL((kern), dim3((unsigned)((n + (wg) - 1) / (wg))), dim3(wg), 0, 0, in16, out, n); }))
+        RUN16("16-byte blocks, BC1 decode of half, 256 thr", (lab16_kernel<0, 256>), 256);
+        RUN16("16-byte blocks, BC2 decode, 256 thr", (lab16_kernel<2, 256>), 256);
+        RUN16("16-byte blocks, BC3 decode, 256 thr", (lab16_kernel<3, 256>), 256);
+        RUN16("16-byte blocks, BC2 decode, 128 thr", (lab16_kernel<2, 128>), 128);
+        RUN16("16-byte blocks, BC3 decode, 128 thr", (lab16_kernel<3, 128>), 128);
+        RUN16("16-byte blocks, BC1 decode of half, 128 thr", (lab16_kernel<0, 128>), 128);
+        CHECK(hipFree(in16));
     }
     RUN("direct 64 B per lane, nt", (direct_kernel<0>), g1);
     RUN("direct 64 B per lane, sc1 nt", (direct_kernel<1>), g1);
