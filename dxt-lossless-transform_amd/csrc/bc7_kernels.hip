@@ -82,7 +82,8 @@ bc7_hist_fwd(const uint8_t* __restrict__ aos, uint8_t* __restrict__ first_out, u
     // block 0.776 ms; the same with the first bytes through LDS 0.744 ms; a kernel that only reads these dwords 0.593 ms.
     // hipcc gives each conditional load below its own branch and `s_waitcnt vmcnt(0)`, so a wave has ONE load in flight
     // at a time -- and that is the fast form here: branch-free (clamped) loads with sixteen or with four in flight
-    // both took 0.80 ms against 0.69 ms (profiles/r01_z/bc7_hist_per_wave.txt).
+    // both took 0.80 ms, two in flight 0.77 ms, one branch-free load at a time 0.69 ms like the compiled form
+    // (profiles/r01_z/bc7_hist_per_wave.txt): it is the depth, not the branches.
     __shared__ __attribute__((aligned(16))) uint8_t firsts[kThreads / 64][kTileBlocks];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * (kThreads / 64) + wave;
