@@ -1,29 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- BCn block-transform hot path on MI355X: GiB/s of BC blocks transformed (forward + inverse).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
 
-Workload at every N: BASELINE.json configs[1] taken with the north-star's "forward+inverse" reading -- BC1, default
-settings {YCoCg Variant1, split colour endpoints}, an 8 GiB block buffer per GPU (2^30 blocks) of splitmix64 random
-blocks generated on the device.  One step = one forward transform of the buffer + one inverse transform of the
-result, both through the C ABI of libdxtlt_gfx950.so, inputs resident in HBM.  `value` counts the block bytes fed to
-each direction: (len + len) * steps * N / time.
+`python bench.py --gpus N` with N > 1 and no launcher environment starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` as a
+CHILD process before anything touches the GPU, relays rank 0's JSON line and exits with the child's code.  Under a
+launcher (WORLD_SIZE set, as the driver does it) it is one rank of N.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), used only for the barrier and the max-over-ranks
-reduction of the timing.  The block array shards by contiguous range; every rank transforms its own 8 GiB shard
-(weak scaling); there is no data-path collective (DESIGN.md "Multi-GPU").
+Workload: BASELINE.json configs[1] taken with the north-star's "forward+inverse" reading -- BC1, default settings
+{YCoCg Variant1, split colour endpoints}, splitmix64 random blocks generated on the device.  One step = one forward
+transform + one inverse transform of the result, both through the C ABI of libdxtlt_gfx950.so, inputs resident in
+HBM.  `value` counts the block bytes fed to each direction: (len + len) * steps / time.
+
+  --scaling weak   (default) one logical array of N x 8 GiB; rank r holds blocks [r * 2^30, (r+1) * 2^30) -- 8 GiB per
+                   GPU -- and transforms them as a stand-alone buffer (a shard's stand-alone result IS its slice of
+                   every stream, packed: DESIGN.md "Multi-GPU").  JSON "scaling": "weak".
+  --scaling strong one logical 8 GiB array whatever N; rank r owns the contiguous block range plan_shards() gives it and
+                   calls dxtlt_transform_range_device on it: AoS slice in, its slice of every stream of the WHOLE
+                   transformed buffer out (and back).  JSON "scaling": "strong".
+
+Either way there is no data-path collective: torch.distributed (backend nccl = RCCL) carries the barrier and the
+MAX-over-ranks of the elapsed time only.
 
 The JSON line also carries
-  roofline      for the dominant kernel (BC1 forward, fwd_tiled): algorithmic bytes = 16 B/block = 2*len per launch,
-                divided by the launch's average duration measured with HIP events on the launch stream
-  cpu_baseline  the C oracle (a port of the reference's scalar loops) timed on this box's host cores on a bounded
-                sample of the same workload, rank 0 at N=1 only
+  roofline            for the dominant kernel (BC1 forward, fwd_tiled): algorithmic bytes = 16 B/block = 2*len per
+                      launch, divided by the launch's average duration measured with HIP events on the launch stream
+  cpu_baseline        the CPU port of the reference's algorithm timed on this box's host cores on a bounded sample of
+                      the same workload, rank 0 at N=1 only
+  sharded_host_array  north_star's "shard by contiguous range across the GPUs, concatenate on the host": ONE host
+                      resident array, one call (dxtlt_transform_sharded) that splits it by block range over all N
+                      devices and places every shard's stream slices at their final host offsets.  PCIe included,
+                      reported beside `value`, never as `value`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +47,97 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def self_launch_if_needed(args) -> None:
+    """`python bench.py --gpus N` from a bare shell: become the parent of a torch.distributed.run job.  Runs before
+    torch is imported; the parent never initialises the GPU and never exec()s (it waits for the child)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in child.stdout:          # rank 0's JSON line (and nothing else) arrives here; relay as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(child.wait())
+
+
+class Ranks:
+    """This process's place in the job: rank / world from the launcher's environment, its device, and the only two
+    collectives the bench uses (barrier, MAX of a double)."""
+
+    def __init__(self, args, need_gpu: bool = True):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # Rehearsal knob (never set by the driver): DXTLT_BENCH_BACKEND=gloo lets several ranks share one GPU so that
+        # the N > 1 code path (rank-dependent data, barrier, MAX-reduce, rank-0 reporting) runs on a 1-GPU box.
+        self.backend = os.environ.get("DXTLT_BENCH_BACKEND", "nccl")
+        self.dev = None
+        self.dist = None
+        self.cpu_group = None
+        import torch
+
+        self.torch = torch
+        if need_gpu:
+            assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
+            n = torch.cuda.device_count()
+            index = self.local_rank if self.backend == "nccl" else self.local_rank % n
+            torch.cuda.set_device(index)
+            self.dev = torch.device("cuda", index)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            self.dist = dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+                # waiting for rank 0's host-side legs must not park a spinning RCCL kernel on every GPU
+                self.cpu_group = dist.new_group(backend="gloo")
+            else:
+                dist.init_process_group(self.backend)
+                self.cpu_group = None
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def cpu_barrier(self) -> None:
+        """A barrier that idles on the host (gloo), for waits that last seconds."""
+        if self.dist is not None:
+            self.dist.barrier(group=self.cpu_group)
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.dist is None:
+            return seconds
+        on = self.dev if self.backend == "nccl" else "cpu"
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=on)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self) -> None:
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def rendezvous_only(args) -> None:
+    """--rendezvous-only: the launcher / rank plumbing without a GPU (CPU tests): rendezvous over gloo, barrier,
+    MAX-reduce, rank 0 prints one JSON line."""
+    os.environ.setdefault("DXTLT_BENCH_BACKEND", "gloo")
+    R = Ranks(args, need_gpu=False)
+    R.barrier()
+    worst = R.max_over_ranks(float(R.rank + 1))
+    if R.rank == 0:
+        print(json.dumps({"rendezvous": "ok", "n_gpus": R.world, "max_over_ranks": worst, "backend": R.backend}), flush=True)
+    R.finish()
 
 
 def parse_args():
@@ -44,6 +151,12 @@ def parse_args():
     p.add_argument("--workload", default="buffer", choices=["buffer", "archive"],
                    help="buffer: one block buffer per GPU (configs[1..3]); archive: BASELINE.json configs[4], alternating "
                         "256 MiB BC1 / BC3 textures, --size-gib per GPU (default 8: 64 GiB over 8 GPUs)")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak: --size-gib per GPU (default); strong: --size-gib in all, split by contiguous block range")
+    p.add_argument("--host-array-gib", type=float, default=None,
+                   help="size of the host-resident array of the sharded_host_array leg (default: --size-gib for "
+                        "bc1/bc2/bc3 buffers; 0 = skip)")
+    p.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
     p.add_argument("--settings", default="", help="variant,split_alpha,split_colour (e.g. 0,0,1) instead of the "
@@ -132,24 +245,8 @@ def bc7_main(args) -> None:
     import dxt_lossless_transform_amd as pkg
     from dxt_lossless_transform_amd import bc7
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
-    backend = os.environ.get("DXTLT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    R = Ranks(args)
+    rank, world, dev = R.rank, R.world, R.dev
     pkg.load()
     nbytes = int((args.size_gib if args.size_gib else 4.0) * (1 << 30))
     nbytes -= nbytes % (16 * 2048)
@@ -168,9 +265,7 @@ def bc7_main(args) -> None:
     y, z = torch.empty_like(x), torch.empty_like(x)
     ws = torch.empty(bc7.workspace_bytes(nbytes), dtype=torch.uint8, device=dev)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = R.barrier
 
     for _ in range(args.warmup):
         bc7.transform_bc7(x, y, ws)
@@ -189,10 +284,7 @@ def bc7_main(args) -> None:
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.max_over_ranks(elapsed)
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     ok = bool(torch.equal(z, x))
@@ -220,8 +312,7 @@ def bc7_main(args) -> None:
                "fwd_value": round(sample / (t2 - t1) / 2**30, 3)}
     assert ok, "GPU result differs from the oracle / round trip failed"
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        R.finish()
         return
     achieved = 2 * nbytes / (fwd_ms * 1e-3) / 1e9
     achieved_inv = 2 * nbytes / (inv_ms * 1e-3) / 1e9
@@ -251,8 +342,7 @@ def bc7_main(args) -> None:
     if world == 1 and not args.no_cpu_baseline and cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.finish()
 
 
 def archive_main(args) -> None:
@@ -270,24 +360,8 @@ def archive_main(args) -> None:
     import dxt_lossless_transform_amd as pkg
     from oracle import oracle_c
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
-    backend = os.environ.get("DXTLT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    R = Ranks(args)
+    rank, world, dev = R.rank, R.world, R.dev
     pkg.load()
     tex_bytes = 256 << 20
     per_gpu = int((args.size_gib if args.size_gib else 8.0) * (1 << 30))
@@ -302,9 +376,7 @@ def archive_main(args) -> None:
     for i, x in enumerate(xs):
         pkg.fill_splitmix64(x, 0x0A5C0005, (rank * k + i) * (tex_bytes // 8))   # one logical 64 GiB stream of blocks
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = R.barrier
 
     def step():
         for i in range(k):
@@ -323,10 +395,7 @@ def archive_main(args) -> None:
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.max_over_ranks(elapsed)
 
     ok = all(bool(torch.equal(z, x)) for x, z in zip(xs, zs))
     win = 1 << 15
@@ -358,8 +427,7 @@ def archive_main(args) -> None:
                          "transformed_cpu_zlib6": round(tiled.size / len(zlib.compress(cpu_out.tobytes(), 6)), 4)}
     assert ok, "GPU result differs from the oracle / round trip failed"
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        R.finish()
         return
     total = 2 * k * tex_bytes * args.steps * world
     out = {
@@ -380,42 +448,88 @@ def archive_main(args) -> None:
                      "note": "wall clock of the whole step per GPU (launch gaps included), algorithmic 2 * bytes per direction"},
     }
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.finish()
+
+
+def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev) -> dict:
+    """north_star's multi-GPU statement as ONE call: a host-resident block array is split by contiguous block range over
+    every visible device and each shard's slice of every stream lands at its final host offset (dxtlt_transform_sharded;
+    the reference side of the contract is one call over the whole array, transform_with_settings.rs:31-72).  Host
+    buffers are pinned.  Checked: exact round trip of the whole array, oracle windows that straddle every shard
+    boundary."""
+    import numpy as np
+
+    from oracle import oracle_c
+
+    block = pkg.BLOCK_BYTES[fmt]
+    nbytes -= nbytes % (block * 2048)
+    blocks = nbytes // block
+    n_dev = pkg.load().dxtlt_device_count()
+    t0 = time.perf_counter()
+    h_in = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    h_soa = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    h_back = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    # the same logical array as the kernel legs, generated on the device in pieces and copied out
+    piece = min(nbytes, 1 << 30)
+    scratch = torch.empty(piece, dtype=torch.uint8, device=dev)
+    for lo in range(0, nbytes, piece):
+        n = min(piece, nbytes - lo)
+        pkg.fill_splitmix64(scratch[:n], seed, lo // 8)
+        h_in[lo:lo + n].copy_(scratch[:n])
+    torch.cuda.synchronize()
+    del scratch
+    setup_s = time.perf_counter() - t0
+    a_in, a_soa, a_back = h_in.numpy(), h_soa.numpy(), h_back.numpy()
+
+    def timed(inverse, src, dst):
+        best = None
+        for _ in range(3):
+            t = time.perf_counter()
+            pkg.transform_sharded(fmt, inverse, src, dst, settings, 0)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return best
+
+    fwd_s = timed(False, a_in, a_soa)
+    inv_s = timed(True, a_soa, a_back)
+    ok = bool(torch.equal(h_back, h_in))
+    win = 1 << 14
+    table = pkg.stream_table(fmt, settings)
+    mode, sa, sc = int(settings.decorrelation_mode), getattr(settings, "split_alpha_endpoints", True), settings.split_colour_endpoints
+    firsts = [0, blocks - win] + [max(0, f - win // 2) for f, _ in pkg.plan_shards(blocks, max(1, n_dev))[1:]]
+    for first in firsts:
+        want = oracle_c.transform(fmt, a_in[first * block:(first + win) * block], mode, sc, sa)
+        got = np.empty_like(want)
+        for off, w in table:
+            got[off * win: off * win + w * win] = a_soa[off * blocks + w * first: off * blocks + w * (first + win)]
+        ok = ok and bool(np.array_equal(got, want))
+    assert ok, "sharded host array: result differs from the oracle / round trip failed"
+    return {
+        "entry_point": "dxtlt_transform_sharded (one process, one host thread per device, chunked H2D | kernel | per-stream D2H)",
+        "array_bytes": nbytes, "devices": n_dev, "host_memory": "pinned",
+        "fwd_GiBps": round(nbytes / fwd_s / 2**30, 2), "inv_GiBps": round(nbytes / inv_s / 2**30, 2),
+        "fwd_plus_inv_GiBps": round(2 * nbytes / (fwd_s + inv_s) / 2**30, 2),
+        "bit_exact_roundtrip_and_oracle_windows_across_shard_boundaries": ok,
+        "setup_s": round(setup_s, 2),
+        "note": "host -> device -> host with placement, PCIe-bound; reported beside `value`, never as `value`",
+    }
 
 
 def main() -> None:
     args = parse_args()
+    self_launch_if_needed(args)
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     if args.workload == "archive":
         return archive_main(args)
     if args.format == "bc7":
         return bc7_main(args)
     if args.size_gib is None:
         args.size_gib = 8.0
-    import torch
+    R = Ranks(args)
+    torch, rank, world, dev = R.torch, R.rank, R.world, R.dev
 
     import dxt_lossless_transform_amd as pkg
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
-    # Rehearsal knob (never set by the driver): DXTLT_BENCH_BACKEND=gloo lets several ranks share one GPU so that the
-    # N > 1 code path (rank-dependent data, barrier, MAX-reduce, rank-0 reporting) can be exercised on a 1-GPU box.
-    backend = os.environ.get("DXTLT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
 
     pkg.load()
     if args.tile_threads or args.force_path:
@@ -429,54 +543,70 @@ def main() -> None:
         settings = {"bc1": lambda: pkg.Bc1TransformSettings(pkg.YCoCgVariant(v), bool(sc)),
                     "bc2": lambda: pkg.Bc2TransformSettings(pkg.YCoCgVariant(v), bool(sc)),
                     "bc3": lambda: pkg.Bc3TransformSettings(pkg.YCoCgVariant(v), bool(sa), bool(sc))}[fmt]()
-    fwd = getattr(pkg, f"transform_{fmt}_with_settings")
-    inv = getattr(pkg, f"untransform_{fmt}_with_settings")
-
-    nbytes = int(args.size_gib * (1 << 30))
-    nbytes -= nbytes % (block * 2048)
-    nbytes -= args.drop_blocks * block
-    blocks = nbytes // block
     seed = {"bc1": 0x0BC10002, "bc2": 0x0BC20002, "bc3": 0x0BC30003}[fmt]
+    strong = args.scaling == "strong"
+
+    size_bytes = int(args.size_gib * (1 << 30))
+    size_bytes -= size_bytes % (block * 2048)
+    size_bytes -= args.drop_blocks * block
+    if strong:
+        # ONE logical array of --size-gib; this rank owns a contiguous block range of it
+        total_blocks = size_bytes // block
+        first, blocks = pkg.plan_shards(total_blocks, world)[rank]
+    else:
+        # one logical array of world * --size-gib; rank r holds blocks [r * blocks, (r + 1) * blocks)
+        blocks = size_bytes // block
+        total_blocks, first = blocks * world, rank * blocks
+    nbytes = blocks * block
 
     x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    y = torch.empty_like(x)
     z = torch.empty_like(x)
-    # rank r holds blocks [r*blocks, (r+1)*blocks) of one logical array
-    pkg.fill_splitmix64(x, seed, rank * (nbytes // 8))
+    pkg.fill_splitmix64(x, seed, first * block // 8)
+    if strong:
+        # the WHOLE transformed buffer; the range calls touch only this rank's slice of every stream
+        y = torch.empty(total_blocks * block, dtype=torch.uint8, device=dev)
+        y_total, y_first = total_blocks, first
+
+        def fwd():
+            pkg.transform_range(fmt, False, x, y, total_blocks, first, blocks, settings)
+
+        def inv():
+            pkg.transform_range(fmt, True, y, z, total_blocks, first, blocks, settings)
+    else:
+        # stand-alone shard: its compact result is this rank's slice of every stream, packed
+        y = torch.empty_like(x)
+        y_total, y_first = blocks, 0
+        f_fwd = getattr(pkg, f"transform_{fmt}_with_settings")
+        f_inv = getattr(pkg, f"untransform_{fmt}_with_settings")
+
+        def fwd():
+            f_fwd(x, y, settings)
+
+        def inv():
+            f_inv(y, z, settings)
     torch.cuda.synchronize()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def step():
-        fwd(x, y, settings)
-        inv(y, z, settings)
-
     for _ in range(args.warmup):
-        step()
+        fwd()
+        inv()
     torch.cuda.synchronize()
 
     # per-kernel timing: HIP events on the stream the kernels are launched on (torch's current stream)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
-    barrier()
+    R.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        fwd(x, y, settings)
+        fwd()
         ev[k][1].record()
-        inv(y, z, settings)
+        inv()
         ev[k][2].record()
     torch.cuda.synchronize()
-    barrier()
+    R.barrier()
     elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.max_over_ranks(elapsed)
 
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
@@ -488,38 +618,52 @@ def main() -> None:
 
         from oracle import oracle_c
 
-        win = 1 << 16
-        first = blocks // 2 + 4097
-        xin = x[first * block:(first + win) * block].cpu().numpy()
+        win = min(1 << 16, blocks)
+        lf = min(blocks // 2 + 4097, blocks - win)
+        xin = x[lf * block:(lf + win) * block].cpu().numpy()
         want = oracle_c.transform(fmt, xin, int(settings.decorrelation_mode), settings.split_colour_endpoints,
                                   getattr(settings, "split_alpha_endpoints", True))
         got = np.empty_like(want)
         for off, w in pkg.stream_table(fmt, settings):
-            got[off * win: off * win + w * win] = y[off * blocks + w * first: off * blocks + w * (first + win)].cpu().numpy()
+            lo = off * y_total + w * (y_first + lf)
+            got[off * win: off * win + w * win] = y[lo: lo + w * win].cpu().numpy()
         bit_exact = bit_exact and bool(np.array_equal(got, want))
     assert bit_exact, "GPU result differs from the oracle / round trip failed"
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        # rank 0 still drives every device for the sharded_host_array leg; stay out of its way, then leave together
+        del x, y, z
+        torch.cuda.empty_cache()
+        R.cpu_barrier()
+        R.finish()
         return
 
-    total_in = 2 * nbytes * args.steps * world
-    value = total_in / elapsed / 2**30
+    job_bytes = (total_blocks * block) if strong else nbytes * world     # block bytes fed to one direction per step
+    value = 2 * job_bytes * args.steps / elapsed / 2**30
     achieved = 2 * nbytes / (fwd_ms * 1e-3) / 1e9  # algorithmic bytes: read len + write len
     achieved_inv = 2 * nbytes / (inv_ms * 1e-3) / 1e9
 
-    traffic = None
+    # HBM traffic is a PMC figure and PMC passes are separate runs (tools/pmc_traffic.sh): what is quoted here is the
+    # committed result of such a pass over this very workload, and says so
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
                 rec = json.load(f)
-            if rec.get("workload_bytes") == nbytes and rec.get("format") == fmt:
+            if rec.get("workload_bytes") == nbytes and rec.get("format") == fmt and not args.settings:
                 traffic = rec.get("fwd_hbm_bytes_per_launch")
+                traffic_source = (f"{rec.get('source', 'profiles/pmc_traffic.json')}: committed rocprofv3 --pmc passes over this "
+                                  "workload (FETCH_SIZE x2 per the gfx950 rule, WRITE_SIZE); NOT measured by this run")
         except Exception:
             traffic = None
 
+    dflt = "YCoCg Variant1, split colour endpoints" if fmt != "bc3" else "YCoCg Variant1, split alpha + colour endpoints"
+    if strong:
+        shape = (f"ONE logical {job_bytes / 2**30:g} GiB random block array split by contiguous block range over {world} GPU(s) "
+                 f"(dxtlt_transform_range_device: AoS slice <-> its slices of the whole transformed buffer)")
+    else:
+        shape = f"{nbytes / 2**30:g} GiB random block buffer per GPU (BASELINE.json configs[1])"
     out = {
         "metric": "GiB/s BC blocks transformed (fwd+inv)",
         "value": round(value, 2),
@@ -529,16 +673,17 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
         "config": {
             "workload": f"{fmt.upper()} forward+inverse, "
-                        + (f"settings {args.settings} (variant,split_alpha,split_colour), " if args.settings else
-                           f"default settings ({'YCoCg Variant1, split colour endpoints' if fmt != 'bc3' else 'YCoCg Variant1, split alpha + colour endpoints'}), ")
-                        + f"{nbytes / 2**30:g} GiB random block buffer per GPU (BASELINE.json configs[1])",
-            "format": fmt, "blocks_per_gpu": blocks, "bytes_per_gpu": nbytes, "seed": hex(seed),
+                        + (f"settings {args.settings} (variant,split_alpha,split_colour), " if args.settings else f"default settings ({dflt}), ")
+                        + shape,
+            "mode": ("strong scaling: one array, range-sharded" if strong else
+                     "weak scaling: one stand-alone shard of the logical array per GPU") + "; `value` = kernels only, data resident in HBM",
+            "format": fmt, "blocks_per_gpu": blocks, "bytes_per_gpu": nbytes, "total_blocks": total_blocks, "seed": hex(seed),
             "sharding": "contiguous block range per rank, no collective",
             "bit_exact_roundtrip_and_oracle_window": bit_exact,
             "fwd_ms": round(fwd_ms, 4), "inv_ms": round(inv_ms, 4),
@@ -546,19 +691,24 @@ def main() -> None:
         },
         "roofline": {
             "bound": "hbm", "kernel": f"fwd_tiled<{fmt}>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": 2 * nbytes,
             "inverse_kernel": {"kernel": f"inv_tiled<{fmt}>", "achieved": round(achieved_inv, 1),
                                "frac": round(achieved_inv / HBM_PEAK_GBPS, 4)},
         },
     }
+    host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
+    if host_gib > 0 and not args.drop_blocks:
+        del y, z
+        torch.cuda.empty_cache()
+        out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev)
+    R.cpu_barrier()
     if world == 1 and not args.no_cpu_baseline:
         s = (int(settings.decorrelation_mode), bool(getattr(settings, "split_alpha_endpoints", True)),
              bool(settings.split_colour_endpoints))
         out["cpu_baseline"] = cpu_baseline(fmt, s, args.cpu_sample_mib)
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.finish()
 
 
 if __name__ == "__main__":

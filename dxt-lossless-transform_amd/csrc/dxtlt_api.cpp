@@ -199,14 +199,39 @@ struct PipeShared {
     bool failed = false;  // uploader gave up
 };
 
-int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint8_t* in, uint8_t* out, uint64_t blocks,
-                            uint8_t mode, bool sa, bool sc, uint8_t normalize)
+// One pipelined job: blocks [first, first + count) of a host-resident array of `total` blocks, on device `dev`.
+// The device holds the range as a stand-alone array of `count` blocks (d_in / d_out of count * B bytes: AoS slice
+// and compact SoA, which IS the range's slice of every stream, packed); host offsets are those of the whole array.
+// With first = 0 and count = total this is the whole-buffer pipeline of the host-pointer entry points; with a proper
+// sub-range it is one shard of dxtlt_transform_sharded.
+struct PipeJob {
+    int dev;
+    hipStream_t up;
+    void* d_in;
+    void* d_out;
+    int32_t format;
+    bool inverse;
+    const uint8_t* in;
+    uint8_t* out;
+    uint64_t total, first, count;
+    uint8_t mode;
+    bool sa, sc;
+    uint8_t normalize;
+    uint64_t chunk_bytes;
+};
+
+int32_t pipelined_range(const PipeJob& j)
 {
-    const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
-    const dxtlt::Streams S = dxtlt::make_streams(format, format == 3 && sa, sc);
-    uint64_t chunk_blocks = pipeline_chunk_bytes(blocks * B) / B;  // a multiple of every tile size
-    const int nchunks = (int)((blocks + chunk_blocks - 1) / chunk_blocks);
-    const int dev = c.device;
+    const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)j.format);
+    const dxtlt::Streams S = dxtlt::make_streams(j.format, j.format == 3 && j.sa, j.sc);
+    const uint64_t chunk_blocks = j.chunk_bytes / B;  // a multiple of every tile size
+    const int nchunks = (int)((j.count + chunk_blocks - 1) / chunk_blocks);
+    const int dev = j.dev;
+    const int32_t format = j.format;
+    const bool inverse = j.inverse;
+    const uint64_t total = j.total, base = j.first, blocks = j.count;
+    const uint8_t* in = j.in;
+    uint8_t* out = j.out;
 
     hipStream_t down = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking), "hipStreamCreate(download)");
@@ -236,18 +261,19 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
             e = hipStreamWaitEvent(down, ev[(size_t)k], 0);
             if (!inverse) {
                 for (int s = 0; s < S.n && e == hipSuccess; ++s) {
-                    const uint64_t o = (uint64_t)S.off[s] * blocks + (uint64_t)S.width[s] * first;
-                    e = hipMemcpyAsync(out + o, (const uint8_t*)c.d_out + o, (size_t)(S.width[s] * count),
+                    const uint64_t w = (uint64_t)S.width[s], off = (uint64_t)S.off[s];
+                    e = hipMemcpyAsync(out + off * total + w * (base + first),
+                                       (const uint8_t*)j.d_out + off * blocks + w * first, (size_t)(w * count),
                                        hipMemcpyDeviceToHost, down);
                 }
             } else if (e == hipSuccess) {
-                e = hipMemcpyAsync(out + first * B, (const uint8_t*)c.d_out + first * B, (size_t)(count * B),
+                e = hipMemcpyAsync(out + (base + first) * B, (const uint8_t*)j.d_out + first * B, (size_t)(count * B),
                                    hipMemcpyDeviceToHost, down);
             }
         }
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(down);
-        down_err = e;
+        // drain whatever was enqueued, also after a failure: the events and the stream die with this call
+        hipError_t e2 = hipStreamSynchronize(down);
+        down_err = e != hipSuccess ? e : e2;
     });
 
     hipError_t up_err = hipSuccess;
@@ -256,23 +282,23 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
         const uint64_t first = (uint64_t)k * chunk_blocks;
         const uint64_t count = std::min<uint64_t>(chunk_blocks, blocks - first);
         if (!inverse) {
-            up_err = hipMemcpyAsync((uint8_t*)c.d_in + first * B, in + first * B, (size_t)(count * B),
-                                    hipMemcpyHostToDevice, c.stream);
+            up_err = hipMemcpyAsync((uint8_t*)j.d_in + first * B, in + (base + first) * B, (size_t)(count * B),
+                                    hipMemcpyHostToDevice, j.up);
             if (up_err == hipSuccess)
-                rc = device_range(format, false, (const uint8_t*)c.d_in + first * B, c.d_out, blocks, first, count, mode,
-                                  sa, sc, c.stream, normalize);
+                rc = device_range(format, false, (const uint8_t*)j.d_in + first * B, j.d_out, blocks, first, count,
+                                  j.mode, j.sa, j.sc, j.up, j.normalize);
         } else {
             for (int s = 0; s < S.n && up_err == hipSuccess; ++s) {
-                const uint64_t o = (uint64_t)S.off[s] * blocks + (uint64_t)S.width[s] * first;
-                up_err = hipMemcpyAsync((uint8_t*)c.d_in + o, in + o, (size_t)(S.width[s] * count), hipMemcpyHostToDevice,
-                                        c.stream);
+                const uint64_t w = (uint64_t)S.width[s], off = (uint64_t)S.off[s];
+                up_err = hipMemcpyAsync((uint8_t*)j.d_in + off * blocks + w * first, in + off * total + w * (base + first),
+                                        (size_t)(w * count), hipMemcpyHostToDevice, j.up);
             }
             if (up_err == hipSuccess)
-                rc = device_range(format, true, c.d_in, (uint8_t*)c.d_out + first * B, blocks, first, count, mode, sa, sc,
-                                  c.stream);
+                rc = device_range(format, true, j.d_in, (uint8_t*)j.d_out + first * B, blocks, first, count, j.mode, j.sa,
+                                  j.sc, j.up);
         }
         if (up_err == hipSuccess && rc == DXTLT_OK)
-            up_err = hipEventRecord(ev[(size_t)k], c.stream);
+            up_err = hipEventRecord(ev[(size_t)k], j.up);
         {
             std::lock_guard<std::mutex> lk(sh.m);
             if (up_err == hipSuccess && rc == DXTLT_OK)
@@ -285,8 +311,11 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
             break;
     }
     downloader.join();
+    // every exit drains the upload stream before the events go away and the staging buffers can be reused
+    // (a failed copy or launch leaves earlier chunks queued)
+    const hipError_t drain = hipStreamSynchronize(j.up);
     if (up_err == hipSuccess && rc == DXTLT_OK)
-        up_err = hipStreamSynchronize(c.stream);
+        up_err = drain;
     for (auto& e : ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(down);
     if (rc != DXTLT_OK)
@@ -296,6 +325,15 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
     if (down_err != hipSuccess)
         return fail(DXTLT_E_DEVICE, "pipelined download", down_err);
     return DXTLT_OK;
+}
+
+int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint8_t* in, uint8_t* out, uint64_t blocks,
+                            uint8_t mode, bool sa, bool sc, uint8_t normalize)
+{
+    const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
+    PipeJob j{c.device, c.stream, c.d_in, c.d_out, format, inverse, in, out, blocks, 0, blocks, mode, sa, sc, normalize,
+              pipeline_chunk_bytes(blocks * B)};
+    return pipelined_range(j);
 }
 
 }  // namespace
@@ -333,12 +371,23 @@ int32_t dxtlt_host::transform(int32_t format, bool inverse, const uint8_t* in, u
     const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
     if (len >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0)
         return pipelined_transform(c, format, inverse, in, out, blocks, mode, sa, sc, normalize);
-    HIP_TRY(hipMemcpyAsync(c.d_in, in, len, hipMemcpyHostToDevice, c.stream), "H2D copy");
-    rc = device_range(format, inverse, c.d_in, c.d_out, blocks, 0, blocks, mode, sa, sc, c.stream, normalize);
-    if (rc != DXTLT_OK)
-        return rc;
-    HIP_TRY(hipMemcpyAsync(out, c.d_out, len, hipMemcpyDeviceToHost, c.stream), "D2H copy");
-    HIP_TRY(hipStreamSynchronize(c.stream), "stream synchronize");
+    // Every failure exit drains the stream first: the staging buffers belong to this thread's next call, which may
+    // free or regrow them while an earlier copy or kernel of this one is still queued.
+    hipError_t e = hipMemcpyAsync(c.d_in, in, len, hipMemcpyHostToDevice, c.stream);
+    const char* what = "H2D copy";
+    if (e == hipSuccess) {
+        rc = device_range(format, inverse, c.d_in, c.d_out, blocks, 0, blocks, mode, sa, sc, c.stream, normalize);
+        if (rc != DXTLT_OK) {
+            (void)hipStreamSynchronize(c.stream);
+            return rc;
+        }
+        e = hipMemcpyAsync(out, c.d_out, len, hipMemcpyDeviceToHost, c.stream);
+        what = "D2H copy";
+    }
+    const hipError_t drained = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess)
+        return fail(DXTLT_E_DEVICE, what, e);
+    HIP_TRY(drained, "stream synchronize");
     return DXTLT_OK;
 }
 
@@ -400,6 +449,12 @@ int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, u
         return done(fail(DXTLT_E_DEVICE, "hipMalloc(shard buffers)", hipGetLastError()));
 
     hipError_t e = hipSuccess;
+    if (bytes >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0) {
+        // large shard: upload, kernel and the per-stream downloads of consecutive chunks overlap
+        PipeJob j{dev, st, d_a, d_b, format, inverse, in, out, total, sp.first, sp.count, mode, sa, sc, 0,
+                  pipeline_chunk_bytes(bytes)};
+        return done(pipelined_range(j));
+    }
     if (!inverse) {
         // AoS slice in, compact SoA out, then scatter the stream slices to their final host offsets
         e = hipMemcpyAsync(d_a, in + sp.first * B, bytes, hipMemcpyHostToDevice, st);
@@ -422,8 +477,10 @@ int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, u
         if (e == hipSuccess && rc == DXTLT_OK)
             e = hipMemcpyAsync(out + sp.first * B, d_b, bytes, hipMemcpyDeviceToHost, st);
     }
+    // drained on every exit: the buffers and the stream are freed below
+    const hipError_t drained = hipStreamSynchronize(st);
     if (e == hipSuccess && rc == DXTLT_OK)
-        e = hipStreamSynchronize(st);
+        e = drained;
     if (rc != DXTLT_OK)
         return done(rc);
     if (e != hipSuccess)
@@ -520,7 +577,8 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in,
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
         return fail(DXTLT_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)", e);
-    int shards = (num_devices <= 0 || num_devices > count) ? count : num_devices;
+    // more shards than devices are dealt round robin (a 1-GPU box runs the multi-shard placement that way)
+    int shards = num_devices <= 0 ? count : std::min(num_devices, 64);
     const uint64_t total = len / (size_t)dxtlt::block_bytes((Format)format);
     if ((uint64_t)shards > total)
         shards = (int)total;
@@ -534,7 +592,7 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in,
     std::vector<std::thread> threads;
     for (int d = 0; d < shards; ++d) {
         threads.emplace_back([&, d] {
-            codes[(size_t)d] = shard_worker(d, format, inverse, in, out, total, plan[(size_t)d], mode, sa, sc);
+            codes[(size_t)d] = shard_worker(d % count, format, inverse, in, out, total, plan[(size_t)d], mode, sa, sc);
             if (codes[(size_t)d] != DXTLT_OK)
                 msgs[(size_t)d] = g_last_error;
         });

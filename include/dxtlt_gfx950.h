@@ -152,7 +152,9 @@ int32_t dxtlt_transform_batch_device(const DxtltBatchItem *items, size_t count, 
 /* ---- single-process multi-GPU: shard [0, N) by contiguous block range over `num_devices` GPUs -----
  * Host pointers.  Each device receives its slice of the input, runs the range kernel, and its slice of
  * every output stream is copied straight to its final place in `output_ptr` (no collective; see
- * DESIGN.md "Multi-GPU").  num_devices <= 0 means all visible devices. */
+ * DESIGN.md "Multi-GPU").  num_devices <= 0 means all visible devices; a number above the visible devices (at most
+ * 64) is that many shards dealt round robin over them.  Shards of 96 MiB or more run as a chunked pipeline (upload,
+ * kernel and the per-stream downloads of consecutive chunks overlap). */
 int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t *input_ptr, uint8_t *output_ptr,
                                 size_t len, uint8_t decorrelation_mode, bool split_alpha_endpoints,
                                 bool split_colour_endpoints, int32_t num_devices);

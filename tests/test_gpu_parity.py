@@ -529,6 +529,42 @@ def test_mixed_bc1_bc3_archive(pkg, oracle, dev):
         assert np.array_equal(z, x), (i, fmt, blocks, "inverse")
 
 
+@pytest.mark.parametrize("fmt,shards", [("bc1", 3), ("bc3", 5), ("bc2", 2)])
+def test_sharded_entry_point_many_shards_pipelined(pkg, oracle, dev, fmt, shards):
+    """dxtlt_transform_sharded with several shards, each large enough (>= 96 MiB) to take the chunked pipeline with a
+    non-zero base block: every visible device is used, more shards than devices are dealt round robin.  Whole-buffer
+    comparison with the oracle, then the inverse."""
+    blocks = shards * ((112 << 20) // BLOCK[fmt]) + 12_345
+    x = oracle.fill_splitmix64(blocks * BLOCK[fmt], 0x5AAD + shards)
+    st = pkg_settings(pkg, fmt, (1, 1, 1))
+    y = np.zeros_like(x)
+    pkg.transform_sharded(fmt, False, x, y, st, shards)
+    want = np.empty_like(x)
+    oracle.run_mt(fmt, x, want, 1, True, True, False, 8)
+    assert np.array_equal(y, want)
+    z = np.zeros_like(x)
+    pkg.transform_sharded(fmt, True, y, z, st, shards)
+    assert np.array_equal(z, x)
+
+
+def test_sharded_entry_point_on_every_visible_device(pkg, oracle, dev):
+    """More than one device visible (the driver's 8-GPU node): the same call over all of them, one shard per device."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device visible")
+    fmt = "bc3"
+    blocks = (1 << 30) // 16 + 77
+    x = oracle.fill_splitmix64(blocks * 16, 0xD371CE5)
+    st = pkg_settings(pkg, fmt, (1, 1, 1))
+    y = np.zeros_like(x)
+    pkg.transform_sharded(fmt, False, x, y, st, 0)
+    want = np.empty_like(x)
+    oracle.run_mt(fmt, x, want, 1, True, True, False, 8)
+    assert np.array_equal(y, want)
+    z = np.zeros_like(x)
+    pkg.transform_sharded(fmt, True, y, z, st, 0)
+    assert np.array_equal(z, x)
+
+
 def test_real_textures(pkg, oracle, dev):
     """assets/tests/r2-256-bc{1,2,3}.dds payloads: every settings combination, forward bytes and round trip
     (reference: debug_bcN roundtrip commands)."""
