@@ -36,7 +36,9 @@
 //     element-granular kernel: one lane per block, natural-width or byte accesses.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
+#include <type_traits>
 
 #include "bc1_normalize.h"
 #include "bcn_launch.h"
@@ -317,6 +319,7 @@ struct Shifts {
     int line_policy;  // 1: forward stores of lines written whole by one wave instruction are write-through (sc1 nt)
     int skip_partial; // timing experiment only (wrong output): 1 = leave out the partial head / tail segments
     int natural;      // 1: every d[s] is a multiple of stream s's element width (always so when the SoA pointer is 8-byte aligned)
+    int halo_vecs;    // halo tiles: 16-byte vectors in front of a tile whose blocks have bytes in the tile's windows
 };
 
 // element width of a stream: its bytes per block, except the 6-byte alpha index records, which move as three halfwords
@@ -718,6 +721,123 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
     fwd_shift_tile<FMT, VARIANT, SA, SC, NORM, R>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward shifted tiles, second form ("halo tiles").  What the counters said about the form above on odd block counts
+// (profiles/r02_a_shift_pmc.txt, BC3 default settings, 2^26 + 1 blocks against 2^26): HBM requests identical and all of
+// them full 64-byte ones (TCC_EA0_WRREQ == TCC_EA0_WRREQ_64B, no read-modify-write), memory-side write stalls 50 x
+// LOWER -- but 5.5 x the vector-memory store instructions per wave (the typed partial segments), 2 x the VALU and 3.6 x
+// the SALU instructions, 2.65 x the issue-stall cycles: the kernel is bound by its own instruction stream, not by memory.
+// So the partial segments go: a tile's window on stream s is moved back by the stream's misalignment d_s, to the
+// aligned segments [G_s - d_s, G_s - d_s + w_s * T).  Its first d_s bytes are records of the up to 16 blocks BEFORE the
+// tile: the workgroup loads that halo too (16 blocks, one more load instruction for a quarter of wave 0; the lines were
+// just fetched by the previous tile, which the XCD-contiguous tile order keeps on the same L2), every stream region of
+// the LDS image is 16 blocks longer at the front, and what leaves the workgroup is exactly what leaves an aligned tile:
+// one full, aligned 16-byte store per lane.  Bytes no window covers -- the first 16 - d_s bytes of every stream of the
+// RANGE (tile 0 has no halo: the blocks before it may not exist or belong to another call) and everything behind the
+// last tile's windows -- are records of the first 16 and of the last 16 + (num_blocks mod T) blocks of the range, which
+// the element kernel writes (launch_transform); where the two overlap they write the same values.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHaloBlocks = 16;
+template <int FMT>
+constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, 256) + kHaloBlocks) + 16 * 6; }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Copy-out of wave W of a halo tile: lane t moves image byte 16 t of the tile's windows.  A wave's 1 KiB of the image
+// meets at most three streams (BC3 with split alphas, wave 0) and usually one, and which ones is known at compile time:
+// the per-lane select over the streams -- a third of the first version's vector instructions -- shrinks to the streams
+// the wave can meet.
+template <int FMT, bool SA, bool SC, int W>
+__device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, const uint8_t* lds, int t, bool first_tile,
+                                                   const uint64_t (&gb)[6], const Shifts& sh)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int H = kHaloBlocks;
+    constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
+    const int o = t * 16;
+    int la = 0;
+    uint64_t g = 0;
+    bool skip = false;
+    static_for<0, S.n>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int lo = S.off[s] * T;
+        constexpr int hi = lo + S.width[s] * T;
+        if constexpr (lo < wave_hi && hi > wave_lo) {
+            constexpr bool only = lo <= wave_lo && hi >= wave_hi;   // the whole wave sits in this stream
+            if (only || (o >= lo && o < hi)) {
+                la = S.off[s] * (T + H) + 16 * s + S.width[s] * H + (o - lo);
+                g = gb[s] + (uint64_t)(o - lo);
+                // no halo in front of the range: the element kernel writes the bytes of that first segment
+                skip = first_tile && o == lo && sh.d[s] > 0;
+            }
+        }
+    });
+    if (skip)
+        return;
+    // line_policy 3 (launch_transform: every window starts on a 128-byte line, so no line is shared between tiles):
+    // write-through streaming stores as in the aligned tiles; otherwise plain nt, which lets L2 merge the two halves
+    // of a shared line
+    if (sh.line_policy == 3)
+        gstore16(soa + g, lds_at<u32x4>(const_cast<uint8_t*>(lds), la));
+    else
+        __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
+__global__ void __launch_bounds__(256)
+fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
+               Shifts sh)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int H = kHaloBlocks;
+    constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors: 16 (BC2 / BC3) or 8 (BC1)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
+    const int t = threadIdx.x;
+    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    const uint64_t blk0 = first_block + tile * T;
+    // region of stream s: starts at off_s * (T + H) + 16 * s (16-byte aligned), holds the records of blocks
+    // [blk0 - H, blk0 + T) from byte d_s on; base[s] = address of the record of the tile's block 0
+    int base[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+        base[s] = s < S.n ? S.off[s] * (T + H) + 16 * s + sh.d[s] + S.width[s] * H : 0;
+
+    const uint8_t* tile_aos = aos + tile * 4096;
+    const u32x4 q = gload16(tile_aos + t * 16);
+    // Only the blocks that have bytes inside a window are fetched: max over the streams of ceil(d_s / w_s) blocks, at
+    // most 16 (the whole halo costs 0.02 of peak on BC3 -- 6 % more bytes read -- profiles/r02_b_shift_probe.txt).
+    // skip_partial: timing experiment (wrong output)
+    const int hv = sh.halo_vecs;
+    const bool has_halo = tile > 0 && t < hv && !sh.skip_partial;
+    if (has_halo) {
+        // plain load: the previous tile has just fetched these lines
+        const u32x4 qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
+        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
+    }
+    static_assert(HV <= 64, "the halo is loaded by lanes of wave 0");
+    scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
+    __syncthreads();
+
+    uint64_t gb[6];
+    slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
+    const bool first_tile = tile == 0;
+    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+    case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, first_tile, gb, sh); break;
+    case 1: halo_copy_out_wave<FMT, SA, SC, 1>(soa, lds, t, first_tile, gb, sh); break;
+    case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, first_tile, gb, sh); break;
+    default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, first_tile, gb, sh); break;
+    }
+}
+
 // one shifted tile, inverse
 template <int FMT, int VARIANT, bool SA, bool SC, int R = 1>
 __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
@@ -1038,6 +1158,7 @@ __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, 
         sh.xcd_remap = 0;
         sh.line_policy = 1;
         sh.skip_partial = 0;
+        sh.halo_vecs = 0;
         sh.natural = shifts_are_natural(make_streams(FMT, SA, SC), sh.d);
         // every buffer's first workgroup is a multiple of 8 (the host pads), so local % 8 is the XCD this workgroup
         // runs on and the XCD-contiguous tile order of the single-buffer shifted kernels applies per buffer
@@ -1128,6 +1249,7 @@ struct KernelSet {
     TiledFn tiled[4];  // 64, 128, 256, 512 threads
     ShiftFn shifted;   // 256 threads, misaligned stream bases
     GenericFn generic;
+    ShiftFn halo[2];   // forward only: shifted tiles with a halo, whole segments only ([1]: natural shifts); nullptr for the inverse
 };
 
 inline int threads_slot(int threads) { return threads == 64 ? 0 : threads == 128 ? 1 : threads == 512 ? 3 : 2; }
@@ -1138,10 +1260,11 @@ KernelSet kernels_for(bool inverse)
     if (inverse)
         return {{inv_tiled<FMT, VARIANT, SA, SC, 64>, inv_tiled<FMT, VARIANT, SA, SC, 128>,
                  inv_tiled<FMT, VARIANT, SA, SC, 256>, inv_tiled<FMT, VARIANT, SA, SC, 512>},
-                inv_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, true>};
+                inv_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, true>, {nullptr, nullptr}};
     return {{fwd_tiled<FMT, VARIANT, SA, SC, 64>, fwd_tiled<FMT, VARIANT, SA, SC, 128>,
              fwd_tiled<FMT, VARIANT, SA, SC, 256>, fwd_tiled<FMT, VARIANT, SA, SC, 512>},
-            fwd_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, false>};
+            fwd_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, false>,
+            {fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false>, fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true>}};
 }
 
 template <int FMT, int VARIANT>
@@ -1174,7 +1297,8 @@ KernelSet bc1_norm_kernels()
     constexpr int TH = default_tile_threads(kBc1, false);
     TiledFn tiled = fwd_tiled<kBc1, VARIANT, false, SC, TH, NORM>;
     return {{tiled, tiled, tiled, tiled}, fwd_tiled_shift<kBc1, VARIANT, false, SC, NORM>,
-            generic_kernel<kBc1, VARIANT, false, SC, false, NORM>};
+            generic_kernel<kBc1, VARIANT, false, SC, false, NORM>,
+            {fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, false>, fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, true>}};
 }
 
 template <int NORM>
@@ -1297,8 +1421,33 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         threads = 256;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
     const uint64_t num_tiles = use_tiles ? r.num_blocks / T : 0;
+    // forward shifted tiles take the halo form (whole segments only) unless experiment switch 0x400 asks for the first form
+    const bool use_halo = use_shift && !inverse && ks.halo[0] != nullptr && !(force_bits & 0x400);
+    if (use_halo) {
+        // Windows that all start on a 128-byte line share no line with the neighbouring tile: identity tile order and
+        // write-through stores, as for aligned tiles.  Otherwise two tiles complete each boundary line and should
+        // meet in one L2 (XCD-contiguous order: 0.74-0.75 against 0.67-0.69, profiles/r02_b_shift_probe.txt).
+        bool line_aligned = true;
+        for (int i = 0; i < S.n; ++i) {
+            const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
+                                  (uint64_t)S.width[i] * r.first_block;
+            line_aligned = line_aligned && ((base - (base & 15)) & 127) == 0;
+        }
+        if (remap_override < 0)
+            sh.xcd_remap = line_aligned ? 0 : 1;
+        if (line_aligned && sh.line_policy == 1 && !(force_bits & 0x800))
+            sh.line_policy = 3;
+        int halo_blocks = 0;
+        for (int i = 0; i < S.n; ++i)
+            halo_blocks = std::max(halo_blocks, (sh.d[i] + S.width[i] - 1) / S.width[i]);
+        const int per_vec = 16 / fmt_block(fmt);
+        sh.halo_vecs = (halo_blocks + per_vec - 1) / per_vec;
+    }
     if (num_tiles > 0) {
-        if (use_shift)
+        if (use_halo)
+            hipLaunchKernelGGL(ks.halo[sh.natural ? 1 : 0], dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8,
+                               r.total_blocks, r.first_block, sh);
+        else if (use_shift)
             hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
                                r.first_block, sh);
         else
@@ -1308,17 +1457,23 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         if (e != hipSuccess)
             return e;
     }
-    const uint64_t done = num_tiles * T;
-    const uint64_t rest = r.num_blocks - done;
-    if (rest > 0) {
-        const uint64_t grid = (rest + kThreads - 1) / kThreads;   // rest <= 2^31 blocks, one per thread
+    uint64_t done = num_tiles * T;
+    auto element_range = [&](uint64_t local_first, uint64_t count) -> hipError_t {
+        if (count == 0)
+            return hipSuccess;
+        const uint64_t grid = (count + kThreads - 1) / kThreads;   // count <= 2^31 blocks, one per thread
         hipLaunchKernelGGL(ks.generic, dim3((unsigned)grid), dim3(kThreads), 0, stream, src8, dst8, r.total_blocks,
-                           r.first_block, done, rest);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess)
+                           r.first_block, local_first, count);
+        return hipGetLastError();
+    };
+    if (use_halo && num_tiles > 0) {
+        // what the halo tiles' windows leave out: the head of every stream of the range (records of its first 16 blocks)
+        // and everything behind the last window (records of the last 16 blocks of the tiles, and the rest)
+        if (hipError_t e = element_range(0, kHaloBlocks); e != hipSuccess)
             return e;
+        done -= kHaloBlocks;
     }
-    return hipSuccess;
+    return element_range(done, r.num_blocks - done);
 }
 
 uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)

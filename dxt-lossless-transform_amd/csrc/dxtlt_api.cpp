@@ -57,7 +57,7 @@ dxtlt::LaunchTuning current_tuning()
 {
     dxtlt::LaunchTuning t;
     t.tile_threads = g_tile_threads.load(std::memory_order_relaxed);
-    t.force_generic = g_force_generic.load(std::memory_order_relaxed) & 0xFF;
+    t.force_generic = g_force_generic.load(std::memory_order_relaxed);
     t.xcd_remap = g_xcd_remap.load(std::memory_order_relaxed);
     return t;
 }
@@ -632,7 +632,7 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 {
     g_tile_threads.store(tile_threads);
     // bits 8..9 of force_path carry the XCD-remap experiment switch: 0x100 = off, 0x200 = on, 0 = default
-    g_force_generic.store(force_generic & 0xFF);
+    g_force_generic.store(force_generic & 0xCFF);  // 0x400: first form of the forward shifted tiles (no halo)
     g_xcd_remap.store((force_generic & 0x100) ? 0 : (force_generic & 0x200) ? 1 : -1);
 }
 

@@ -173,6 +173,39 @@ def test_shifted_tiles(pkg, oracle, dev, fmt):
         assert np.array_equal(back, x)
 
 
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_forward_shifted_tiles_both_forms(pkg, oracle, dev, fmt):
+    """The forward shifted tiles exist in two forms: halo tiles (whole 16-byte segments only; the default) and the first
+    form with typed partial segments (experiment switch 0x400).  Both must equal the oracle on odd counts, on ranges
+    that start at odd blocks and on an SoA pointer that is itself misaligned."""
+    t = TILE[fmt]
+    B = BLOCK[fmt]
+    for force in (0, 0x400):
+        try:
+            pkg.set_tuning(0, force)
+            for n in (t + 1, 2 * t + 15, 9 * t + 7, 40 * t + 16 + 3):
+                x = oracle.fill_splitmix64(n * B, 0xA110 + n)
+                for s in all_settings(fmt):
+                    assert np.array_equal(run_device(pkg, fmt, x, s, dev), fwd_oracle(oracle, fmt, x, s)), (force, n, settings_id(s))
+            # ranges with odd starts, written into one whole buffer; guard bytes around it
+            total = 11 * t + 9
+            x = oracle.fill_splitmix64(total * B, 0xA111)
+            xd = torch.from_numpy(x).to(dev)
+            cuts = [0, 3 * t + 1, 3 * t + 1 + 2 * t, 8 * t + 5, total]
+            for s in [(1, 1, 1), (2, 0, 1), (0, 1, 0)]:
+                st = pkg_settings(pkg, fmt, s)
+                for lead in (0, 1, 6):   # the SoA pointer itself off by `lead` bytes
+                    buf = torch.full((x.size + 256,), 0x5E, dtype=torch.uint8, device=dev)
+                    yd = buf[64 + lead: 64 + lead + x.size]
+                    for a, b in zip(cuts, cuts[1:]):
+                        pkg.transform_range(fmt, False, xd[a * B:], yd, total, a, b - a, st)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(yd.cpu().numpy(), fwd_oracle(oracle, fmt, x, s)), (force, settings_id(s), lead)
+                    assert bool((buf[:64 + lead] == 0x5E).all()) and bool((buf[64 + lead + x.size:] == 0x5E).all())
+        finally:
+            pkg.set_tuning(0, 0)
+
+
 def test_no_write_past_the_end(pkg, oracle, dev):
     """Stream sections are adjacent in one buffer: a wide store of one stream must never spill into the next
     (SURVEY.md 2, AVX-512 crib) nor past the end of the output."""
