@@ -1,5 +1,5 @@
-"""BC7 mode-split transform, version 0 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has no BC7
-transform.  Thin Python layer over include/dxtlt_bc7.h, same buffer conventions as the BC1-3 functions."""
+"""BC7 granule-sorted field split, version 1 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
+no BC7 transform.  Thin Python layer over include/dxtlt_bc7.h, same buffer conventions as the BC1-3 functions."""
 from __future__ import annotations
 
 import ctypes as C
@@ -19,6 +19,9 @@ def _l():
         for n in ("dxtlt_transform_bc7_device", "dxtlt_untransform_bc7_device"):
             getattr(l, n).argtypes, getattr(l, n).restype = [vp, vp, sz, vp, sz, vp], i32
         l.dxtlt_bc7_workspace_bytes.argtypes, l.dxtlt_bc7_workspace_bytes.restype = [sz], sz
+        l.dxtlt_transform_bc7_range_device.argtypes = [C.c_bool, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+        l.dxtlt_transform_bc7_range_device.restype = i32
+        l.dxtlt_bc7_sort_granule.argtypes, l.dxtlt_bc7_sort_granule.restype = [], C.c_uint32
         _declared = True
     return l
 
@@ -44,13 +47,9 @@ def _run(inverse: bool, input, output, workspace=None) -> None:
     else:
         import torch
 
-        need = workspace_bytes(src.nbytes)
         with torch.cuda.device(src.device):
-            if workspace is None:
-                workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=input.device)
-            ws = _Buf(workspace, True)
             stream = torch.cuda.current_stream().cuda_stream
-            rc = getattr(l, name + "_device")(src.ptr, dst.ptr, src.nbytes, ws.ptr, ws.nbytes, stream)
+            rc = getattr(l, name + "_device")(src.ptr, dst.ptr, src.nbytes, None, 0, stream)   # version 1: no workspace
     if rc != _lib.OK:
         raise DeviceError(rc, _lib.last_error())
 
@@ -63,20 +62,44 @@ def untransform_bc7(input, output, workspace=None) -> None:
     _run(True, input, output, workspace)
 
 
+def sort_granule() -> int:
+    return int(_l().dxtlt_bc7_sort_granule())
+
+
+def transform_bc7_range(inverse: bool, src, dst, total_blocks: int, first_block: int, num_blocks: int) -> None:
+    """dxtlt_transform_bc7_range_device on torch CUDA tensors: the AoS-side tensor starts at block `first_block` (a
+    multiple of the sort granule), the SoA-side tensor is the whole transformed buffer."""
+    import torch
+
+    from . import DeviceError, OutputBufferTooSmall, _Buf
+
+    s, d = _Buf(src, False), _Buf(dst, True)
+    if s.device is None or d.device is None:
+        raise TypeError("transform_bc7_range takes device tensors")
+    aos, soa = (d, s) if inverse else (s, d)
+    if aos.nbytes < num_blocks * 16 or soa.nbytes < total_blocks * 16:
+        raise OutputBufferTooSmall(max(num_blocks, total_blocks) * 16, min(aos.nbytes, soa.nbytes))
+    with torch.cuda.device(s.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _l().dxtlt_transform_bc7_range_device(bool(inverse), s.ptr, d.ptr, total_blocks, first_block, num_blocks, stream)
+    if rc != _lib.OK:
+        raise DeviceError(rc, _lib.last_error())
+
+
 def _declare_sharded(l):
     if not getattr(l, "_bc7_sharded_declared", False):
-        vp, sz, i32, u64p = C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_uint64)
+        vp, sz, i32, u64, u64p = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)
         for n in ("dxtlt_transform_bc7_sharded", "dxtlt_untransform_bc7_sharded"):
             getattr(l, n).argtypes, getattr(l, n).restype = [vp, vp, sz, i32], i32
-        l.dxtlt_bc7_shard_pieces.argtypes = [u64p, i32, i32, u64p, u64p, C.c_uint64, u64p, u64p, u64p]
+        l.dxtlt_bc7_shard_pieces.argtypes = [u64, u64, u64, u64p, u64p, u64p]
         l.dxtlt_bc7_shard_pieces.restype = i32
         l._bc7_sharded_declared = True
     return l
 
 
 def transform_bc7_sharded(input, output, num_shards: int = 0, inverse: bool = False) -> None:
-    """Host buffers, block range sharded over the node's GPUs inside this process (no collective).  ``num_shards`` <= 0:
-    one shard per device; more shards than devices run round robin."""
+    """Host buffers, block range sharded over the node's GPUs inside this process (no collective, no counter
+    exchange).  ``num_shards`` <= 0: one shard per device; more shards than devices run round robin."""
     from . import DeviceError, InvalidLength, OutputBufferTooSmall, _Buf
 
     src, dst = _Buf(input, False), _Buf(output, True)
@@ -93,18 +116,14 @@ def transform_bc7_sharded(input, output, num_shards: int = 0, inverse: bool = Fa
         raise DeviceError(rc, _lib.last_error())
 
 
-def shard_pieces(counts, shard: int, first_blocks, num_blocks, total_blocks: int):
-    """Placement table of one shard (pure host code): three lists of 19 ints (global offset, local offset, bytes) for
-    the pieces `first`, head_0..8, tail_0..8.  ``counts``: per shard, nine per-mode block counts."""
+def shard_pieces(total_blocks: int, first_block: int, num_blocks: int):
+    """Placement of one granule-aligned shard (pure host code): three lists of 9 ints (global offset, local offset,
+    bytes) -- its slice of the eight main streams and, for the shard that reaches the end, the tail part."""
     from . import DeviceError
 
     l = _declare_sharded(_l())
-    s = len(counts)
-    flat = (C.c_uint64 * (9 * s))(*[int(c) for row in counts for c in row])
-    fb = (C.c_uint64 * s)(*[int(v) for v in first_blocks])
-    nb = (C.c_uint64 * s)(*[int(v) for v in num_blocks])
-    g, lo, n = (C.c_uint64 * 19)(), (C.c_uint64 * 19)(), (C.c_uint64 * 19)()
-    rc = l.dxtlt_bc7_shard_pieces(flat, s, int(shard), fb, nb, int(total_blocks), g, lo, n)
+    g, lo, n = (C.c_uint64 * 9)(), (C.c_uint64 * 9)(), (C.c_uint64 * 9)()
+    rc = l.dxtlt_bc7_shard_pieces(int(total_blocks), int(first_block), int(num_blocks), g, lo, n)
     if rc != _lib.OK:
         raise DeviceError(rc, _lib.last_error())
     return list(g), list(lo), list(n)

@@ -1,4 +1,4 @@
-// bc7_api.cpp -- C ABI of the BC7 mode-split transform, version 0 (include/dxtlt_bc7.h, docs/BC7_FORMAT.md).
+// bc7_api.cpp -- C ABI of the BC7 granule-sorted field split, version 1 (include/dxtlt_bc7.h, docs/BC7_FORMAT.md).
 // A format of this build's own: the reference has no BC7 transform; parity unpinned.
 #include "../../include/dxtlt_bc7.h"
 
@@ -8,18 +8,6 @@
 #include "host_common.h"
 
 namespace {
-
-// per-thread device scratch for the host-pointer entry points (grow-only)
-struct Bc7Scratch {
-    void* ptr = nullptr;
-    size_t cap = 0;
-    int device = -1;
-    ~Bc7Scratch()
-    {
-        if (ptr) (void)hipFree(ptr);
-    }
-};
-thread_local Bc7Scratch g_scratch;
 
 int32_t host_call(bool inverse, const uint8_t* in, uint8_t* out, size_t len)
 {
@@ -35,59 +23,47 @@ int32_t host_call(bool inverse, const uint8_t* in, uint8_t* out, size_t len)
     int32_t rc = acquire_staging(len, &d_in, &d_out, &st);
     if (rc != kOk)
         return rc;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t need = dxtlt::bc7::workspace_bytes(len / 16);
-    if (g_scratch.device != dev || g_scratch.cap < need) {
-        if (g_scratch.ptr) (void)hipFree(g_scratch.ptr);
-        g_scratch.ptr = nullptr;
-        g_scratch.cap = 0;
-        hipError_t e = hipMalloc(&g_scratch.ptr, need);
-        if (e != hipSuccess)
-            return fail(kDevice, "hipMalloc(BC7 workspace)", e);
-        g_scratch.cap = need;
-        g_scratch.device = dev;
-    }
     hipError_t e = hipMemcpyAsync(d_in, in, len, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
-        e = dxtlt::bc7::launch(inverse, d_in, d_out, len / 16, g_scratch.ptr, g_scratch.cap, st);
+        e = dxtlt::bc7::launch(inverse, d_in, d_out, len / 16, st);
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, d_out, len, hipMemcpyDeviceToHost, st);
+    // drained on every exit: the staging buffers belong to this thread's next call
+    const hipError_t drained = hipStreamSynchronize(st);
     if (e == hipSuccess)
-        e = hipStreamSynchronize(st);
+        e = drained;
     if (e != hipSuccess)
         return fail(kDevice, "BC7 transform", e);
     return kOk;
 }
 
-int32_t device_call(bool inverse, const void* d_in, void* d_out, size_t len, void* ws, size_t ws_bytes, void* stream)
+int32_t device_range(bool inverse, const void* d_src, void* d_dst, uint64_t total, uint64_t first, uint64_t num, void* stream)
 {
     using namespace dxtlt_host;
-    if (len % 16 != 0)
-        return fail(kInvalidLength, "len is not a multiple of 16 (BC7 block size)");
-    if (len == 0)
+    if (num == 0)
         return kOk;
-    if (d_in == nullptr || d_out == nullptr || ws == nullptr)
-        return fail(kInvalidArgument, "NULL device buffer / workspace");
-    if (ws_bytes < dxtlt::bc7::workspace_bytes(len / 16))
-        return fail(kInvalidArgument, "workspace smaller than dxtlt_bc7_workspace_bytes(len)");
-    hipError_t e = dxtlt::bc7::launch(inverse, d_in, d_out, len / 16, ws, ws_bytes, (hipStream_t)stream);
+    if (d_src == nullptr || d_dst == nullptr)
+        return fail(kInvalidArgument, "NULL device buffer");
+    hipError_t e = dxtlt::bc7::launch_range(inverse, d_src, d_dst, total, first, num, (hipStream_t)stream);
     if (e == hipErrorInvalidValue)
-        return fail(kInvalidArgument, "BC7 v0 needs 16-byte aligned device buffers");
+        return fail(kInvalidArgument, "BC7: device buffers must be 16-byte aligned; a range starts on a sort granule (1024 "
+                                      "blocks) and ends on one or at the end of the array");
     if (e != hipSuccess)
         return fail(kDevice, "BC7 kernel launch", e);
     return kOk;
 }
 
+int32_t device_call(bool inverse, const void* d_in, void* d_out, size_t len, void* stream)
+{
+    using namespace dxtlt_host;
+    if (len % 16 != 0)
+        return fail(kInvalidLength, "len is not a multiple of 16 (BC7 block size)");
+    return device_range(inverse, d_in, d_out, len / 16, 0, len / 16, stream);
+}
+
 }  // namespace
 
-void dxtlt_host::release_bc7_thread_scratch()
-{
-    if (g_scratch.ptr) (void)hipFree(g_scratch.ptr);
-    g_scratch.ptr = nullptr;
-    g_scratch.cap = 0;
-    g_scratch.device = -1;
-}
+void dxtlt_host::release_bc7_thread_scratch() {}   // version 1 keeps no per-thread device scratch
 
 extern "C" {
 
@@ -99,16 +75,31 @@ int32_t dxtlt_untransform_bc7(const uint8_t* input_ptr, uint8_t* output_ptr, siz
 {
     return host_call(true, input_ptr, output_ptr, len);
 }
-size_t dxtlt_bc7_workspace_bytes(size_t len) { return dxtlt::bc7::workspace_bytes(len / 16); }
+size_t dxtlt_bc7_workspace_bytes(size_t len)
+{
+    (void)len;
+    return 0;   // version 1 is a single pass with no device scratch
+}
 int32_t dxtlt_transform_bc7_device(const void* d_input, void* d_output, size_t len, void* d_workspace,
                                    size_t workspace_bytes, void* hip_stream)
 {
-    return device_call(false, d_input, d_output, len, d_workspace, workspace_bytes, hip_stream);
+    (void)d_workspace;
+    (void)workspace_bytes;
+    return device_call(false, d_input, d_output, len, hip_stream);
 }
 int32_t dxtlt_untransform_bc7_device(const void* d_input, void* d_output, size_t len, void* d_workspace,
                                      size_t workspace_bytes, void* hip_stream)
 {
-    return device_call(true, d_input, d_output, len, d_workspace, workspace_bytes, hip_stream);
+    (void)d_workspace;
+    (void)workspace_bytes;
+    return device_call(true, d_input, d_output, len, hip_stream);
+}
+int32_t dxtlt_transform_bc7_range_device(bool inverse, const void* d_src, void* d_dst, uint64_t total_blocks,
+                                         uint64_t first_block, uint64_t num_blocks, void* hip_stream)
+{
+    if (first_block > total_blocks || num_blocks > total_blocks - first_block)
+        return dxtlt_host::fail(dxtlt_host::kInvalidArgument, "block range exceeds total_blocks");
+    return device_range(inverse, d_src, d_dst, total_blocks, first_block, num_blocks, hip_stream);
 }
 
 }  // extern "C"

@@ -174,8 +174,15 @@ int32_t map_device_status(int32_t st)
 int dds_to_bcn(uint8_t fmt) { return fmt == BC1 ? 1 : fmt == BC2 ? 2 : fmt == BC3 ? 3 : 0; }
 
 // BC7 payloads: refused as upstream (dispatch.rs knows no BC7 transform) unless the caller opts in to this build's own
-// mode-split format (include/dxtlt_bc7.h); TransformFormat::Bc7 = 3 exists upstream, its data bits are unassigned
+// format (include/dxtlt_bc7.h).  TransformFormat::Bc7 = 3 exists upstream and its 28 data bits are unassigned ("3 bits
+// for each of BC7's 8 modes" is a comment, embed/mod.rs:49-51), so all-zero data bits are what upstream's first BC7
+// header version would look like.  Files written here must not be mistaken for that: the data bits carry a vendor tag
+// in the upper 16 bits and this build's format version in the lower 12, and anything else -- all zeros included -- is
+// refused on the way back.
 std::atomic<bool> g_bc7_enabled{false};
+constexpr uint32_t kBc7VendorTag = 0xD175u;    // data bits 27..12
+constexpr uint32_t kBc7FormatVersion = 1u;     // data bits 11..0: docs/BC7_FORMAT.md version
+constexpr uint32_t kBc7PrivateHeader = (uint32_t)DXTLT_TF_BC7 | (((kBc7VendorTag << 12) | kBc7FormatVersion) << 4);
 
 int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len,
                              const DltSizeEstimator* estimator, bool use_all, uint8_t mode, bool sa, bool sc)
@@ -191,7 +198,7 @@ int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* ou
     if (input_len < off + length)
         return DXTLT_FF_INPUT_TOO_SHORT;
     if (info.Format == BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
-        // no settings and nothing to estimate: version 0 of the mode-split format has one layout
+        // no settings and nothing to estimate: version 1 of the format has one layout
         if (length % 16 != 0)
             return DXTLT_FF_INVALID_DATA_ALIGNMENT;
         std::memcpy(output, input, off);
@@ -200,7 +207,7 @@ int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* ou
             return map_device_status(st7);
         if (input_len > off + length)
             std::memcpy(output + off + length, input + off + length, input_len - off - length);
-        wr32(output, dxtlt_transform_header_pack(DXTLT_TF_BC7, 0, false, false));
+        wr32(output, kBc7PrivateHeader);
         return DXTLT_FF_OK;
     }
     const int bcn = dds_to_bcn(info.Format);
@@ -332,8 +339,8 @@ int32_t dxtlt_dds_untransform(const uint8_t* input, size_t input_len, uint8_t* o
     bool sa = false, sc = false;
     // dispatch_untransform (handlers/dispatch.rs:39-): format first, then the details, then the alignment
     if ((header & 0xF) == DXTLT_TF_BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
-        if ((header >> 4) != 0)
-            return DXTLT_FF_CORRUPTED_EMBEDDED_DATA;  // version 0 of the BC7 format has no data bits
+        if (header != kBc7PrivateHeader)
+            return DXTLT_FF_CORRUPTED_EMBEDDED_DATA;  // not this build's tag + version (all-zero data bits: upstream's to assign)
         if (length % 16 != 0)
             return DXTLT_FF_INVALID_DATA_ALIGNMENT;
         wr32(output, kDdsMagic);

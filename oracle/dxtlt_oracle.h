@@ -112,10 +112,14 @@ void oracle_bc1_default_simd_range(int inverse, const uint8_t *in, uint8_t *out,
                                    size_t count);
 void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads);
 
-/* BC7 mode-split transform, version 0 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has no
- * BC7 transform, so these two are a definition, not a restatement: PARITY UNPINNED.  (dxtlt_oracle_bc7.c) */
+/* BC7 granule-sorted field split, version 1 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
+ * no BC7 transform, so these are a definition, not a restatement: PARITY UNPINNED.  (dxtlt_oracle_bc7.c) */
 void oracle_transform_bc7(const uint8_t *in, uint8_t *out, size_t len);
 void oracle_untransform_bc7(const uint8_t *in, uint8_t *out, size_t len);
+/* one 16-byte block <-> its 16-byte record (class from byte 0) */
+void oracle_bc7_record_of_block(const uint8_t *block, uint8_t *record);
+void oracle_bc7_block_of_record(const uint8_t *record, uint8_t *block);
+unsigned oracle_bc7_granule(void);
 /* force a valid mode marker into byte 0 of every block: mode = (byte 15 & 7) */
 void oracle_bc7_force_modes(uint8_t *blocks, size_t len);
 

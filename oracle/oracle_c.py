@@ -76,6 +76,9 @@ def lib() -> C.CDLL:
             getattr(l, n).restype = None
         l.oracle_bc7_force_modes.argtypes = [u8p, sz]
         l.oracle_bc7_force_modes.restype = None
+        for n in ("oracle_bc7_record_of_block", "oracle_bc7_block_of_record"):
+            getattr(l, n).argtypes, getattr(l, n).restype = [u8p, u8p], None
+        l.oracle_bc7_granule.argtypes, l.oracle_bc7_granule.restype = [], C.c_uint
         l.oracle_simd_available.argtypes, l.oracle_simd_available.restype = [], i
         l.oracle_simd_level.argtypes, l.oracle_simd_level.restype = [], i
         l.oracle_simd_set_cap.argtypes, l.oracle_simd_set_cap.restype = [i], i
@@ -212,12 +215,25 @@ def run_bc1_default_simd(src: np.ndarray, dst: np.ndarray, inverse: bool, thread
 
 
 def transform_bc7(data, inverse: bool = False) -> np.ndarray:
-    """BC7 mode-split transform v0 (docs/BC7_FORMAT.md) -- this build's own format, parity unpinned."""
+    """BC7 granule-sorted field split v1 (docs/BC7_FORMAT.md) -- this build's own format, parity unpinned."""
     a = np.ascontiguousarray(_as_u8(data))
     assert a.size % 16 == 0
     out = np.empty_like(a)
     (lib().oracle_untransform_bc7 if inverse else lib().oracle_transform_bc7)(_ptr(a), _ptr(out), a.size)
     return out
+
+
+def bc7_record(block, inverse: bool = False) -> np.ndarray:
+    """One 16-byte block -> its 16-byte record (or back)."""
+    a = np.ascontiguousarray(_as_u8(block))
+    assert a.size == 16
+    out = np.empty_like(a)
+    (lib().oracle_bc7_block_of_record if inverse else lib().oracle_bc7_record_of_block)(_ptr(a), _ptr(out))
+    return out
+
+
+def bc7_granule() -> int:
+    return int(lib().oracle_bc7_granule())
 
 
 def bc7_force_modes(data: np.ndarray) -> np.ndarray:

@@ -181,13 +181,26 @@ def splitmix64(seed: int, first_qword: int, count: int) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------------------
-# BC7 mode-split transform, version 0 (docs/BC7_FORMAT.md) -- a format defined by this build; parity unpinned.
+# BC7 granule-sorted field split, version 1 (docs/BC7_FORMAT.md) -- a format defined by this build; parity unpinned.
+# Second, independently written statement: one block at a time as a Python integer, fields by name (slow: small cases).
 # ------------------------------------------------------------------------------------------------------------
-BC7_HEAD = np.array([9, 9, 11, 11, 5, 7, 7, 11, 15])
+BC7_GRANULE = 1024
+# fields after the mode marker, LSB first: (name, count, width); hexpat:286-654
+BC7_FIELDS = {
+    0: [("part", 1, 4), ("R", 6, 4), ("G", 6, 4), ("B", 6, 4), ("P", 6, 1), ("idx", 1, 45)],
+    1: [("part", 1, 6), ("R", 4, 6), ("G", 4, 6), ("B", 4, 6), ("P", 2, 1), ("idx", 1, 46)],
+    2: [("part", 1, 6), ("R", 6, 5), ("G", 6, 5), ("B", 6, 5), ("idx", 1, 29)],
+    3: [("part", 1, 6), ("R", 4, 7), ("G", 4, 7), ("B", 4, 7), ("P", 4, 1), ("idx", 1, 30)],
+    4: [("rot", 1, 2), ("sel", 1, 1), ("R", 2, 5), ("G", 2, 5), ("B", 2, 5), ("A", 2, 6), ("idx", 1, 31), ("idx2", 1, 47)],
+    5: [("rot", 1, 2), ("R", 2, 7), ("G", 2, 7), ("B", 2, 7), ("A", 2, 8), ("idx", 1, 31), ("idx2", 1, 31)],
+    6: [("R", 2, 7), ("G", 2, 7), ("B", 2, 7), ("A", 2, 7), ("P", 2, 1), ("idx", 1, 63)],
+    7: [("part", 1, 6), ("R", 4, 5), ("G", 4, 5), ("B", 4, 5), ("A", 4, 5), ("P", 4, 1), ("idx", 1, 30)],
+}
+_BC7_HEADER, _BC7_ENDPOINTS = ("part", "rot", "sel"), ("R", "G", "B", "A")
 
 
 def bc7_modes(first: np.ndarray) -> np.ndarray:
-    """mode = trailing zero count of byte 0, 8 when byte 0 is zero"""
+    """class = trailing zero count of byte 0, 8 when byte 0 is zero (the reserved encoding)"""
     f = first.astype(np.int64)
     low = f & -f  # lowest set bit, 0 for 0
     m = np.full(f.shape, 8, dtype=np.int64)
@@ -196,35 +209,123 @@ def bc7_modes(first: np.ndarray) -> np.ndarray:
     return m
 
 
+def _bc7_parse(b: int, m: int):
+    pos, out = m + 1, []
+    for name, count, width in BC7_FIELDS[m]:
+        for _ in range(count):
+            out.append((name, (b >> pos) & ((1 << width) - 1), width))
+            pos += width
+    assert pos == 128
+    return out
+
+
+def _bc7_pack(pieces, start: int, value: int) -> int:
+    at = start
+    for v, w in pieces:
+        value |= v << at
+        at += w
+    assert at == 128
+    return value
+
+
+def bc7_record_of_block(b: int, m: int) -> int:
+    """marker | header | p-bits | index bits | low parts of the endpoints | high nibbles of the endpoints"""
+    if m == 8:
+        return b
+    f = _bc7_parse(b, m)
+    hdr = [(v, w) for n, v, w in f if n in _BC7_HEADER]
+    pb = [(v, w) for n, v, w in f if n == "P"]
+    idx = [(v, w) for n, v, w in f if n.startswith("idx")]
+    ep = [(v, w) for n, v, w in f if n in _BC7_ENDPOINTS]
+    lows = [(v & ((1 << (w - 4)) - 1), w - 4) for v, w in ep]
+    highs = [(v >> (w - 4), 4) for v, w in ep]
+    return _bc7_pack(hdr + pb + idx + lows + highs, m + 1, 1 << m)
+
+
+def bc7_block_of_record(r: int, m: int) -> int:
+    if m == 8:
+        return r
+    layout = BC7_FIELDS[m]
+    widths = {"hdr": [], "pb": [], "idx": [], "ep": []}
+    for name, count, width in layout:
+        key = "hdr" if name in _BC7_HEADER else "pb" if name == "P" else "idx" if name.startswith("idx") else "ep"
+        widths[key] += [width] * count
+    pos = m + 1
+
+    def take(w):
+        nonlocal pos
+        v = (r >> pos) & ((1 << w) - 1)
+        pos += w
+        return v
+
+    hdr = [take(w) for w in widths["hdr"]]
+    pb = [take(w) for w in widths["pb"]]
+    idx = [take(w) for w in widths["idx"]]
+    lows = [take(w - 4) for w in widths["ep"]]
+    highs = [take(4) for _ in widths["ep"]]
+    assert pos == 128
+    ep = [(h << (w - 4)) | l for h, l, w in zip(highs, lows, widths["ep"])]
+    # back into block order: header, endpoints, p-bits, indices
+    b, at = 1 << m, m + 1
+    for v, w in list(zip(hdr, widths["hdr"])) + list(zip(ep, widths["ep"])) + list(zip(pb, widths["pb"])) + list(zip(idx, widths["idx"])):
+        b |= v << at
+        at += w
+    assert at == 128
+    return b
+
+
+_BC7_STREAMS = [(0, 8, 1), (8, 2, 9), (10, 1, 11), (11, 1, 12), (12, 1, 13), (13, 1, 14), (14, 1, 15)]  # (offset, width, record byte)
+
+
+def _bc7_sorted_order(modes: np.ndarray) -> np.ndarray:
+    """sorted position -> block index, granule by granule, stable by class"""
+    order = []
+    for g0 in range(0, modes.size, BC7_GRANULE):
+        m = modes[g0:g0 + BC7_GRANULE]
+        order.append(g0 + np.argsort(m, kind="stable"))
+    return np.concatenate(order) if order else np.zeros(0, dtype=np.int64)
+
+
+def _bc7_part(blk: np.ndarray) -> np.ndarray:
+    n = blk.shape[0]
+    modes = bc7_modes(blk[:, 0])
+    recs = np.empty((n, 16), dtype=np.uint8)
+    for i in range(n):
+        r = bc7_record_of_block(int.from_bytes(blk[i].tobytes(), "little"), int(modes[i]))
+        recs[i] = np.frombuffer(r.to_bytes(16, "little"), dtype=np.uint8)
+    srt = recs[_bc7_sorted_order(modes)]
+    parts = [srt[:, rb:rb + w].reshape(-1) for _, w, rb in _BC7_STREAMS]
+    parts.append(recs[:, 0].copy())
+    return np.concatenate(parts) if n else np.zeros(0, dtype=np.uint8)
+
+
+def _bc7_unpart(a: np.ndarray) -> np.ndarray:
+    n = a.size // 16
+    first = a[15 * n:16 * n]
+    modes = bc7_modes(first)
+    order = _bc7_sorted_order(modes)
+    recs = np.empty((n, 16), dtype=np.uint8)
+    recs[:, 0] = first
+    for off, w, rb in _BC7_STREAMS:
+        recs[order, rb:rb + w] = a[off * n:(off + w) * n].reshape(n, w)
+    out = np.empty((n, 16), dtype=np.uint8)
+    for i in range(n):
+        b = bc7_block_of_record(int.from_bytes(recs[i].tobytes(), "little"), int(modes[i]))
+        out[i] = np.frombuffer(b.to_bytes(16, "little"), dtype=np.uint8)
+    return out.reshape(-1)
+
+
 def transform_bc7(data) -> np.ndarray:
     blk = _u8(data).reshape(-1, 16)
-    modes = bc7_modes(blk[:, 0])
-    parts = [blk[:, 0].copy()]
-    for m in range(9):
-        sel = blk[modes == m]
-        h = BC7_HEAD[m]
-        parts.append(sel[:, 1:1 + h].reshape(-1))
-        parts.append(sel[:, 1 + h:].reshape(-1))
-    return np.ascontiguousarray(np.concatenate(parts))
+    main_n = blk.shape[0] - blk.shape[0] % BC7_GRANULE
+    return np.ascontiguousarray(np.concatenate([_bc7_part(blk[:main_n]), _bc7_part(blk[main_n:])]))
 
 
 def untransform_bc7(data) -> np.ndarray:
     a = _u8(data)
     n = a.size // 16
-    first = a[:n]
-    modes = bc7_modes(first)
-    out = np.empty((n, 16), dtype=np.uint8)
-    out[:, 0] = first
-    pos = n
-    for m in range(9):
-        idx = np.nonzero(modes == m)[0]
-        h = int(BC7_HEAD[m])
-        c = idx.size
-        out[idx, 1:1 + h] = a[pos:pos + c * h].reshape(c, h)
-        pos += c * h
-        out[idx, 1 + h:] = a[pos:pos + c * (15 - h)].reshape(c, 15 - h)
-        pos += c * (15 - h)
-    return out.reshape(-1)
+    main_n = n - n % BC7_GRANULE
+    return np.ascontiguousarray(np.concatenate([_bc7_unpart(a[:16 * main_n]), _bc7_unpart(a[16 * main_n:])]))
 
 
 # ---- BC1 block normalisation (reference experimental module), second statement: all 16 pixels, vectorised -------------

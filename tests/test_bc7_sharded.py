@@ -1,11 +1,11 @@
-"""Multi-GPU sharding of the BC7 mode-split transform (per-mode counts exchanged on the host, no
-collective).  CPU part: the placement table (dxtlt_bc7_shard_pieces, host code) assembles per-shard ORACLE transforms
-into exactly the whole-buffer oracle transform, for ragged partitions and empty mode classes.  GPU part: the sharded
-entry points with more shards than devices (round robin on the one GPU of the test box) equal the oracle."""
+"""Multi-GPU sharding of the BC7 granule-sorted field split (contiguous ranges, no collective; in
+version 1 of the format no counters are exchanged either -- a granule's output depends on that granule alone).  CPU
+part: the placement table (dxtlt_bc7_shard_pieces, host code) assembles per-shard ORACLE transforms into exactly the
+whole-buffer oracle transform.  GPU part: the sharded entry points with more shards than devices (round robin on the
+one GPU of the test box) equal the oracle."""
 import numpy as np
 import pytest
 
-from oracle import oracle_np as onp
 from tests.test_bc7 import make_blocks
 
 
@@ -21,44 +21,38 @@ def partition(n, cuts):
     return [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
 
 
-def mode_counts(blocks):
-    modes = onp.bc7_modes(blocks.reshape(-1, 16)[:, 0])
-    return [int((modes == m).sum()) for m in range(9)]
-
-
 @pytest.mark.parametrize("kind", ["uniform", "mode6", "skewed", "raw"])
 def test_placement_table_assembles_the_whole_transform(pkg, bc7, oracle, kind):
-    n = 5000
-    x = make_blocks(oracle, n, kind, 21)
-    want = oracle.transform_bc7(x)
-    for cuts in ([], [2500], [1, 2, 4999], [1024, 2048, 3072, 4096], [777, 778, 3001]):
-        parts = partition(n, cuts)
-        counts = [mode_counts(x[16 * f: 16 * (f + c)]) for f, c in parts]
-        firsts, nums = [f for f, _ in parts], [c for _, c in parts]
-        got = np.full(x.size, 0xEE, dtype=np.uint8)
-        covered = np.zeros(x.size, dtype=np.int32)
-        for s, (f, c) in enumerate(parts):
-            local = oracle.transform_bc7(x[16 * f: 16 * (f + c)])
-            g, l, b = bc7.shard_pieces(counts, s, firsts, nums, n)
-            assert sum(b) == 16 * c
-            for p in range(19):
-                got[g[p]: g[p] + b[p]] = local[l[p]: l[p] + b[p]]
-                covered[g[p]: g[p] + b[p]] += 1
-        assert (covered == 1).all(), (kind, cuts)           # the pieces tile the buffer exactly once
-        assert np.array_equal(got, want), (kind, cuts)
+    for n in (5000, 4096, 1024 * 3 + 1):
+        x = make_blocks(oracle, n, kind, 21)
+        want = oracle.transform_bc7(x)
+        for cuts in ([], [2048], [1024, 2048, 3072], [1024], [3072]):
+            parts = partition(n, [c for c in cuts if c < n])
+            got = np.full(x.size, 0xEE, dtype=np.uint8)
+            covered = np.zeros(x.size, dtype=np.int32)
+            for f, c in parts:
+                local = oracle.transform_bc7(x[16 * f: 16 * (f + c)])
+                g, l, b = bc7.shard_pieces(n, f, c)
+                assert sum(b) == 16 * c
+                for p in range(9):
+                    got[g[p]: g[p] + b[p]] = local[l[p]: l[p] + b[p]]
+                    covered[g[p]: g[p] + b[p]] += 1
+            assert (covered == 1).all(), (kind, n, cuts)           # the pieces tile the buffer exactly once
+            assert np.array_equal(got, want), (kind, n, cuts)
 
 
-def test_placement_table_rejects_inconsistent_input(pkg, bc7):
-    counts = [[1, 0, 0, 0, 0, 0, 0, 0, 0], [0, 2, 0, 0, 0, 0, 0, 0, 0]]
-    g, l, b = bc7.shard_pieces(counts, 1, [0, 1], [1, 2], 3)
-    assert b[0] == 2 and g[0] == 1 and l[0] == 0            # `first` piece of shard 1: two bytes at offset 1
-    assert b[2] == 2 * 9 and g[2] == 3 + 15 and b[11] == 2 * 6   # head_1 after mode 0's 15 bytes; tail_1
-    with pytest.raises(pkg.DeviceError):                     # counts do not add up to the shard's size
-        bc7.shard_pieces(counts, 0, [0, 1], [2, 2], 4)
-    with pytest.raises(pkg.DeviceError):                     # ranges are not contiguous
-        bc7.shard_pieces(counts, 0, [0, 2], [1, 2], 4)
+def test_placement_table_rejects_unaligned_shards(pkg, bc7):
+    g, l, b = bc7.shard_pieces(3000, 1024, 1024)
+    assert b[:8] == [8192, 2048, 1024, 1024, 1024, 1024, 1024, 1024] and b[8] == 0
+    assert g[0] == 8 * 1024 and g[1] == 8 * 2048 + 2 * 1024 and g[7] == 15 * 2048 + 1024 and l[1] == 8 * 1024
+    g, l, b = bc7.shard_pieces(3000, 2048, 952)          # the shard that reaches the end: only the tail part
+    assert b[:8] == [0] * 8 and b[8] == 16 * 952 and g[8] == 16 * 2048 and l[8] == 0
+    with pytest.raises(pkg.DeviceError):                     # starts inside a granule
+        bc7.shard_pieces(3000, 100, 1024)
+    with pytest.raises(pkg.DeviceError):                     # ends inside a granule, not at the end
+        bc7.shard_pieces(3000, 0, 1500)
     with pytest.raises(pkg.DeviceError):
-        bc7.shard_pieces(counts, 2, [0, 1], [1, 2], 3)
+        bc7.shard_pieces(3000, 2048, 2000)
 
 
 torch = pytest.importorskip("torch")

@@ -209,6 +209,9 @@ def test_dds_auto_transform(lib, oracle):
         assert np.array_equal(r, d)
 
 
+BC7_PRIVATE_HEADER = 3 | ((0xD175 << 12 | 1) << 4)   # TransformFormat::Bc7, vendor tag 0xD175, format version 1
+
+
 def test_bc7_switch_is_off_by_default_and_needs_no_device(lib):
     """Upstream's dispatch refuses BC7; so do the handler functions unless the caller opts in to this build's format."""
     lib.dxtlt_file_formats_enable_bc7.argtypes, lib.dxtlt_file_formats_enable_bc7.restype = [C.c_bool], None
@@ -219,8 +222,11 @@ def test_bc7_switch_is_off_by_default_and_needs_no_device(lib):
     assert lib.dxtlt_dds_untransform(hdr.ctypes.data, hdr.size, out.ctypes.data, out.size) == 4
     lib.dxtlt_file_formats_enable_bc7(True)
     try:
-        bad = np.concatenate([np.frombuffer(struct.pack("<I", 3 | (1 << 6)), dtype=np.uint8), d[4:]])
-        assert lib.dxtlt_dds_untransform(bad.ctypes.data, bad.size, out.ctypes.data, out.size) == 5   # corrupted data bits
+        # this build's BC7 files carry a vendor tag and a format version in the data bits; all-zero data bits are
+        # upstream's to assign and are refused, as is any other tag or version
+        for word in (3, 3 | (1 << 6), BC7_PRIVATE_HEADER ^ (1 << 4), BC7_PRIVATE_HEADER ^ (1 << 20)):
+            bad = np.concatenate([np.frombuffer(struct.pack("<I", word), dtype=np.uint8), d[4:]])
+            assert lib.dxtlt_dds_untransform(bad.ctypes.data, bad.size, out.ctypes.data, out.size) == 5, hex(word)
     finally:
         lib.dxtlt_file_formats_enable_bc7(False)
 
@@ -236,7 +242,7 @@ def test_bc7_dds_roundtrip_when_enabled(lib, oracle):
     try:
         t = np.zeros_like(d)
         assert lib.dxtlt_dds_transform(d.ctypes.data, d.size, t.ctypes.data, t.size, 1, False, True) == 0
-        assert struct.unpack("<I", t[:4].tobytes())[0] == 3
+        assert struct.unpack("<I", t[:4].tobytes())[0] == BC7_PRIVATE_HEADER
         assert np.array_equal(t[4:off], d[4:off]) and np.array_equal(t[-21:], d[-21:])
         assert np.array_equal(t[off:off + length], oracle.transform_bc7(d[off:off + length]))
         r = np.zeros_like(d)
