@@ -31,6 +31,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 
 #include "bc7_fields.h"
 #include "bc7_launch.h"
@@ -42,22 +43,22 @@ namespace bc7 {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kT = kGranule;          // blocks per granule == lanes per workgroup
-constexpr int kWaves = kT / 64;       // 16
+constexpr int kT = kGranule;          // blocks per granule
+constexpr int kSegments = kT / 64;    // 16 runs of 64 consecutive blocks: one wave instruction's worth each
 constexpr int kClasses = 9;
-static_assert(kT == 1024, "one block per lane, the copy-out assigns whole waves to streams");
+static_assert(kT == 1024, "the copy-out assigns whole 64-block segments to streams");
 
 // stream s of a part of n blocks starts at byte off[s] * n and holds width[s] bytes per block:
 //   s      0 (Q8)  1 (Q2)  2 (B0)  3 (B1)  4 (B2)  5 (B3)  6 (B4)  7 (F)
 //   off    0       8       10      11      12      13      14      15
 //   width  8       2       1       1       1       1       1       1
 
-// LDS: raw blocks at sorted positions | image of the output | per-class per-wave counts | per-wave class bases | sorted F
+// LDS: raw blocks at sorted positions | image of the output | per-class per-segment counts | per-segment class bases | sorted F
 constexpr int kLdsRaw = 0;
 constexpr int kLdsImage = kLdsRaw + kT * 16;
-constexpr int kLdsCounts = kLdsImage + kT * 16;               // uint16_t [9][16]
-constexpr int kLdsBases = kLdsCounts + kClasses * kWaves * 2 + 32;  // uint16_t [16 waves][16]
-constexpr int kLdsSortedF = kLdsBases + kWaves * 16 * 2;      // uint8_t [1024] (inverse)
+constexpr int kLdsCounts = kLdsImage + kT * 16;                       // uint16_t [9][16]
+constexpr int kLdsBases = kLdsCounts + kClasses * kSegments * 2 + 32;  // uint16_t [16 segments][16]
+constexpr int kLdsSortedF = kLdsBases + kSegments * 16 * 2;           // uint8_t [1024] (inverse)
 constexpr int kLdsBytes = kLdsSortedF + kT;
 
 __device__ __forceinline__ u32x4 gload16(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
@@ -68,171 +69,236 @@ __device__ __forceinline__ T& lds_at(uint8_t* lds, int byte_off)
     return *reinterpret_cast<T*>(lds + byte_off);
 }
 
-// Sorted position of this lane's block inside the granule.  cls: 0..8, or 9 for lanes beyond a tail part's blocks (they
-// sort behind everything and are never stored).  Two barriers inside; the counts table must have been zeroed and a
-// barrier passed before the call.
-__device__ __forceinline__ int sorted_position(uint8_t* lds, int cls, int lane, int wave)
+// Rank of this lane's block among the blocks of its class in its 64-block segment (= wave instruction), and the class's
+// count in the segment: lanes with the same class = AND over the class bits of (bit set ? ballot : ~ballot).
+// cls: 0..8, or 9 for lanes beyond a tail part's blocks.
+__device__ __forceinline__ void rank_in_segment(int cls, int& rank, int& count)
 {
-    // lanes of this wave with the same class: AND over the four class bits of (bit set ? ballot : ~ballot)
-    uint64_t same = ~0ull;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool bit = (cls >> k) & 1;
-        const uint64_t b = __ballot(bit);
-        same &= bit ? b : ~b;
+        const int sext = __builtin_amdgcn_sbfe(cls, k, 1);   // -1 when bit k is set, else 0
+        const uint64_t b = __ballot(sext != 0);
+        lo &= ~((uint32_t)b ^ (uint32_t)sext);               // bit set: b, else ~b
+        hi &= ~((uint32_t)(b >> 32) ^ (uint32_t)sext);
     }
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0));
-    const int in_wave = __popcll(same);
-    uint16_t* counts = reinterpret_cast<uint16_t*>(lds + kLdsCounts);
-    if (rank == in_wave - 1 && cls < kClasses)
-        counts[cls * kWaves + wave] = (uint16_t)in_wave;   // the class's last lane in the wave reports its count
-    __syncthreads();
-
-    // lanes 0..8 of every wave, lane = class c: blocks of class c in the waves before this one, and in all waves;
-    // exclusive scan of the totals over the classes; the wave's base for class c
-    {
-        const int c = lane < kClasses ? lane : kClasses - 1;
-        const u32x4 lo = lds_at<u32x4>(lds, kLdsCounts + c * (kWaves * 2));
-        const u32x4 hi = lds_at<u32x4>(lds, kLdsCounts + c * (kWaves * 2) + 16);
-        const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};   // d[k] = counts of waves 2k, 2k + 1
-        uint32_t all = 0, before = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            all += d[k];   // two 16-bit sums side by side; at most 1024 each, no carry between them
-            const uint32_t mask = (2 * k < wave ? 0xFFFFu : 0u) | (2 * k + 1 < wave ? 0xFFFF0000u : 0u);
-            before += d[k] & mask;
-        }
-        const int total = (int)((all & 0xFFFFu) + (all >> 16));
-        const int prior = (int)((before & 0xFFFFu) + (before >> 16));
-        // inclusive scan of `total` over lanes 0..15 of each row (classes sit in lanes 0..8): DPP row_shr 1, 2, 4, 8
-        int x = lane < kClasses ? total : 0;
-        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
-        if (lane < kClasses)
-            lds_at<uint16_t>(lds, kLdsBases + wave * 32 + lane * 2) = (uint16_t)(x - total + prior);
-    }
-    // same wave, LDS operations complete in order: no barrier between the store above and this load
-    const int base = cls < kClasses ? (int)lds_at<uint16_t>(lds, kLdsBases + wave * 32 + cls * 2) : 0;
-    return base + rank;
+    rank = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+    count = __popc(lo) + __popc(hi);
 }
 
-// offset of image byte 16 * t inside a full granule's slices: wave -> stream (8 waves Q8, 2 waves Q2, 6 byte streams)
-__device__ __forceinline__ uint64_t slice_offset_of_lane(int t, int wave, uint64_t part_blocks, uint64_t first_block_of_granule)
+// Every wave turns the counts table into the class bases of ITS segments: 16-lane row r of the wave works on the wave's
+// r-th segment (segment number r * WAVES + wave), lane c of the row on class c: blocks of class c in earlier segments
+// and in all segments; exclusive scan of the totals over the classes (DPP row shifts stay inside a row).
+template <int WAVES, int V>
+__device__ __forceinline__ void segment_bases(uint8_t* lds, int lane, int wave)
 {
-    const int s = wave < 8 ? 0 : wave < 10 ? 1 : wave - 8;   // wave-uniform
-    const int off = s == 0 ? 0 : s == 1 ? 8 : s + 8;          // kOff[s]
-    const int width = s == 0 ? 8 : s == 1 ? 2 : 1;            // kWidth[s]
-    return (uint64_t)off * part_blocks + (uint64_t)width * first_block_of_granule + (uint64_t)(16 * t - off * kT);
+    const int row = lane >> 4, c = (lane & 15) < kClasses ? (lane & 15) : kClasses - 1;
+    const int segment = row * WAVES + wave;   // rows >= V compute something harmless
+    const u32x4 lo = lds_at<u32x4>(lds, kLdsCounts + c * (kSegments * 2));
+    const u32x4 hi = lds_at<u32x4>(lds, kLdsCounts + c * (kSegments * 2) + 16);
+    const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};   // d[k] = counts of segments 2k, 2k + 1
+    uint32_t all = 0, before = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        all += d[k];   // two 16-bit sums side by side; at most 1024 each, no carry between them
+        const uint32_t mask = (2 * k < segment ? 0xFFFFu : 0u) | (2 * k + 1 < segment ? 0xFFFF0000u : 0u);
+        before += d[k] & mask;
+    }
+    const int total = (int)((all & 0xFFFFu) + (all >> 16));
+    const int prior = (int)((before & 0xFFFFu) + (before >> 16));
+    int x = (lane & 15) < kClasses ? total : 0;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1, 2, 4, 8: inclusive scan inside the row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    if (row < V && (lane & 15) < kClasses)
+        lds_at<uint16_t>(lds, kLdsBases + segment * 32 + (lane & 15) * 2) = (uint16_t)(x - total + prior);
 }
 
-// Forward.  aos: the range's first block.  Full granules (TAIL = false): soa = byte 0 of the part's streams, part_blocks
-// = blocks of the part (a multiple of 1024), first_block = the range's first block inside the part (a multiple of 1024),
-// gridDim.x = granules of the range.  TAIL: one workgroup, n = blocks of the tail part (< 1024), soa = its first byte.
-template <bool TAIL>
-__global__ void __launch_bounds__(kT)
+// byte offset, from the part's first byte, of image byte 16 * j of a full granule (j = 0..1023): the image's 64-block
+// segment -> stream (8 segments Q8, 2 segments Q2, one per byte stream); wave-uniform
+__device__ __forceinline__ uint64_t slice_offset(int j, int segment, uint64_t part_blocks, uint64_t first_block_of_granule)
+{
+    const int s = segment < 8 ? 0 : segment < 10 ? 1 : segment - 8;
+    const int off = s == 0 ? 0 : s == 1 ? 8 : s + 8;
+    const int width = s == 0 ? 8 : s == 1 ? 2 : 1;
+    return (uint64_t)off * part_blocks + (uint64_t)width * first_block_of_granule + (uint64_t)(16 * j - off * kT);
+}
+
+// Forward.  LANES lanes per workgroup, V = 1024 / LANES blocks per lane: lane t owns blocks t, t + LANES, ... of the
+// granule (coalesced).  aos: the range's first block.  Full granules (TAIL = false): soa = byte 0 of the part's streams,
+// part_blocks = blocks of the part (a multiple of 1024), first_block = the range's first block inside the part (a
+// multiple of 1024), gridDim.x = granules of the range.  TAIL: one workgroup, n = blocks of the tail part (< 1024),
+// soa = its first byte.
+template <int LANES, bool TAIL>
+__global__ void __launch_bounds__(LANES)
 bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t part_blocks, uint64_t first_block, int n_tail)
 {
+    constexpr int V = kT / LANES, WAVES = LANES / 64;
+    static_assert(V >= 1 && V <= 4 && V * LANES == kT, "four 16-lane rows per wave: at most four segments per wave");
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = TAIL ? n_tail : kT;
     const uint64_t granule = blockIdx.x;
-    const bool live = !TAIL || t < n;
+    const uint8_t* src = aos + granule * (kT * 16);
 
-    u32x4 q = {0, 0, 0, 0};
-    if (live)
-        q = gload16(aos + (granule * kT + (uint64_t)t) * 16);
-    if (t < kClasses * kWaves)
+    u32x4 q[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        q[v] = u32x4{0, 0, 0, 0};
+        if (!TAIL || v * LANES + t < n)
+            q[v] = gload16(src + (v * LANES + t) * 16);
+    }
+    if (t < kClasses * kSegments)
         lds_at<uint16_t>(lds, kLdsCounts + 2 * t) = 0;
     __syncthreads();
 
-    const B128 b = {{q.x, q.y, q.z, q.w}};
-    const int cls = live ? block_class(q.x) : kClasses;
-    const int pos = sorted_position(lds, cls, lane, wave);
-    if (live) {
-        lds_at<u32x4>(lds, kLdsRaw + 16 * pos) = q;
-        lds_at<uint8_t>(lds, kLdsImage + 15 * n + t) = (uint8_t)record_byte0(b, cls);   // F: block order
+    int cls[V], rank[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const bool live = !TAIL || v * LANES + t < n;
+        cls[v] = live ? block_class(q[v].x) : kClasses;
+        int count;
+        rank_in_segment(cls[v], rank[v], count);
+        if (rank[v] == count - 1 && cls[v] < kClasses)   // the class's last lane in the segment reports its count
+            lds_at<uint16_t>(lds, kLdsCounts + cls[v] * (kSegments * 2) + (v * WAVES + wave) * 2) = (uint16_t)count;
     }
     __syncthreads();
 
-    // sorted domain: lane j holds sorted block j; the class is the same across the wave except where two classes meet
-    if (live) {
-        const u32x4 s = lds_at<u32x4>(lds, kLdsRaw + 16 * t);
-        const B128 sb = {{s.x, s.y, s.z, s.w}};
-        const B128 r = record_of_block_any(sb, block_class(s.x));
-        // record bytes 1..8 -> Q8, 9..10 -> Q2, 11..15 -> B0..B4
-        lds_at<u32x2>(lds, kLdsImage + 8 * t) = u32x2{__builtin_amdgcn_alignbyte(r.d[1], r.d[0], 1), __builtin_amdgcn_alignbyte(r.d[2], r.d[1], 1)};
-        lds_at<uint16_t>(lds, kLdsImage + 8 * n + 2 * t) = (uint16_t)(r.d[2] >> 8);
-        lds_at<uint8_t>(lds, kLdsImage + 10 * n + t) = (uint8_t)(r.d[2] >> 24);
-        lds_at<uint8_t>(lds, kLdsImage + 11 * n + t) = (uint8_t)r.d[3];
-        lds_at<uint8_t>(lds, kLdsImage + 12 * n + t) = (uint8_t)(r.d[3] >> 8);
-        lds_at<uint8_t>(lds, kLdsImage + 13 * n + t) = (uint8_t)(r.d[3] >> 16);
-        lds_at<uint8_t>(lds, kLdsImage + 14 * n + t) = (uint8_t)(r.d[3] >> 24);
+    segment_bases<WAVES, V>(lds, lane, wave);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        if (cls[v] < kClasses) {
+            // same wave, LDS operations complete in order: no barrier between segment_bases' stores and this load
+            const int pos = (int)lds_at<uint16_t>(lds, kLdsBases + (v * WAVES + wave) * 32 + cls[v] * 2) + rank[v];
+            const B128 b = {{q[v].x, q[v].y, q[v].z, q[v].w}};
+            lds_at<u32x4>(lds, kLdsRaw + 16 * pos) = q[v];
+            lds_at<uint8_t>(lds, kLdsImage + 15 * n + v * LANES + t) = (uint8_t)record_byte0(b, cls[v]);   // F: block order
+        }
     }
     __syncthreads();
 
-    if constexpr (TAIL) {
-        // the tail part is one contiguous run of 16 n bytes with the image's own layout
-        if (live)
-            *reinterpret_cast<u32x4*>(soa + 16 * t) = lds_at<u32x4>(lds, kLdsImage + 16 * t);
-    } else {
-        const uint64_t o = slice_offset_of_lane(t, wave, part_blocks, first_block + granule * kT);
-        store_streaming16(soa + o, lds_at<u32x4>(lds, kLdsImage + 16 * t));
+    // sorted domain: lane t holds sorted blocks t, t + LANES, ...; the class is the same across a wave's 64 blocks except
+    // where two classes meet
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        if (!TAIL || j < n) {
+            const u32x4 s = lds_at<u32x4>(lds, kLdsRaw + 16 * j);
+            const B128 sb = {{s.x, s.y, s.z, s.w}};
+            const B128 r = record_of_block_any(sb, block_class(s.x));
+            // record bytes 1..8 -> Q8, 9..10 -> Q2, 11..15 -> B0..B4
+            lds_at<u32x2>(lds, kLdsImage + 8 * j) = u32x2{__builtin_amdgcn_alignbyte(r.d[1], r.d[0], 1), __builtin_amdgcn_alignbyte(r.d[2], r.d[1], 1)};
+            lds_at<uint16_t>(lds, kLdsImage + 8 * n + 2 * j) = (uint16_t)(r.d[2] >> 8);
+            lds_at<uint8_t>(lds, kLdsImage + 10 * n + j) = (uint8_t)(r.d[2] >> 24);
+            lds_at<uint8_t>(lds, kLdsImage + 11 * n + j) = (uint8_t)r.d[3];
+            lds_at<uint8_t>(lds, kLdsImage + 12 * n + j) = (uint8_t)(r.d[3] >> 8);
+            lds_at<uint8_t>(lds, kLdsImage + 13 * n + j) = (uint8_t)(r.d[3] >> 16);
+            lds_at<uint8_t>(lds, kLdsImage + 14 * n + j) = (uint8_t)(r.d[3] >> 24);
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        if constexpr (TAIL) {
+            // the tail part is one contiguous run of 16 n bytes with the image's own layout
+            if (j < n)
+                *reinterpret_cast<u32x4*>(soa + 16 * j) = lds_at<u32x4>(lds, kLdsImage + 16 * j);
+        } else {
+            const uint64_t o = slice_offset(j, v * WAVES + wave, part_blocks, first_block + granule * kT);
+            store_streaming16(soa + o, lds_at<u32x4>(lds, kLdsImage + 16 * j));
+        }
     }
 }
 
-template <bool TAIL>
-__global__ void __launch_bounds__(kT)
+template <int LANES, bool TAIL>
+__global__ void __launch_bounds__(LANES)
 bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t part_blocks, uint64_t first_block, int n_tail)
 {
+    constexpr int V = kT / LANES, WAVES = LANES / 64;
+    static_assert(V >= 1 && V <= 4 && V * LANES == kT, "four 16-lane rows per wave: at most four segments per wave");
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = TAIL ? n_tail : kT;
     const uint64_t granule = blockIdx.x;
-    const bool live = !TAIL || t < n;
 
-    if constexpr (TAIL) {
-        if (live)
-            lds_at<u32x4>(lds, kLdsImage + 16 * t) = *reinterpret_cast<const u32x4*>(soa + 16 * t);
-    } else {
-        const uint64_t o = slice_offset_of_lane(t, wave, part_blocks, first_block + granule * kT);
-        lds_at<u32x4>(lds, kLdsImage + 16 * t) = gload16(soa + o);
+    u32x4 in[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        in[v] = u32x4{0, 0, 0, 0};
+        if constexpr (TAIL) {
+            if (j < n)
+                in[v] = *reinterpret_cast<const u32x4*>(soa + 16 * j);
+        } else {
+            in[v] = gload16(soa + slice_offset(j, v * WAVES + wave, part_blocks, first_block + granule * kT));
+        }
     }
-    if (t < kClasses * kWaves)
+    if (t < kClasses * kSegments)
         lds_at<uint16_t>(lds, kLdsCounts + 2 * t) = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        if (!TAIL || v * LANES + t < n)
+            lds_at<u32x4>(lds, kLdsImage + 16 * (v * LANES + t)) = in[v];
     __syncthreads();
 
-    const uint32_t f = live ? lds_at<uint8_t>(lds, kLdsImage + 15 * n + t) : 0u;
-    const int cls = live ? block_class(f) : kClasses;
-    const int pos = sorted_position(lds, cls, lane, wave);
-    if (live)
-        lds_at<uint8_t>(lds, kLdsSortedF + pos) = (uint8_t)f;
-    __syncthreads();
-
-    if (live) {
-        const uint32_t f2 = lds_at<uint8_t>(lds, kLdsSortedF + t);
-        const u32x2 q8 = lds_at<u32x2>(lds, kLdsImage + 8 * t);
-        const uint32_t q2 = lds_at<uint16_t>(lds, kLdsImage + 8 * n + 2 * t);
-        const uint32_t b0 = lds_at<uint8_t>(lds, kLdsImage + 10 * n + t);
-        const uint32_t b1 = lds_at<uint8_t>(lds, kLdsImage + 11 * n + t);
-        const uint32_t b2 = lds_at<uint8_t>(lds, kLdsImage + 12 * n + t);
-        const uint32_t b3 = lds_at<uint8_t>(lds, kLdsImage + 13 * n + t);
-        const uint32_t b4 = lds_at<uint8_t>(lds, kLdsImage + 14 * n + t);
-        B128 r;
-        r.d[0] = f2 | (q8.x << 8);
-        r.d[1] = (q8.x >> 24) | (q8.y << 8);
-        r.d[2] = (q8.y >> 24) | (q2 << 8) | (b0 << 24);
-        r.d[3] = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
-        const B128 blk = block_of_record_any(r, block_class(f2));
-        lds_at<u32x4>(lds, kLdsRaw + 16 * t) = u32x4{blk.d[0], blk.d[1], blk.d[2], blk.d[3]};
+    int cls[V], rank[V];
+    uint32_t f[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const bool live = !TAIL || v * LANES + t < n;
+        f[v] = live ? lds_at<uint8_t>(lds, kLdsImage + 15 * n + v * LANES + t) : 0u;
+        cls[v] = live ? block_class(f[v]) : kClasses;
+        int count;
+        rank_in_segment(cls[v], rank[v], count);
+        if (rank[v] == count - 1 && cls[v] < kClasses)
+            lds_at<uint16_t>(lds, kLdsCounts + cls[v] * (kSegments * 2) + (v * WAVES + wave) * 2) = (uint16_t)count;
     }
     __syncthreads();
 
-    if (live)
-        store_streaming16(aos + (granule * kT + (uint64_t)t) * 16, lds_at<u32x4>(lds, kLdsRaw + 16 * pos));
+    segment_bases<WAVES, V>(lds, lane, wave);
+    int pos[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        pos[v] = 0;
+        if (cls[v] < kClasses) {
+            pos[v] = (int)lds_at<uint16_t>(lds, kLdsBases + (v * WAVES + wave) * 32 + cls[v] * 2) + rank[v];
+            lds_at<uint8_t>(lds, kLdsSortedF + pos[v]) = (uint8_t)f[v];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        if (!TAIL || j < n) {
+            const uint32_t f2 = lds_at<uint8_t>(lds, kLdsSortedF + j);
+            const u32x2 q8 = lds_at<u32x2>(lds, kLdsImage + 8 * j);
+            const uint32_t q2 = lds_at<uint16_t>(lds, kLdsImage + 8 * n + 2 * j);
+            const uint32_t b0 = lds_at<uint8_t>(lds, kLdsImage + 10 * n + j);
+            const uint32_t b1 = lds_at<uint8_t>(lds, kLdsImage + 11 * n + j);
+            const uint32_t b2 = lds_at<uint8_t>(lds, kLdsImage + 12 * n + j);
+            const uint32_t b3 = lds_at<uint8_t>(lds, kLdsImage + 13 * n + j);
+            const uint32_t b4 = lds_at<uint8_t>(lds, kLdsImage + 14 * n + j);
+            B128 r;
+            r.d[0] = f2 | (q8.x << 8);
+            r.d[1] = (q8.x >> 24) | (q8.y << 8);
+            r.d[2] = (q8.y >> 24) | (q2 << 8) | (b0 << 24);
+            r.d[3] = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
+            const B128 blk = block_of_record_any(r, block_class(f2));
+            lds_at<u32x4>(lds, kLdsRaw + 16 * j) = u32x4{blk.d[0], blk.d[1], blk.d[2], blk.d[3]};
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+        if (cls[v] < kClasses)
+            store_streaming16(aos + (granule * kT + (uint64_t)(v * LANES + t)) * 16, lds_at<u32x4>(lds, kLdsRaw + 16 * pos[v]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,17 +320,22 @@ hipError_t launch_range(bool inverse, const void* src, void* dst, uint64_t total
     const uint8_t* aos = static_cast<const uint8_t*>(inverse ? dst : src);     // the range's first block
     const uint8_t* soa = static_cast<const uint8_t*>(inverse ? src : dst);     // byte 0 of the whole transformed buffer
     const uint64_t range_main = first_block >= main_blocks ? 0 : (first_block + num_blocks > main_blocks ? main_blocks : first_block + num_blocks) - first_block;
-    // a launch of 2^32 or more threads is refused: at most 2^21 granules (32 GiB of blocks) per launch
+    // Workgroup size: 256 lanes x 4 blocks per lane unless DXTLT_BC7_LANES says 512 or 1024 (experiments; DESIGN.md
+    // section 9 has the measurements).  A launch of 2^32 or more threads is refused: at most 2^21 granules per launch.
+    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 512 || x == 1024 ? x : 256; }();
+    using Kernel = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int);
+    const Kernel fwd = lanes == 1024 ? bc7_forward<1024, false> : lanes == 512 ? bc7_forward<512, false> : bc7_forward<256, false>;
+    const Kernel inv = lanes == 1024 ? bc7_inverse<1024, false> : lanes == 512 ? bc7_inverse<512, false> : bc7_inverse<256, false>;
     constexpr uint64_t kMaxGranules = 1ull << 21;
     for (uint64_t g0 = 0; g0 < range_main / kT; g0 += kMaxGranules) {
         const uint64_t ng = range_main / kT - g0 < kMaxGranules ? range_main / kT - g0 : kMaxGranules;
         const uint8_t* a = aos + g0 * kT * 16;
         if (inverse)
-            hipLaunchKernelGGL(bc7_inverse<false>, dim3((unsigned)ng), dim3(kT), 0, stream, soa, const_cast<uint8_t*>(a),
-                               main_blocks, first_block + g0 * kT, 0);
+            hipLaunchKernelGGL(inv, dim3((unsigned)ng), dim3(lanes), 0, stream, soa, const_cast<uint8_t*>(a), main_blocks,
+                               first_block + g0 * kT, 0);
         else
-            hipLaunchKernelGGL(bc7_forward<false>, dim3((unsigned)ng), dim3(kT), 0, stream, a, const_cast<uint8_t*>(soa),
-                               main_blocks, first_block + g0 * kT, 0);
+            hipLaunchKernelGGL(fwd, dim3((unsigned)ng), dim3(lanes), 0, stream, a, const_cast<uint8_t*>(soa), main_blocks,
+                               first_block + g0 * kT, 0);
         if (hipError_t e = hipGetLastError(); e != hipSuccess)
             return e;
     }
@@ -272,9 +343,9 @@ hipError_t launch_range(bool inverse, const void* src, void* dst, uint64_t total
         const uint8_t* a = aos + (main_blocks - first_block) * 16;   // first_block <= main_blocks here
         const uint8_t* s = soa + main_blocks * 16;
         if (inverse)
-            hipLaunchKernelGGL(bc7_inverse<true>, dim3(1), dim3(kT), 0, stream, s, const_cast<uint8_t*>(a), tail, 0, (int)tail);
+            hipLaunchKernelGGL((bc7_inverse<256, true>), dim3(1), dim3(256), 0, stream, s, const_cast<uint8_t*>(a), tail, 0, (int)tail);
         else
-            hipLaunchKernelGGL(bc7_forward<true>, dim3(1), dim3(kT), 0, stream, a, const_cast<uint8_t*>(s), tail, 0, (int)tail);
+            hipLaunchKernelGGL((bc7_forward<256, true>), dim3(1), dim3(256), 0, stream, a, const_cast<uint8_t*>(s), tail, 0, (int)tail);
         if (hipError_t e = hipGetLastError(); e != hipSuccess)
             return e;
     }
