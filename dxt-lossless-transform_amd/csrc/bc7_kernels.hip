@@ -71,16 +71,23 @@ __device__ __forceinline__ T& lds_at(uint8_t* lds, int byte_off)
 
 // Rank of this lane's block among the blocks of its class in its 64-block segment (= wave instruction), and the class's
 // count in the segment: lanes with the same class = AND over the class bits of (bit set ? ballot : ~ballot).
-// cls: 0..8, or 9 for lanes beyond a tail part's blocks.
+// cls: 0..8, or 9 for lanes beyond a tail part's blocks.  Classes 8 and 9 are rare: the fourth class bit is only
+// matched when some lane of the wave has it set (a scalar branch).
 __device__ __forceinline__ void rank_in_segment(int cls, int& rank, int& count)
 {
     uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 3; ++k) {
         const int sext = __builtin_amdgcn_sbfe(cls, k, 1);   // -1 when bit k is set, else 0
         const uint64_t b = __ballot(sext != 0);
         lo &= ~((uint32_t)b ^ (uint32_t)sext);               // bit set: b, else ~b
         hi &= ~((uint32_t)(b >> 32) ^ (uint32_t)sext);
+    }
+    const uint64_t high = __ballot(cls >= 8);
+    if (high != 0) {
+        const uint32_t m = cls >= 8 ? 0xFFFFFFFFu : 0u;
+        lo &= ~((uint32_t)high ^ m);
+        hi &= ~((uint32_t)(high >> 32) ^ m);
     }
     rank = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
     count = __popc(lo) + __popc(hi);
@@ -89,21 +96,43 @@ __device__ __forceinline__ void rank_in_segment(int cls, int& rank, int& count)
 // Every wave turns the counts table into the class bases of ITS segments: 16-lane row r of the wave works on the wave's
 // r-th segment (segment number r * WAVES + wave), lane c of the row on class c: blocks of class c in earlier segments
 // and in all segments; exclusive scan of the totals over the classes (DPP row shifts stay inside a row).
+// "Earlier segments" of row r = all of the segment groups 0..r-1 (WAVES segments each) plus the segments of group r
+// below `wave`; the latter is the same masked sum for every group, with masks that depend on the wave number only
+// (scalar registers) -- built per lane from the segment number it cost more vector instructions than everything else
+// in this function.
 template <int WAVES, int V>
 __device__ __forceinline__ void segment_bases(uint8_t* lds, int lane, int wave)
 {
+    constexpr int P = WAVES / 2;   // pairs of 16-bit counts (dwords) per group
+    static_assert(P * 2 == WAVES && P * V == 8, "a group's counts fill whole dwords");
     const int row = lane >> 4, c = (lane & 15) < kClasses ? (lane & 15) : kClasses - 1;
-    const int segment = row * WAVES + wave;   // rows >= V compute something harmless
     const u32x4 lo = lds_at<u32x4>(lds, kLdsCounts + c * (kSegments * 2));
     const u32x4 hi = lds_at<u32x4>(lds, kLdsCounts + c * (kSegments * 2) + 16);
     const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};   // d[k] = counts of segments 2k, 2k + 1
-    uint32_t all = 0, before = 0;
+    uint32_t mask[P];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        all += d[k];   // two 16-bit sums side by side; at most 1024 each, no carry between them
-        const uint32_t mask = (2 * k < segment ? 0xFFFFu : 0u) | (2 * k + 1 < segment ? 0xFFFF0000u : 0u);
-        before += d[k] & mask;
+    for (int j = 0; j < P; ++j)
+        mask[j] = (2 * j < wave ? 0xFFFFu : 0u) | (2 * j + 1 < wave ? 0xFFFF0000u : 0u);   // scalar
+    // two 16-bit sums side by side; at most 1024 each, no carry between them
+    uint32_t group_sum[V], group_below[V];
+#pragma unroll
+    for (int g = 0; g < V; ++g) {
+        group_sum[g] = 0;
+        group_below[g] = 0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            group_sum[g] += d[g * P + j];
+            group_below[g] += d[g * P + j] & mask[j];
+        }
     }
+    uint32_t all = 0, before = 0, running = 0;
+#pragma unroll
+    for (int g = 0; g < V; ++g) {
+        if (row == g)
+            before = running + group_below[g];
+        running += group_sum[g];
+    }
+    all = running;
     const int total = (int)((all & 0xFFFFu) + (all >> 16));
     const int prior = (int)((before & 0xFFFFu) + (before >> 16));
     int x = (lane & 15) < kClasses ? total : 0;
@@ -112,7 +141,7 @@ __device__ __forceinline__ void segment_bases(uint8_t* lds, int lane, int wave)
     x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
     x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
     if (row < V && (lane & 15) < kClasses)
-        lds_at<uint16_t>(lds, kLdsBases + segment * 32 + (lane & 15) * 2) = (uint16_t)(x - total + prior);
+        lds_at<uint16_t>(lds, kLdsBases + (row * WAVES + wave) * 32 + (lane & 15) * 2) = (uint16_t)(x - total + prior);
 }
 
 // byte offset, from the part's first byte, of image byte 16 * j of a full granule (j = 0..1023): the image's 64-block
@@ -320,9 +349,9 @@ hipError_t launch_range(bool inverse, const void* src, void* dst, uint64_t total
     const uint8_t* aos = static_cast<const uint8_t*>(inverse ? dst : src);     // the range's first block
     const uint8_t* soa = static_cast<const uint8_t*>(inverse ? src : dst);     // byte 0 of the whole transformed buffer
     const uint64_t range_main = first_block >= main_blocks ? 0 : (first_block + num_blocks > main_blocks ? main_blocks : first_block + num_blocks) - first_block;
-    // Workgroup size: 256 lanes x 4 blocks per lane unless DXTLT_BC7_LANES says 512 or 1024 (experiments; DESIGN.md
+    // Workgroup size: 512 lanes x 2 blocks per lane unless DXTLT_BC7_LANES says 256 or 1024 (experiments; DESIGN.md
     // section 9 has the measurements).  A launch of 2^32 or more threads is refused: at most 2^21 granules per launch.
-    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 512 || x == 1024 ? x : 256; }();
+    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 256 || x == 1024 ? x : 512; }();
     using Kernel = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int);
     const Kernel fwd = lanes == 1024 ? bc7_forward<1024, false> : lanes == 512 ? bc7_forward<512, false> : bc7_forward<256, false>;
     const Kernel inv = lanes == 1024 ? bc7_inverse<1024, false> : lanes == 512 ? bc7_inverse<512, false> : bc7_inverse<256, false>;
