@@ -12,13 +12,19 @@
 //   * strict `<` against the running best (first best wins), defaults as the initial best;
 //   * if the best candidate was not the last one tried, the data is transformed once more with it.
 //
-// GPU shape: the input is uploaded once; every candidate is one kernel launch on the resident copy (2.6 ms per
-// 8 GiB); only the section(s) the estimator looks at travel back per candidate (half or a quarter of the buffer);
-// the full result is downloaded once at the end.  The estimator itself stays on the CPU behind the callback
-// (zstd ~1 GB/s, LTU ~2.5 GB/s in the reference's own numbers), so it, not the transform, bounds this path.
+// GPU shape: the input is uploaded once.  ONE fused kernel (auto_kernels.hip) reads it once and writes every endpoint
+// section any candidate can show the estimator into a device arena -- 4 / 8 colour sections (YCoCg-R variant x
+// split) and, for BC3, 2 alpha-endpoint sections cover all 4 / 8 / 16 candidates; the index sections are the same for
+// every candidate and are never produced here (transform_auto.rs:245-256).  Per candidate only its section(s) travel
+// back (half or a quarter of the buffer), into the output buffer at the offsets the reference estimates at, and the
+// estimator -- on the CPU behind the callback, as in the reference -- is called in the reference's order with the
+// reference's bytes.  One transform launch with the winning settings and one download of the whole result finish the
+// call.  If the arena (2-4 x len) cannot be allocated the candidates are produced one full transform at a time, as in
+// round 1 (same results, len x 2 of traffic per candidate).
 #include <cstdlib>
 
 #include "../../include/dxtlt_gfx950.h"
+#include "auto_launch.h"
 #include "bcn_launch.h"
 #include "host_common.h"
 
@@ -47,16 +53,53 @@ bool same(const Candidate& a, const Candidate& b)
     return a.mode == b.mode && a.split_alpha == b.split_alpha && a.split_colour == b.split_colour;
 }
 
+// every failure exit drains the stream first: the staging buffers and the arena belong to this thread's next call
 #define HIP_TRY_AUTO(expr, what)                                        \
     do {                                                                \
         hipError_t e_ = (expr);                                         \
         if (e_ != hipSuccess) {                                         \
+            if (st) (void)hipStreamSynchronize(st);                     \
             std::free(scratch);                                         \
             return dxtlt_host::fail(dxtlt_host::kDevice, what, e_);     \
         }                                                               \
     } while (0)
 
+// per-thread candidate arena (grow-only, like the staging buffers)
+struct Arena {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int device = -1;
+    ~Arena() { release(); }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        device = -1;
+    }
+    void* get(size_t bytes)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess)
+            return nullptr;
+        if (dev != device || bytes > cap) {
+            release();
+            if (hipMalloc(&ptr, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                ptr = nullptr;
+                return nullptr;
+            }
+            cap = bytes;
+            device = dev;
+        }
+        return ptr;
+    }
+};
+thread_local Arena g_arena;
+
 }  // namespace
+
+void dxtlt_host::release_auto_thread_arena() { g_arena.release(); }
 
 int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* out, size_t len,
                                    const DltSizeEstimator* est, bool use_all, AutoChoice* choice)
@@ -98,6 +141,7 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
 
     void *d_in = nullptr, *d_out = nullptr;
     hipStream_t st = nullptr;
+    uint8_t* arena = nullptr;   // device: every candidate section, from one read of the input
     if (len > 0) {
         int32_t rc = acquire_staging(len, &d_in, &d_out, &st);
         if (rc != kOk) {
@@ -105,6 +149,12 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
             return rc;
         }
         HIP_TRY_AUTO(hipMemcpyAsync(d_in, in, len, hipMemcpyHostToDevice, st), "H2D copy");
+        static const bool fused = [] { const char* v = std::getenv("DXTLT_AUTO_FUSED"); return !(v && v[0] == '0'); }();
+        if (fused)
+            arena = static_cast<uint8_t*>(g_arena.get((size_t)dxtlt::auto_arena_bytes((dxtlt::Format)format, use_all, blocks)));
+        if (arena != nullptr)
+            HIP_TRY_AUTO(dxtlt::launch_auto_candidates((dxtlt::Format)format, use_all, d_in, arena, blocks, st),
+                         "candidate kernel launch");
     }
 
     const Candidate* order;
@@ -120,19 +170,28 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
     for (int i = 0; i < count; ++i) {
         const Candidate c = order[i];
         if (len > 0) {
-            int32_t rc = enqueue(format, false, d_in, d_out, blocks, c.mode, c.split_alpha, c.split_colour, st);
-            if (rc != kOk) {
-                std::free(scratch);
-                return rc;
+            const uint8_t* alpha_src = (const uint8_t*)d_out;
+            const uint8_t* colour_src = (const uint8_t*)d_out + colour_off;
+            if (arena != nullptr) {
+                alpha_src = arena + dxtlt::auto_alpha_section_offset(blocks, c.split_alpha);
+                colour_src = arena + dxtlt::auto_section_offset((dxtlt::Format)format, blocks, c.mode, c.split_colour);
+            } else {
+                int32_t rc = enqueue(format, false, d_in, d_out, blocks, c.mode, c.split_alpha, c.split_colour, st);
+                if (rc != kOk) {
+                    (void)hipStreamSynchronize(st);
+                    std::free(scratch);
+                    return rc;
+                }
+                last = c;
             }
             if (alpha_len)
-                HIP_TRY_AUTO(hipMemcpyAsync(out, d_out, alpha_len, hipMemcpyDeviceToHost, st), "D2H alpha endpoints");
-            HIP_TRY_AUTO(hipMemcpyAsync(out + colour_off, (const uint8_t*)d_out + colour_off, colour_len,
-                                        hipMemcpyDeviceToHost, st),
+                HIP_TRY_AUTO(hipMemcpyAsync(out, alpha_src, alpha_len, hipMemcpyDeviceToHost, st), "D2H alpha endpoints");
+            HIP_TRY_AUTO(hipMemcpyAsync(out + colour_off, colour_src, colour_len, hipMemcpyDeviceToHost, st),
                          "D2H colour endpoints");
             HIP_TRY_AUTO(hipStreamSynchronize(st), "stream synchronize");
+        } else {
+            last = c;
         }
-        last = c;
 
         size_t total = 0, part = 0;
         if (format == 3) {
@@ -158,9 +217,11 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
     }
 
     if (len > 0) {
-        if (!same(best, last)) {
+        // with the arena no full transform has run yet; without it the last candidate's is in d_out
+        if (arena != nullptr || !same(best, last)) {
             int32_t rc = enqueue(format, false, d_in, d_out, blocks, best.mode, best.split_alpha, best.split_colour, st);
             if (rc != kOk) {
+                (void)hipStreamSynchronize(st);
                 std::free(scratch);
                 return rc;
             }

@@ -20,6 +20,10 @@ enum StableCode : int32_t {
     kInvalidLength = 1,
     kOutputBufferTooSmall = 2,
     kAllocationFailed = 3,
+    // additive, above the reference's range (error.rs:10-40 ends at 12): a caller on a box without a usable GPU must be
+    // able to tell that from an out-of-memory condition
+    kDeviceUnavailable = 100,
+    kDeviceError = 101,
     kSizeEstimationFailed = 4,
     kNullDataPointer = 5,
     kNullEstimatorPointer = 6,
@@ -64,7 +68,9 @@ int32_t map_status(int32_t st)
     case dxtlt_host::kOk: return kSuccess;
     case dxtlt_host::kInvalidLength: return kInvalidLength;
     case dxtlt_host::kEstimator: return kSizeEstimationFailed;
-    default: return kAllocationFailed;  // device / runtime / host allocation failures
+    case dxtlt_host::kAllocation: return kAllocationFailed;
+    case dxtlt_host::kNoDevice: return kDeviceUnavailable;
+    default: return kDeviceError;  // HIP runtime failure: allocation on the device, copy, launch (dxtlt_last_error() has the text)
     }
 }
 
@@ -127,6 +133,8 @@ const char* message(int32_t code, const char* invalid_length_text, const char* s
     case kInvalidLength: return invalid_length_text;
     case kOutputBufferTooSmall: return "Output buffer too small for the operation";
     case kAllocationFailed: return "Memory allocation failed";
+    case kDeviceUnavailable: return "No usable HIP device (this library has no CPU fallback)";
+    case kDeviceError: return "HIP runtime failure (device allocation, copy or kernel launch); see dxtlt_last_error()";
     case kSizeEstimationFailed: return "Size estimation failed during transform optimization";
     case kNullDataPointer: return "Null pointer provided for data parameter";
     case kNullEstimatorPointer: return "Null pointer provided for DltSizeEstimator parameter";

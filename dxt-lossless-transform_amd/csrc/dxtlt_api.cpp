@@ -644,6 +644,7 @@ void dxtlt_release_thread_resources(void)
     dxtlt_host::release_bc7_thread_scratch();
     dxtlt_host::release_normalize_thread_flag();
     dxtlt_host::release_batch_thread_tables();
+    dxtlt_host::release_auto_thread_arena();
 }
 
 }  // extern "C"

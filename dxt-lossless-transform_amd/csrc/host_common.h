@@ -39,6 +39,7 @@ int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, ui
 void release_bc7_thread_scratch();      // bc7_api.cpp
 void release_normalize_thread_flag();   // normalize_api.cpp
 void release_batch_thread_tables();     // batch_api.cpp
+void release_auto_thread_arena();       // auto_transform.cpp
 
 struct AutoChoice {
     uint8_t mode;  // core numbering

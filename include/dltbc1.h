@@ -8,8 +8,9 @@
  *   error.rs:10-47,131                             error codes, Dltbc1Result, dltbc1_error_message
  *   mod.rs:188-217                                 Dltbc1TransformSettings helper struct
  *
- * Host pointers in and out; the transform runs on the current HIP device.  A device or runtime failure is
- * reported as AllocationFailed (3), the only non-argument failure the stable enum has.
+ * Host pointers in and out; the transform runs on the current HIP device.  The reference's enum values keep their
+ * numbers; two additive codes above its range report what a CPU library cannot fail with: DeviceUnavailable (100, no
+ * usable HIP device) and DeviceError (101, HIP runtime failure).
  *
  * NOTE: this header and dltbc1core.h define different types under the same names (they are different cdylibs
  * upstream): include only one of them per translation unit.
@@ -58,6 +59,11 @@ typedef enum Dltbc1ErrorCode {
   NullManualTransformBuilderPointer = 10,
   NullBuilderPointer = 11,
   NullManualBuilderOutputPointer = 12,
+  /* ADDITIVE, above the reference's range (error.rs:10-40 ends at 12): the transform runs on a HIP device, and a caller
+   * must be able to tell a missing or failing device from an out-of-memory condition.  dxtlt_last_error()
+   * (dxtlt_gfx950.h) has the runtime's text. */
+  DeviceUnavailable = 100,
+  DeviceError = 101,
 } Dltbc1ErrorCode;
 
 /* c_api/error.rs:43-47 */

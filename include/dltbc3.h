@@ -54,6 +54,11 @@ typedef enum Dltbc3ErrorCode {
   NullManualTransformBuilderPointer = 10,
   NullBuilderPointer = 11,
   NullManualBuilderOutputPointer = 12,
+  /* ADDITIVE, above the reference's range (error.rs:10-40 ends at 12): the transform runs on a HIP device, and a caller
+   * must be able to tell a missing or failing device from an out-of-memory condition.  dxtlt_last_error()
+   * (dxtlt_gfx950.h) has the runtime's text. */
+  DeviceUnavailable = 100,
+  DeviceError = 101,
 } Dltbc3ErrorCode;
 
 /* c_api/error.rs:43-47 */

@@ -28,6 +28,9 @@ typedef enum Dltbc7ErrorCode {
   Dltbc7NullDataPointer = 5,
   Dltbc7NullOutputBufferPointer = 9,
   Dltbc7NullManualTransformBuilderPointer = 10,
+  /* additive (above the reference's range): no usable HIP device / HIP runtime failure */
+  Dltbc7DeviceUnavailable = 100,
+  Dltbc7DeviceError = 101,
 } Dltbc7ErrorCode;
 
 /* c_api/error.rs:43-47 */

@@ -76,13 +76,15 @@ def make_estimator(kind: str, log=None):
     def py_estimate(buf: bytes) -> int:
         if kind == "zlib":
             return len(zlib.compress(buf, 1))
+        if kind == "crc":          # every byte of the section matters; the log records what the estimator was shown
+            return zlib.crc32(buf) & 0xFFFFF
         return len(buf)
 
     @MAXFN
     def max_fn(ctx, n, out):
         if kind == "fail_max":
             return 41
-        out[0] = n + 64 if kind == "zlib" else (0 if kind == "dummy0" else n)
+        out[0] = n + 64 if kind in ("zlib", "crc") else (0 if kind == "dummy0" else n)
         return 0
 
     @ESTFN
@@ -91,7 +93,7 @@ def make_estimator(kind: str, log=None):
             return 42
         data = C.string_at(inp, n) if n else b""
         if log is not None:
-            log.append(n)
+            log.append((n, zlib.crc32(data)) if kind == "crc" else n)
         out[0] = py_estimate(data)
         return 0
 

@@ -121,6 +121,23 @@ def test_error_messages(lib):
         assert lib.dltbc1_error_message(code) and lib.dltbc2_error_message(code)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_stable_api_tells_a_missing_device_from_an_allocation_failure(lib, n):
+    """Additive codes above the reference's range: on a box without a usable GPU a valid call reports DeviceUnavailable
+    (100), not the reference's AllocationFailed (3); both have a message."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    p = f"dltbc{n}_"
+    b = getattr(lib, p + "new_ManualTransformBuilder")()
+    x, y = np.frombuffer(DATA16 * 2, dtype=np.uint8).copy(), buf(32)
+    assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, 32, y.ctypes.data, 32, b).ErrorCode == 100
+    assert getattr(lib, p + "ManualTransformBuilder_Transform")(x.ctypes.data, 0, y.ctypes.data, 0, b).ErrorCode == 0   # nothing to do
+    getattr(lib, p + "free_ManualTransformBuilder")(b)
+    msg = getattr(lib, p + "error_message")
+    assert b"HIP device" in msg(100) and b"HIP runtime" in msg(101) and msg(3) == b"Memory allocation failed"
+
+
 def test_struct_layouts_match_headers():
     # core: {bool, u8} = 2 bytes; BC3 additive {bool, bool, u8} = 3 bytes; estimator = 3 pointers
     assert C.sizeof(cabi.CoreSettings2) == 2 and C.sizeof(cabi.CoreSettings3) == 3

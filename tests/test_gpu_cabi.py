@@ -1,6 +1,8 @@
 """The reference-shaped C APIs (core dltbcNcore_*, stable dltbcN_*) end to end on the GPU, against the oracle."""
 import ctypes as C
 
+import zlib
+
 import numpy as np
 import pytest
 
@@ -99,6 +101,25 @@ def test_core_auto_matches_reference_algorithm(lib, oracle, n, use_all):
         z = np.zeros_like(x)
         assert getattr(lib, f"dltbc{n}core_untransform")(y.ctypes.data, y.size, z.ctypes.data, z.size, out).ErrorCode == 0
         assert np.array_equal(z, x)
+    # every byte the estimator is shown, candidate by candidate: the sections come from the fused candidate kernel's
+    # arena (one read of the input), the oracle's from one full transform per candidate
+    for blocks in (1, 2, 3, 255, 256, 257, 4099):
+        xs = np.ascontiguousarray(np.resize(x, blocks * (8 if n == 1 else 16)))
+        log, seen = [], []
+        est, py_est = cabi.make_estimator("crc", log)
+
+        def spy(b):
+            seen.append((len(b), zlib.crc32(bytes(b))))
+            return py_est(bytes(b))
+
+        want_choice, want_out, _ = oracle_auto.transform_auto(fmt, xs, spy, use_all)
+        y = np.zeros_like(xs)
+        out = CORE_S[n]()
+        r = getattr(lib, f"dltbc{n}core_transform_auto")(xs.ctypes.data, xs.size, y.ctypes.data, y.size, C.byref(est),
+                                                         cabi.AutoSettings(use_all), C.byref(out))
+        assert r.ErrorCode == 0 and log == seen, (blocks, use_all)
+        got = (out.DecorrelationMode, int(out.SplitAlphaEndpoints) if n == 3 else 0, int(out.SplitColourEndpoints))
+        assert got == want_choice and np.array_equal(y, want_out), blocks
     if not use_all and n != 3:
         # with a constant estimator the strict `<` keeps the FIRST candidate: None / NoSplit (settings.rs:81-86)
         assert oracle_auto.transform_auto(fmt, x, len, False)[0] == (0, 0, 0)

@@ -649,12 +649,17 @@ def _window_check(pkg, oracle, fmt, s, x, y, total_blocks, first, count):
     assert np.array_equal(got, want), (fmt, first, count)
 
 
-@pytest.mark.parametrize("fmt,seed", [("bc1", 0x0BC10002), ("bc3", 0x0BC30003)])
-def test_eight_gib_properties(pkg, oracle, dev, fmt, seed):
-    nbytes = 8 << 30
+@pytest.mark.parametrize("fmt,seed,s,drop", [
+    ("bc1", 0x0BC10002, (1, 1, 1), 0), ("bc3", 0x0BC30003, (1, 1, 1), 0),   # BASELINE.json configs[1], [2]: default settings
+    ("bc1", 0x0BC10002, (2, 0, 0), 0),      # one non-default combination per format at the full size
+    ("bc3", 0x0BC30003, (3, 0, 1), 0),
+    ("bc2", 0x0BC20002, (1, 0, 1), 0),      # BC2 at 8 GiB once
+    ("bc3", 0x0BC30003, (1, 1, 1), 5),      # 2^29 - 5 blocks: every stream base misaligned (halo tiles, shifted inverse)
+])
+def test_eight_gib_properties(pkg, oracle, dev, fmt, seed, s, drop):
     B = BLOCK[fmt]
+    nbytes = (8 << 30) - drop * B
     total = nbytes // B
-    s = (1, 1, 1)
     st = pkg_settings(pkg, fmt, s)
     x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     pkg.fill_splitmix64(x, seed)
