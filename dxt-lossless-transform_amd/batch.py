@@ -46,3 +46,46 @@ def transform_batch(items: Sequence[Tuple[str, bool, object, object, object]]) -
         rc = l.dxtlt_transform_batch_device(arr, len(items), torch.cuda.current_stream().cuda_stream)
     if rc != _lib.OK:
         raise DeviceError(rc, _lib.last_error())
+
+
+def prepare_batch_host(items: Sequence[Tuple[str, bool, object, object, object]]):
+    """The C item array of a host batch (and the buffers it points into), for callers that run the same batch again."""
+    from . import (_FMT_ID, BLOCK_BYTES, InvalidLength, OutputBufferTooSmall, _Buf, _settings_tuple)
+
+    arr = (DxtltBatchItem * len(items))()
+    keep = []
+    for k, (fmt, inverse, src, dst, settings) in enumerate(items):
+        s, d = _Buf(src, False), _Buf(dst, True)
+        if s.device is not None or d.device is not None:
+            raise TypeError("transform_batch_host takes host buffers")
+        if s.nbytes % BLOCK_BYTES[fmt] != 0:
+            raise InvalidLength(s.nbytes)
+        if d.nbytes < s.nbytes:
+            raise OutputBufferTooSmall(s.nbytes, d.nbytes)
+        mode, sa, sc = _settings_tuple(fmt, settings)
+        arr[k].d_input, arr[k].d_output, arr[k].len = s.ptr, d.ptr, s.nbytes
+        arr[k].format, arr[k].inverse, arr[k].decorrelation_mode = _FMT_ID[fmt], int(bool(inverse)), mode
+        arr[k].split_alpha_endpoints, arr[k].split_colour_endpoints = int(bool(sa)), int(bool(sc))
+        keep.append((s, d))
+    return arr, keep
+
+
+def run_prepared_batch_host(prepared) -> None:
+    from . import DeviceError
+
+    arr, _keep = prepared
+    l = _lib.load()
+    l.dxtlt_transform_batch_host.argtypes = [C.POINTER(DxtltBatchItem), C.c_size_t]
+    l.dxtlt_transform_batch_host.restype = C.c_int32
+    rc = l.dxtlt_transform_batch_host(arr, len(arr))
+    if rc != _lib.OK:
+        raise DeviceError(rc, _lib.last_error())
+
+
+def transform_batch_host(items: Sequence[Tuple[str, bool, object, object, object]]) -> None:
+    """items: (fmt, inverse, input, output, settings) with HOST buffers (numpy uint8 / bytes / bytearray): packed side by
+    side, one upload, one launch per (format, direction) and one download per ~64 MiB chunk, unpacked
+    (dxtlt_transform_batch_host)."""
+    if not items:
+        return
+    run_prepared_batch_host(prepare_batch_host(items))

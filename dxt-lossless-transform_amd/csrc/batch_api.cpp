@@ -10,7 +10,12 @@
 // element path with that buffer's settings.  Asynchronous and ordered like a single call on the caller's stream.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/dxtlt_gfx950.h"
@@ -98,8 +103,6 @@ thread_local TableRing g_ring;
 
 }  // namespace
 
-void dxtlt_host::release_batch_thread_tables() { g_ring.release(); }
-
 extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, size_t count, void* hip_stream)
 {
     if (count == 0)
@@ -184,5 +187,315 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         if (ev != hipSuccess)
             return fail(kDevice, "batch event", ev);
     }
+    return kOk;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dxtlt_transform_batch_host: the same, for HOST buffers -- the reference's actual call pattern: one call per file,
+// host pointers, textures of 0.1-20 MiB (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:154-199).
+// Through the single-buffer entry points every texture pays a PCIe round trip of its own (1 MiB: 149 us = 6.6 GiB/s,
+// DESIGN.md section 5).  Here the batch is cut into chunks of about 64 MiB and every chunk takes five steps:
+//     pack      a few host threads copy the chunk's buffers side by side into a PINNED arena
+//     upload    one asynchronous copy of the whole chunk
+//     kernels   one batch launch per (format, direction) present in the chunk
+//     download  one asynchronous copy into a second pinned arena
+//     unpack    host threads copy every result to its caller's buffer
+// with two arenas per direction, so that packing chunk k + 1, moving chunk k and unpacking chunk k - 1 overlap and PCIe
+// runs in both directions at once.  (A first version let several threads issue one small pageable copy per buffer
+// straight from / to the callers' memory: 21 GiB/s at 1 MiB per buffer, 16 at 4 MiB -- the runtime pins pageable memory
+// on the fly above 1 MiB; profiles/r02_d_batch_host.txt.)  Synchronous; every failure exit joins the threads and drains
+// the streams before the arenas are released for reuse.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// chunk size and copy threads per direction; DXTLT_BATCH_CHUNK_MIB / DXTLT_BATCH_THREADS override them (experiments)
+size_t env_number(const char* name, size_t fallback)
+{
+    const char* v = std::getenv(name);
+    const unsigned long long x = v ? std::strtoull(v, nullptr, 10) : 0;
+    return x ? (size_t)x : fallback;
+}
+const size_t kHostBatchChunkBytes = env_number("DXTLT_BATCH_CHUNK_MIB", 64) << 20;
+const int kCopyThreads = (int)std::min<size_t>(64, env_number("DXTLT_BATCH_THREADS", 6));
+
+// pinned arenas of the calling thread: two per direction, grow-only
+struct PinnedArenas {
+    void* in[2] = {nullptr, nullptr};
+    void* out[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    ~PinnedArenas() { release(); }
+    void release()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (in[i]) (void)hipHostFree(in[i]);
+            if (out[i]) (void)hipHostFree(out[i]);
+            in[i] = out[i] = nullptr;
+        }
+        cap = 0;
+    }
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        release();
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipHostMalloc(&in[i], bytes, hipHostMallocDefault);
+            if (e == hipSuccess)
+                e = hipHostMalloc(&out[i], bytes, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                release();
+                return e;
+            }
+        }
+        cap = bytes;
+        return hipSuccess;
+    }
+};
+thread_local PinnedArenas g_pinned;
+#define g_pinned_in(c) (pinned_in[(c) & 1])
+#define g_pinned_out(c) (pinned_out[(c) & 1])
+
+struct HostBatchShared {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<int> packed;     // per chunk: packer threads that have finished it
+    std::vector<int> unpacked;   // per chunk: unpacker threads that have finished it
+    int uploaded_recorded = 0;   // chunks whose upload event has been recorded
+    int enqueued = 0;            // chunks whose upload, kernels and download have been enqueued
+    bool failed = false;
+    hipError_t error = hipSuccess;
+};
+
+}  // namespace
+
+void dxtlt_host::release_batch_thread_tables()
+{
+    g_ring.release();
+    g_pinned.release();
+}
+
+extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_t count)
+{
+    if (count == 0)
+        return kOk;
+    if (items == nullptr)
+        return fail(kInvalidArgument, "NULL item array with count > 0");
+    uint64_t total = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const DxtltBatchItem& it = items[i];
+        if (it.format < 1 || it.format > 3)
+            return fail(kInvalidArgument, "batch item: format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
+        if (it.len % (it.format == 1 ? 8u : 16u) != 0)
+            return fail(kInvalidLength, "batch item: len is not a multiple of the block size");
+        if (it.decorrelation_mode > 3)
+            return fail(kInvalidArgument, "batch item: decorrelation_mode must be 0..3");
+        if (it.len > 0 && (it.d_input == nullptr || it.d_output == nullptr))
+            return fail(kInvalidArgument, "batch item: NULL buffer with len > 0");
+        if (it.len >= (size_t(4) << 30))
+            return fail(kInvalidArgument, "batch item of 4 GiB or more: use the single-buffer entry point");
+        total += (it.len + 255) & ~uint64_t(255);
+    }
+    if (total == 0)
+        return kOk;
+
+    // chunks, and every item's 256-byte aligned slot inside its chunk (the same offset in all four arenas and on the device)
+    std::vector<uint64_t> slot(count);
+    std::vector<size_t> chunk_first;   // first item of every chunk, plus the end
+    std::vector<uint64_t> chunk_bytes;
+    {
+        uint64_t in_chunk = 0;
+        chunk_first.push_back(0);
+        for (size_t i = 0; i < count; ++i) {
+            if (in_chunk >= kHostBatchChunkBytes) {
+                chunk_first.push_back(i);
+                chunk_bytes.push_back(in_chunk);
+                in_chunk = 0;
+            }
+            slot[i] = in_chunk;
+            in_chunk += (items[i].len + 255) & ~uint64_t(255);
+        }
+        chunk_first.push_back(count);
+        chunk_bytes.push_back(in_chunk);
+    }
+    const int nchunks = (int)chunk_bytes.size();
+    const uint64_t arena_bytes = *std::max_element(chunk_bytes.begin(), chunk_bytes.end());
+
+    // device: two chunk-sized slots per direction inside this thread's staging buffers
+    void *d_in = nullptr, *d_out = nullptr;
+    hipStream_t up = nullptr;
+    if (int32_t rc = acquire_staging((size_t)(2 * arena_bytes), &d_in, &d_out, &up); rc != kOk)
+        return rc;
+    if (hipError_t e = g_pinned.reserve((size_t)arena_bytes); e != hipSuccess)
+        return fail(kDevice, "hipHostMalloc(batch arenas)", e);
+    // worker threads do not see this thread's thread_local arenas: hand them the pointers
+    void* const pinned_in[2] = {g_pinned.in[0], g_pinned.in[1]};
+    void* const pinned_out[2] = {g_pinned.out[0], g_pinned.out[1]};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipStream_t down = nullptr;
+    if (hipError_t e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking); e != hipSuccess)
+        return fail(kDevice, "hipStreamCreate(download)", e);
+
+    std::vector<hipEvent_t> ev((size_t)nchunks * 3, nullptr);   // per chunk: uploaded, kernels done, downloaded
+    for (auto& e : ev)
+        if (hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming); err != hipSuccess) {
+            for (auto& e2 : ev) if (e2) (void)hipEventDestroy(e2);
+            (void)hipStreamDestroy(down);
+            return fail(kDevice, "hipEventCreate", err);
+        }
+    auto ev_uploaded = [&](int c) { return ev[(size_t)c * 3]; };
+    auto ev_kernels = [&](int c) { return ev[(size_t)c * 3 + 1]; };
+    auto ev_downloaded = [&](int c) { return ev[(size_t)c * 3 + 2]; };
+
+    HostBatchShared sh;
+    sh.packed.assign((size_t)nchunks, 0);
+    sh.unpacked.assign((size_t)nchunks, 0);
+    auto set_failed = [&](hipError_t e) {
+        std::lock_guard<std::mutex> lk(sh.m);
+        if (!sh.failed) {
+            sh.failed = true;
+            sh.error = e;
+        }
+        sh.cv.notify_all();
+    };
+
+    // item i of a chunk belongs to copy thread (i - chunk_first) % kCopyThreads
+    auto packer = [&](int tid) {
+        hipError_t e = hipSetDevice(dev);
+        for (int c = 0; c < nchunks && e == hipSuccess; ++c) {
+            if (c >= 2) {
+                // arena c % 2 is free once chunk c - 2 has left it
+                {
+                    std::unique_lock<std::mutex> lk(sh.m);
+                    sh.cv.wait(lk, [&] { return sh.uploaded_recorded > c - 2 || sh.failed; });
+                    if (sh.failed)
+                        return;
+                }
+                e = hipEventSynchronize(ev_uploaded(c - 2));
+                if (e != hipSuccess)
+                    break;
+            }
+            uint8_t* arena = static_cast<uint8_t*>(g_pinned_in(c));
+            for (size_t i = chunk_first[(size_t)c] + (size_t)tid; i < chunk_first[(size_t)c + 1]; i += kCopyThreads)
+                if (items[i].len)
+                    std::memcpy(arena + slot[i], items[i].d_input, items[i].len);
+            {
+                std::lock_guard<std::mutex> lk(sh.m);
+                sh.packed[(size_t)c]++;
+            }
+            sh.cv.notify_all();
+        }
+        if (e != hipSuccess)
+            set_failed(e);
+    };
+    auto unpacker = [&](int tid) {
+        hipError_t e = hipSetDevice(dev);
+        for (int c = 0; c < nchunks && e == hipSuccess; ++c) {
+            {
+                std::unique_lock<std::mutex> lk(sh.m);
+                sh.cv.wait(lk, [&] { return sh.enqueued > c || sh.failed; });
+                if (sh.enqueued <= c)
+                    return;
+            }
+            e = hipEventSynchronize(ev_downloaded(c));
+            if (e != hipSuccess)
+                break;
+            const uint8_t* arena = static_cast<const uint8_t*>(g_pinned_out(c));
+            for (size_t i = chunk_first[(size_t)c] + (size_t)tid; i < chunk_first[(size_t)c + 1]; i += kCopyThreads)
+                if (items[i].len)
+                    std::memcpy(items[i].d_output, arena + slot[i], items[i].len);
+            {
+                std::lock_guard<std::mutex> lk(sh.m);
+                sh.unpacked[(size_t)c]++;
+            }
+            sh.cv.notify_all();
+        }
+        if (e != hipSuccess)
+            set_failed(e);
+    };
+
+    std::vector<std::thread> threads;
+    for (int t = 0; t < kCopyThreads; ++t) threads.emplace_back(packer, t);
+    for (int t = 0; t < kCopyThreads; ++t) threads.emplace_back(unpacker, t);
+
+    // this thread: upload, kernels, download of every chunk, as soon as it is packed and its arenas are free
+    int32_t rc = kOk;
+    hipError_t err = hipSuccess;
+    std::vector<DxtltBatchItem> dev_items;
+    for (int c = 0; c < nchunks && rc == kOk && err == hipSuccess; ++c) {
+        {
+            std::unique_lock<std::mutex> lk(sh.m);
+            // packed, and the output arena of chunk c - 2 has been emptied by the unpackers
+            sh.cv.wait(lk, [&] { return (sh.packed[(size_t)c] == kCopyThreads && (c < 2 || sh.unpacked[(size_t)c - 2] == kCopyThreads)) || sh.failed; });
+            if (sh.failed)
+                break;
+        }
+        uint8_t* di = static_cast<uint8_t*>(d_in) + (size_t)(c & 1) * arena_bytes;
+        uint8_t* dout = static_cast<uint8_t*>(d_out) + (size_t)(c & 1) * arena_bytes;
+        // device slot c % 2: its previous chunk's download must have been issued behind its kernels (stream order on
+        // `down`) and its kernels behind its upload (stream order on `up`); the upload of chunk c must not overtake the
+        // download of chunk c - 2, which reads the same device output slot's twin -- different buffers, no hazard; the
+        // INPUT slot is rewritten here, so wait for chunk c - 2's kernels
+        if (c >= 2)
+            err = hipStreamWaitEvent(up, ev_kernels(c - 2), 0);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(di, g_pinned_in(c), (size_t)chunk_bytes[(size_t)c], hipMemcpyHostToDevice, up);
+        if (err == hipSuccess)
+            err = hipEventRecord(ev_uploaded(c), up);
+        {
+            std::lock_guard<std::mutex> lk(sh.m);
+            if (err == hipSuccess)
+                sh.uploaded_recorded = c + 1;
+        }
+        sh.cv.notify_all();
+        if (err != hipSuccess)
+            break;
+        // the kernels write device output slot c % 2: chunk c - 2's download must have read it
+        if (c >= 2)
+            err = hipStreamWaitEvent(up, ev_downloaded(c - 2), 0);
+        if (err != hipSuccess)
+            break;
+        dev_items.clear();
+        for (size_t i = chunk_first[(size_t)c]; i < chunk_first[(size_t)c + 1]; ++i) {
+            DxtltBatchItem it = items[i];
+            it.d_input = di + slot[i];
+            it.d_output = dout + slot[i];
+            dev_items.push_back(it);
+        }
+        rc = dxtlt_transform_batch_device(dev_items.data(), dev_items.size(), up);
+        if (rc != kOk)
+            break;
+        err = hipEventRecord(ev_kernels(c), up);
+        if (err == hipSuccess)
+            err = hipStreamWaitEvent(down, ev_kernels(c), 0);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(g_pinned_out(c), dout, (size_t)chunk_bytes[(size_t)c], hipMemcpyDeviceToHost, down);
+        if (err == hipSuccess)
+            err = hipEventRecord(ev_downloaded(c), down);
+        if (err != hipSuccess)
+            break;
+        {
+            std::lock_guard<std::mutex> lk(sh.m);
+            sh.enqueued = c + 1;
+        }
+        sh.cv.notify_all();
+    }
+    if (rc != kOk || err != hipSuccess) {
+        std::lock_guard<std::mutex> lk(sh.m);
+        sh.failed = true;
+        if (err != hipSuccess && sh.error == hipSuccess)
+            sh.error = err;
+        sh.cv.notify_all();
+    }
+    for (auto& t : threads)
+        t.join();
+    (void)hipStreamSynchronize(up);
+    (void)hipStreamSynchronize(down);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(down);
+    if (rc != kOk)
+        return rc;
+    if (sh.failed)
+        return fail(kDevice, "host batch copy", sh.error);
     return kOk;
 }

@@ -149,6 +149,14 @@ typedef struct DxtltBatchItem {
 } DxtltBatchItem;
 int32_t dxtlt_transform_batch_device(const DxtltBatchItem *items, size_t count, void *hip_stream);
 
+/* The same for HOST buffers (d_input / d_output of every item are host pointers here) -- the reference's own call
+ * pattern: one call per file, host pointers, textures of 0.1-20 MiB (tools/dxt-lossless-transform-cli/src/commands/
+ * transform/mod.rs:154-199).  Through the single-buffer host entry points every texture pays a PCIe round trip of its
+ * own (1 MiB: 6.6 GiB/s); this call uploads the buffers side by side into one device arena, transforms them with one
+ * launch per (format, direction) and chunk of ~64 MiB, and downloads the results, with upload, kernels and download of
+ * consecutive chunks overlapped.  Synchronous; items of less than 4 GiB each; validated as a whole first. */
+int32_t dxtlt_transform_batch_host(const DxtltBatchItem *items, size_t count);
+
 /* ---- single-process multi-GPU: shard [0, N) by contiguous block range over `num_devices` GPUs -----
  * Host pointers.  Each device receives its slice of the input, runs the range kernel, and its slice of
  * every output stream is copied straight to its final place in `output_ptr` (no collective; see

@@ -88,3 +88,37 @@ def test_batch_validation_is_all_or_nothing(pkg):
     assert l.dxtlt_transform_batch_device(arr, 2, None) == 2
     assert l.dxtlt_transform_batch_device(None, 0, None) == 0
     assert l.dxtlt_transform_batch_device(None, 1, None) == 2
+
+
+@pytest.mark.gpu
+def test_host_batch_equals_oracle_item_by_item(pkg, oracle):
+    """dxtlt_transform_batch_host: the reference's call pattern (many small HOST buffers) in one call -- mixed formats,
+    directions, settings and sizes, several 64 MiB chunks, guard bytes behind every output."""
+    from dxt_lossless_transform_amd import batch
+
+    rng = np.random.default_rng(0x4057)
+    items, expect = [], []
+    sizes = [0, 1, 3, 255, 256, 1025, 5463, 21845, 65536, 131073, 700_001]
+    for k in range(260):
+        fmt = FORMATS[k % 3]
+        blocks = int(rng.choice(sizes))
+        v, sa, sc = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        x = oracle.fill_splitmix64(blocks * pkg.BLOCK_BYTES[fmt], 0x4057 + k)
+        inverse = bool(k % 2)
+        want = oracle.transform(fmt, x, v, bool(sc), bool(sa), inverse=inverse)
+        y = np.full(x.size + 32, 0x5A, dtype=np.uint8)
+        items.append((fmt, inverse, x, y[: x.size], settings_for(pkg, fmt, v, sa, sc)))
+        expect.append((want, y, x.size))
+    assert sum(n for _, _, n in expect) > 3 * (64 << 20)      # more than three chunks
+    batch.transform_batch_host(items)
+    for k, (want, y, n) in enumerate(expect):
+        assert np.array_equal(y[:n], want), k
+        assert (y[n:] == 0x5A).all(), k
+    batch.transform_batch_host([])
+    with pytest.raises(pkg.InvalidLength):
+        batch.transform_batch_host([("bc1", False, np.zeros(12, np.uint8), np.zeros(12, np.uint8), pkg.Bc1TransformSettings())])
+    # a failing item leaves the library usable: the next call works
+    x = oracle.fill_splitmix64(4096 * 8, 7)
+    y = np.zeros_like(x)
+    batch.transform_batch_host([("bc1", False, x, y, pkg.Bc1TransformSettings())])
+    assert np.array_equal(y, oracle.transform("bc1", x, 1, True))
