@@ -200,7 +200,35 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
         "sample": f"{sample_mib} MiB of the same {fmt.upper()} splitmix64 workload, forward+inverse, best of 3, "
                   f"scalar C oracle (gcc -O3)",
         "all_cores_value": round(allc, 3), "all_cores": cores,
+        "note": "scalar port of the reference's loops" + (
+            "; for BC3 with split alphas + split colours + decorrelation (the default settings) the reference itself "
+            "dispatches to its scalar loop (bc3 with_split_alphas_colour_and_recorr/transform/mod.rs:31), so this leg matches "
+            "upstream's own path" if fmt == "bc3" and (v, bool(sa), bool(sc)) == (1, True, True) else
+            "; the reference has vectorised paths for these settings that this leg does not reproduce"),
     }
+    # AVX2 ports exist for BC2 default {Variant1, split colours} and BC3 "standard" {None, no splits} too
+    simd23 = {("bc2", 1, True): 2, ("bc3", 0, False): 3}.get((fmt, v, bool(sc))) if not (fmt == "bc3" and sa) else None
+    if simd23 and oracle_c.simd_level() >= 2:
+        def run23(threads, reps):
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                oracle_c.run_bc23_simd(simd23, x, y, False, threads)
+                oracle_c.run_bc23_simd(simd23, y, z, True, threads)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            return 2 * nbytes / best / 2**30
+
+        z[:] = 0
+        one23, all23 = run23(1, 3), run23(cores, 3)
+        assert np.array_equal(z, x)
+        out.update({
+            "scalar_value": out["value"], "scalar_all_cores_value": out["all_cores_value"],
+            "value": round(one23, 3), "all_cores_value": round(all23, 3), "isa": "AVX2",
+            "sample": f"{sample_mib} MiB of the same {fmt.upper()} splitmix64 workload, forward+inverse, best of 3, AVX2 port of "
+                      "the reference's SIMD strategy (oracle/dxtlt_oracle_avx2.c, gcc -O3); scalar_* = scalar C oracle",
+            "note": "AVX2 port of the reference's vectorised path for these settings, pinned to the scalar oracle",
+        })
     # Vectorised ports of the reference's AVX2 / AVX-512BW strategy exist for the headline settings (BC1, Variant1 +
     # split): when the host has AVX2 the widest one becomes the quoted figure (closest analogue of "the reference's SIMD path on one core").
     if fmt == "bc1" and (v, bool(sc)) == (1, True) and oracle_c.simd_available():

@@ -607,6 +607,14 @@ static void *mt_worker(void *arg)
     return NULL;
 }
 
+/* one block range of a buffer of n_total blocks through the scalar loops (tails of the vectorised ports) */
+void oracle_transform_range(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count,
+                            int variant, int split_alpha, int split_colour)
+{
+    struct mt_job j = {kind, inverse, variant, split_alpha, split_colour, in, out, n_total, first, count};
+    mt_worker(&j);
+}
+
 void oracle_run_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t len, int variant,
                    int split_alpha, int split_colour, int threads)
 {

@@ -111,6 +111,14 @@ int oracle_simd_set_cap(int cap);
 void oracle_bc1_default_simd_range(int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first,
                                    size_t count);
 void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads);
+/* AVX2 ports (scalar tail; scalar everywhere when the CPU lacks AVX2) of two more of the reference's vectorised paths:
+ * kind 2 = BC2 default settings {Variant1, split colours}, kind 3 = BC3 "standard" {None, no splits}.  Equal to the
+ * scalar oracle byte for byte (tests/test_oracle.py); cpu_baseline leg only.  (dxtlt_oracle_avx2.c) */
+void oracle_bc23_simd_range(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count);
+void oracle_bc23_simd_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads);
+/* one block range through the scalar loops */
+void oracle_transform_range(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count,
+                            int variant, int split_alpha, int split_colour);
 
 /* BC7 granule-sorted field split, version 1 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
  * no BC7 transform, so these are a definition, not a restatement: PARITY UNPINNED.  (dxtlt_oracle_bc7.c) */

@@ -226,6 +226,126 @@ TGT512 static void bc1_default_inv_avx512(const uint8_t *in, uint8_t *out, size_
     }
 }
 
+/* ---- BC2, default settings (YCoCg Variant1 + split colour endpoints), AVX2: 8 blocks (128 B) per iteration.
+ * Strategy followed (not code): /root/reference/src/core/dxt-lossless-transform-bc2/src/transform/
+ * with_split_colour_and_recorr/transform/avx2.rs -- 64-bit unpacks separate the alpha qwords from the (colour, index)
+ * qwords, a dword shuffle separates colours from indices, YCoCg-R on 16-bit lanes, a word shuffle splits c0 / c1. ---- */
+TGT static void bc2_default_fwd_avx2(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    uint8_t *alpha = out + 8 * first, *c0 = out + 8 * n_total + 2 * first, *c1 = out + 10 * n_total + 2 * first,
+            *idx = out + 12 * n_total + 4 * first;
+    const uint8_t *p = in + 16 * first;
+    const __m256i words = _mm256_setr_epi8(0, 1, 4, 5, 8, 9, 12, 13, 2, 3, 6, 7, 10, 11, 14, 15, 0, 1, 4, 5, 8, 9, 12, 13, 2, 3,
+                                           6, 7, 10, 11, 14, 15);
+    for (size_t i = 0; i < count; i += 8, p += 128, alpha += 64, c0 += 16, c1 += 16, idx += 32) {
+        const __m256i v0 = _mm256_loadu_si256((const __m256i *)(p + 0));   /* blocks 0, 1: [alpha, colour|index] x 2 */
+        const __m256i v1 = _mm256_loadu_si256((const __m256i *)(p + 32));
+        const __m256i v2 = _mm256_loadu_si256((const __m256i *)(p + 64));
+        const __m256i v3 = _mm256_loadu_si256((const __m256i *)(p + 96));
+        /* qword unpack per 128-bit lane: (b0, b2 | b1, b3) -> permute to block order */
+        _mm256_storeu_si256((__m256i *)alpha, _mm256_permute4x64_epi64(_mm256_unpacklo_epi64(v0, v1), 0xD8));
+        _mm256_storeu_si256((__m256i *)(alpha + 32), _mm256_permute4x64_epi64(_mm256_unpacklo_epi64(v2, v3), 0xD8));
+        const __m256 ci01 = _mm256_castsi256_ps(_mm256_permute4x64_epi64(_mm256_unpackhi_epi64(v0, v1), 0xD8));   /* c i c i | c i c i */
+        const __m256 ci23 = _mm256_castsi256_ps(_mm256_permute4x64_epi64(_mm256_unpackhi_epi64(v2, v3), 0xD8));
+        __m256i col = _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(ci01, ci23, 0x88)), 0xD8);   /* colours of blocks 0-7 */
+        const __m256i ind = _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(ci01, ci23, 0xDD)), 0xD8);
+        col = decorrelate_var1_epi16(col);
+        const __m256i s = _mm256_permute4x64_epi64(_mm256_shuffle_epi8(col, words), 0xD8);   /* c0 x 8 | c1 x 8 */
+        _mm_storeu_si128((__m128i *)c0, _mm256_castsi256_si128(s));
+        _mm_storeu_si128((__m128i *)c1, _mm256_extracti128_si256(s, 1));
+        _mm256_storeu_si256((__m256i *)idx, ind);
+    }
+}
+
+TGT static void bc2_default_inv_avx2(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    const uint8_t *alpha = in + 8 * first, *c0 = in + 8 * n_total + 2 * first, *c1 = in + 10 * n_total + 2 * first,
+                  *idx = in + 12 * n_total + 4 * first;
+    uint8_t *p = out + 16 * first;
+    for (size_t i = 0; i < count; i += 8, p += 128, alpha += 64, c0 += 16, c1 += 16, idx += 32) {
+        const __m128i w0 = _mm_loadu_si128((const __m128i *)c0), w1 = _mm_loadu_si128((const __m128i *)c1);
+        /* word interleave: blocks 0-3 | 4-7 */
+        __m256i col = _mm256_set_m128i(_mm_unpackhi_epi16(w0, w1), _mm_unpacklo_epi16(w0, w1));
+        col = recorrelate_var1_epi16(col);
+        const __m256i ind = _mm256_loadu_si256((const __m256i *)idx);
+        /* (colour, index) qwords: unpack per lane gives blocks 0,1,4,5 / 2,3,6,7 */
+        const __m256i lo = _mm256_unpacklo_epi32(col, ind), hi = _mm256_unpackhi_epi32(col, ind);
+        const __m256i ci03 = _mm256_permute2x128_si256(lo, hi, 0x20);   /* blocks 0-3 */
+        const __m256i ci47 = _mm256_permute2x128_si256(lo, hi, 0x31);   /* blocks 4-7 */
+        const __m256i a03 = _mm256_loadu_si256((const __m256i *)alpha), a47 = _mm256_loadu_si256((const __m256i *)(alpha + 32));
+        /* interleave alpha qwords with ci qwords: unpack per lane gives blocks 0,2 / 1,3 -> permute sources first */
+        const __m256i a03p = _mm256_permute4x64_epi64(a03, 0xD8), ci03p = _mm256_permute4x64_epi64(ci03, 0xD8);
+        const __m256i a47p = _mm256_permute4x64_epi64(a47, 0xD8), ci47p = _mm256_permute4x64_epi64(ci47, 0xD8);
+        _mm256_storeu_si256((__m256i *)(p + 0), _mm256_unpacklo_epi64(a03p, ci03p));    /* blocks 0, 1 */
+        _mm256_storeu_si256((__m256i *)(p + 32), _mm256_unpackhi_epi64(a03p, ci03p));   /* blocks 2, 3 */
+        _mm256_storeu_si256((__m256i *)(p + 64), _mm256_unpacklo_epi64(a47p, ci47p));
+        _mm256_storeu_si256((__m256i *)(p + 96), _mm256_unpackhi_epi64(a47p, ci47p));
+    }
+}
+
+/* ---- BC3, "standard" layout (no decorrelation, no splits), AVX2: 8 blocks per iteration.  Strategy followed (not code):
+ * /root/reference/src/core/dxt-lossless-transform-bc3/src/transform/standard/transform/avx2.rs:47-140 -- colours and
+ * indices leave as whole vectors, the 2 + 6 alpha bytes of every block through byte shuffles. ---- */
+TGT static void bc3_standard_fwd_avx2(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    uint8_t *aep = out + 2 * first, *aidx = out + 2 * n_total + 6 * first, *col = out + 8 * n_total + 4 * first,
+            *idx = out + 12 * n_total + 4 * first;
+    const uint8_t *p = in + 16 * first;
+    /* per 128-bit lane holding two alpha qwords: bytes 0-11 = the two 6-byte index records, 12-15 = the two endpoint pairs */
+    const __m256i pick = _mm256_setr_epi8(2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14, 15, 0, 1, 8, 9, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13,
+                                          14, 15, 0, 1, 8, 9);
+    for (size_t i = 0; i < count; i += 8, p += 128, aep += 16, aidx += 48, col += 32, idx += 32) {
+        const __m256i v0 = _mm256_loadu_si256((const __m256i *)(p + 0));
+        const __m256i v1 = _mm256_loadu_si256((const __m256i *)(p + 32));
+        const __m256i v2 = _mm256_loadu_si256((const __m256i *)(p + 64));
+        const __m256i v3 = _mm256_loadu_si256((const __m256i *)(p + 96));
+        const __m256i a03 = _mm256_shuffle_epi8(_mm256_permute4x64_epi64(_mm256_unpacklo_epi64(v0, v1), 0xD8), pick);
+        const __m256i a47 = _mm256_shuffle_epi8(_mm256_permute4x64_epi64(_mm256_unpacklo_epi64(v2, v3), 0xD8), pick);
+        const __m256 ci01 = _mm256_castsi256_ps(_mm256_permute4x64_epi64(_mm256_unpackhi_epi64(v0, v1), 0xD8));
+        const __m256 ci23 = _mm256_castsi256_ps(_mm256_permute4x64_epi64(_mm256_unpackhi_epi64(v2, v3), 0xD8));
+        _mm256_storeu_si256((__m256i *)col, _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(ci01, ci23, 0x88)), 0xD8));
+        _mm256_storeu_si256((__m256i *)idx, _mm256_permute4x64_epi64(_mm256_castps_si256(_mm256_shuffle_ps(ci01, ci23, 0xDD)), 0xD8));
+        /* 12 index bytes per lane: a 16-byte store whose last 4 bytes the next store overwrites, then exact 12-byte stores */
+        const __m128i l0 = _mm256_castsi256_si128(a03), l1 = _mm256_extracti128_si256(a03, 1);
+        const __m128i l2 = _mm256_castsi256_si128(a47), l3 = _mm256_extracti128_si256(a47, 1);
+        _mm_storeu_si128((__m128i *)(aidx + 0), l0);
+        _mm_storeu_si128((__m128i *)(aidx + 12), l1);
+        _mm_storeu_si128((__m128i *)(aidx + 24), l2);
+        memcpy(aidx + 36, &l3, 12);
+        const uint32_t e[4] = {(uint32_t)_mm_extract_epi32(l0, 3), (uint32_t)_mm_extract_epi32(l1, 3),
+                               (uint32_t)_mm_extract_epi32(l2, 3), (uint32_t)_mm_extract_epi32(l3, 3)};
+        memcpy(aep, e, 16);
+    }
+}
+
+TGT static void bc3_standard_inv_avx2(const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    const uint8_t *aep = in + 2 * first, *aidx = in + 2 * n_total + 6 * first, *col = in + 8 * n_total + 4 * first,
+                  *idx = in + 12 * n_total + 4 * first;
+    uint8_t *p = out + 16 * first;
+    /* inverse of `pick`: lane bytes = [12 index bytes | 4 endpoint bytes] -> two alpha qwords */
+    const __m128i unpick = _mm_setr_epi8(12, 13, 0, 1, 2, 3, 4, 5, 14, 15, 6, 7, 8, 9, 10, 11);
+    for (size_t i = 0; i < count; i += 8, p += 128, aep += 16, aidx += 48, col += 32, idx += 32) {
+        uint32_t e[4];
+        memcpy(e, aep, 16);
+        __m128i a[4];
+        for (int k = 0; k < 4; ++k) {
+            __m128i t;
+            memcpy(&t, aidx + 12 * k, 12);   /* exact: the last record must not read past the section */
+            a[k] = _mm_shuffle_epi8(_mm_insert_epi32(t, (int)e[k], 3), unpick);   /* alpha qwords of blocks 2k, 2k + 1 */
+        }
+        const __m256i cv = _mm256_loadu_si256((const __m256i *)col), iv = _mm256_loadu_si256((const __m256i *)idx);
+        const __m256i lo = _mm256_unpacklo_epi32(cv, iv), hi = _mm256_unpackhi_epi32(cv, iv);   /* blocks 0,1,4,5 / 2,3,6,7 */
+        const __m128i ci01 = _mm256_castsi256_si128(lo), ci23 = _mm256_castsi256_si128(hi);
+        const __m128i ci45 = _mm256_extracti128_si256(lo, 1), ci67 = _mm256_extracti128_si256(hi, 1);
+        const __m128i ci[4] = {ci01, ci23, ci45, ci67};
+        for (int k = 0; k < 4; ++k) {
+            _mm_storeu_si128((__m128i *)(p + 32 * k), _mm_unpacklo_epi64(a[k], ci[k]));
+            _mm_storeu_si128((__m128i *)(p + 32 * k + 16), _mm_unpackhi_epi64(a[k], ci[k]));
+        }
+    }
+}
+
 #endif /* HAVE_X86 */
 
 /* scalar range kernels live in dxtlt_oracle.c; re-stated minimally here for the tail */
@@ -318,6 +438,68 @@ void oracle_bc1_default_simd_mt(int inverse, const uint8_t *in, uint8_t *out, si
             pthread_create(&tids[t], NULL, simd_worker, &jobs[t]);
     }
     simd_worker(&jobs[0]);
+    for (int t = 1; t < threads; ++t)
+        pthread_join(tids[t], NULL);
+    free(jobs);
+    free(tids);
+}
+
+/* ---- BC2 default / BC3 standard: AVX2 body + scalar tail (the scalar oracle's own functions on the tail's blocks) ---- */
+void oracle_bc23_simd_range(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count)
+{
+    /* kind 2 = BC2 {Variant1, split colours}; kind 3 = BC3 standard {None, no splits} */
+    size_t body = 0;
+#if HAVE_X86
+    if (oracle_simd_level() >= 2) {
+        body = count & ~(size_t)7;
+        if (kind == 2) {
+            if (inverse) bc2_default_inv_avx2(in, out, n_total, first, body);
+            else bc2_default_fwd_avx2(in, out, n_total, first, body);
+        } else {
+            if (inverse) bc3_standard_inv_avx2(in, out, n_total, first, body);
+            else bc3_standard_fwd_avx2(in, out, n_total, first, body);
+        }
+    }
+#endif
+    if (count > body)
+        oracle_transform_range(kind, inverse, in, out, n_total, first + body, count - body, kind == 2 ? ORACLE_YCOCG_VAR1 : ORACLE_YCOCG_NONE,
+                               0, kind == 2 ? 1 : 0);
+}
+
+struct simd23_job {
+    int kind, inverse;
+    const uint8_t *in;
+    uint8_t *out;
+    size_t n_total, first, count;
+};
+
+static void *simd23_worker(void *arg)
+{
+    struct simd23_job *j = (struct simd23_job *)arg;
+    oracle_bc23_simd_range(j->kind, j->inverse, j->in, j->out, j->n_total, j->first, j->count);
+    return NULL;
+}
+
+void oracle_bc23_simd_mt(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t len, int threads)
+{
+    const size_t n = len / 16;
+    if (threads < 1)
+        threads = 1;
+    if ((size_t)threads > n / 8 + 1)
+        threads = (int)(n / 8 + 1);
+    struct simd23_job *jobs = (struct simd23_job *)calloc((size_t)threads, sizeof *jobs);
+    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof *tids);
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    per = (per + 7) & ~(size_t)7;
+    for (int t = 0; t < threads; ++t) {
+        size_t first = per * (size_t)t;
+        size_t count = first >= n ? 0 : (first + per > n ? n - first : per);
+        struct simd23_job j = {kind, inverse, in, out, n, first, count};
+        jobs[t] = j;
+        if (t > 0)
+            pthread_create(&tids[t], NULL, simd23_worker, &jobs[t]);
+    }
+    simd23_worker(&jobs[0]);
     for (int t = 1; t < threads; ++t)
         pthread_join(tids[t], NULL);
     free(jobs);

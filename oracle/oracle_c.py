@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         l.oracle_simd_set_cap.argtypes, l.oracle_simd_set_cap.restype = [i], i
         l.oracle_bc1_default_simd_mt.argtypes = [i, u8p, u8p, sz, i]
         l.oracle_bc1_default_simd_mt.restype = None
+        l.oracle_bc23_simd_mt.argtypes = [i, i, u8p, u8p, sz, i]
+        l.oracle_bc23_simd_mt.restype = None
         l.oracle_decode_bc1_block.argtypes, l.oracle_decode_bc1_block.restype = [u8p, u8p], None
         l.oracle_normalize_bc1_blocks.argtypes, l.oracle_normalize_bc1_blocks.restype = [u8p, u8p, sz, i], None
         l.oracle_normalize_bc1_split_blocks_in_place.argtypes = [u8p, u8p, sz, i]
@@ -212,6 +214,13 @@ SIMD_NAMES = {0: "scalar", 2: "AVX2", 5: "AVX-512BW"}
 def run_bc1_default_simd(src: np.ndarray, dst: np.ndarray, inverse: bool, threads: int) -> None:
     """AVX-512BW / AVX2 port (scalar when the CPU has neither) of BC1 {Variant1, split}; cpu_baseline leg and its test only."""
     lib().oracle_bc1_default_simd_mt(int(inverse), _ptr(src), _ptr(dst), src.size, int(threads))
+
+
+def run_bc23_simd(kind: int, src: np.ndarray, dst: np.ndarray, inverse: bool, threads: int) -> None:
+    """AVX2 port (scalar when the CPU has no AVX2) of BC2 {Variant1, split colours} (kind 2) or BC3 standard {None, no
+    splits} (kind 3); cpu_baseline leg and its test only."""
+    assert kind in (2, 3) and src.size % 16 == 0 and dst.size == src.size
+    lib().oracle_bc23_simd_mt(kind, int(inverse), _ptr(src), _ptr(dst), src.size, int(threads))
 
 
 def transform_bc7(data, inverse: bool = False) -> np.ndarray:

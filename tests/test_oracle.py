@@ -210,6 +210,28 @@ def test_simd_ports_equal_scalar_oracle(oracle):
         oracle.simd_set_cap(5)
 
 
+def test_bc2_default_and_bc3_standard_simd_ports_match_the_scalar_oracle(oracle):
+    """The AVX2 ports of BC2 {Variant1, split colours} and BC3 "standard" {None, no splits} (the two paths bench.py's
+    cpu_baseline leg also quotes vectorised) equal the scalar oracle byte for byte at every ISA level, around the 8-block
+    vector width, over several threads."""
+    try:
+        for n in (0, 1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 999, 100_003):
+            x = oracle.fill_splitmix64(n * 16, 0xB23 + n)
+            for kind, fmt, (v, sc, sa) in ((2, "bc2", (1, True, False)), (3, "bc3", (0, False, False))):
+                want = oracle.transform(fmt, x, v, sc, sa)
+                for cap in (5, 2, 0):
+                    oracle.simd_set_cap(cap)
+                    for threads in (1, 3):
+                        y = np.full_like(x, 0xEE)
+                        oracle.run_bc23_simd(kind, x, y, False, threads)
+                        assert np.array_equal(y, want), (fmt, n, cap, threads)
+                        z = np.full_like(x, 0xEE)
+                        oracle.run_bc23_simd(kind, y, z, True, threads)
+                        assert np.array_equal(z, x), (fmt, n, cap, threads, "inverse")
+    finally:
+        oracle.simd_set_cap(5)
+
+
 def test_mt_range_split_matches_single_thread(oracle):
     for fmt in FORMATS:
         x = oracle.fill_splitmix64(1001 * BLOCK[fmt], 99)
