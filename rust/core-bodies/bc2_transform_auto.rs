@@ -1,0 +1,41 @@
+//! UNCOMPILED (see ../README.md).  New body for
+//! core/dxt-lossless-transform-bc2/src/transform/transform_auto.rs (:196-).
+//! Candidate order, the estimated section, the strict `<` tie-break and the final transform with the winner are
+//! implemented on the library side exactly as in the reference (csrc/auto_transform.cpp), so the same estimator
+//! yields the same settings and the same bytes.
+use crate::gfx950_glue::{abort_on_device_failure, vtable, EstimatorBridge};
+use crate::transform::{Bc2EstimateSettings, DetermineBestTransformError};
+use crate::Bc2TransformSettings;
+use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
+use dxt_lossless_transform_common::allocate::AllocateError;
+use dxt_lossless_transform_common::color_565::YCoCgVariant;
+use dxtlt_gfx950_sys::{dxtlt_transform_bc2_auto, DXTLT_E_ALLOCATION, DXTLT_E_ESTIMATOR};
+
+pub unsafe fn transform_bc2_auto<T>(
+    input_ptr: *const u8,
+    output_ptr: *mut u8,
+    len: usize,
+    transform_options: &Bc2EstimateSettings<T>,
+) -> Result<Bc2TransformSettings, DetermineBestTransformError<T::Error>>
+where
+    T: SizeEstimationOperations,
+{
+    let mut bridge = EstimatorBridge { estimator: &transform_options.size_estimator, error: None };
+    let table = vtable(&mut bridge);
+    let (mut mode, mut split_colour, mut estimator_error) = (0u8, false, 0u32);
+    let rc = dxtlt_transform_bc2_auto(
+        input_ptr, output_ptr, len, &table, transform_options.use_all_decorrelation_modes,
+        &mut mode, &mut split_colour, &mut estimator_error,
+    );
+    match rc {
+        0 => Ok(Bc2TransformSettings {
+            decorrelation_mode: match mode { 1 => YCoCgVariant::Variant1, 2 => YCoCgVariant::Variant2,
+                                             3 => YCoCgVariant::Variant3, _ => YCoCgVariant::None },
+            split_colour_endpoints: split_colour,
+        }),
+        DXTLT_E_ESTIMATOR => Err(DetermineBestTransformError::SizeEstimationError(
+            bridge.error.take().expect("the estimator callback failed, so it parked its error"))),
+        DXTLT_E_ALLOCATION => Err(DetermineBestTransformError::AllocateError(AllocateError::default())),
+        other => abort_on_device_failure("transform_bc2_auto", other),
+    }
+}

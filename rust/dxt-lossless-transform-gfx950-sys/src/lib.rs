@@ -1,0 +1,102 @@
+//! UNCOMPILED (see ../../README.md).  Raw bindings to `libdxtlt_gfx950.so` -- `include/dxtlt_gfx950.h`,
+//! `include/dlt_size_estimator.h`.  Status codes are the `DXTLT_*` values of the header.
+#![no_std]
+#![allow(non_camel_case_types)]
+
+use core::ffi::{c_char, c_void};
+
+pub const DXTLT_OK: i32 = 0;
+pub const DXTLT_E_INVALID_LENGTH: i32 = 1;
+pub const DXTLT_E_INVALID_ARGUMENT: i32 = 2;
+pub const DXTLT_E_NO_DEVICE: i32 = 3;
+pub const DXTLT_E_DEVICE: i32 = 4;
+pub const DXTLT_E_ESTIMATOR: i32 = 5;
+pub const DXTLT_E_ALLOCATION: i32 = 6;
+
+/// `DltSizeEstimator`, the C vtable of `SizeEstimationOperations`
+/// (api-common `c_api/size_estimation.rs:18-52`; `include/dlt_size_estimator.h`).  Callbacks return 0 for success.
+#[repr(C)]
+pub struct DltSizeEstimator {
+    pub context: *mut c_void,
+    pub max_compressed_size: unsafe extern "C" fn(context: *mut c_void, len_bytes: usize, out_size: *mut usize) -> u32,
+    pub estimate_compressed_size: unsafe extern "C" fn(
+        context: *mut c_void,
+        input_ptr: *const u8,
+        len_bytes: usize,
+        output_ptr: *mut u8,
+        output_len: usize,
+        out_size: *mut usize,
+    ) -> u32,
+}
+
+/// One buffer of `dxtlt_transform_batch_host` / `dxtlt_transform_batch_device`.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct DxtltBatchItem {
+    pub d_input: *const c_void,
+    pub d_output: *mut c_void,
+    pub len: u64,
+    pub format: u8,  // 1, 2, 3 = BC1, BC2, BC3
+    pub inverse: u8, // 0 = transform, 1 = untransform
+    pub decorrelation_mode: u8,
+    pub split_alpha_endpoints: u8,
+    pub split_colour_endpoints: u8,
+    pub reserved: [u8; 3],
+}
+
+extern "C" {
+    // ---- host pointers: the bodies of the core crates' unsafe fns ------------------------------------------------
+    pub fn dxtlt_transform_bc1_with_settings(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool) -> i32;
+    pub fn dxtlt_untransform_bc1_with_settings(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool) -> i32;
+    pub fn dxtlt_transform_bc2_with_settings(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool) -> i32;
+    pub fn dxtlt_untransform_bc2_with_settings(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool) -> i32;
+    pub fn dxtlt_transform_bc3_with_settings(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_alpha_endpoints: bool, split_colour_endpoints: bool) -> i32;
+    pub fn dxtlt_untransform_bc3_with_settings(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_alpha_endpoints: bool, split_colour_endpoints: bool) -> i32;
+
+    // ---- transform_bcN_auto ------------------------------------------------------------------------------------
+    pub fn dxtlt_transform_bc1_auto(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        estimator: *const DltSizeEstimator, use_all_decorrelation_modes: bool,
+        out_decorrelation_mode: *mut u8, out_split_colour_endpoints: *mut bool, out_estimator_error: *mut u32) -> i32;
+    pub fn dxtlt_transform_bc2_auto(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        estimator: *const DltSizeEstimator, use_all_decorrelation_modes: bool,
+        out_decorrelation_mode: *mut u8, out_split_colour_endpoints: *mut bool, out_estimator_error: *mut u32) -> i32;
+    pub fn dxtlt_transform_bc3_auto(input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        estimator: *const DltSizeEstimator, use_all_decorrelation_modes: bool,
+        out_decorrelation_mode: *mut u8, out_split_alpha_endpoints: *mut bool, out_split_colour_endpoints: *mut bool,
+        out_estimator_error: *mut u32) -> i32;
+
+    // ---- data that already lives in HBM: device pointers, asynchronous on a HIP stream -----------------------------
+    pub fn dxtlt_transform_bc1_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_untransform_bc1_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_transform_bc2_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_untransform_bc2_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
+        decorrelation_mode: u8, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_transform_bc3_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
+        decorrelation_mode: u8, split_alpha_endpoints: bool, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_untransform_bc3_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
+        decorrelation_mode: u8, split_alpha_endpoints: bool, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_transform_range_device(format: i32, inverse: bool, d_src: *const c_void, d_dst: *mut c_void,
+        total_blocks: u64, first_block: u64, num_blocks: u64, decorrelation_mode: u8, split_alpha_endpoints: bool,
+        split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;
+
+    // ---- many buffers per call (the CLI's file-after-file pattern) --------------------------------------------------
+    pub fn dxtlt_transform_batch_device(items: *const DxtltBatchItem, count: usize, hip_stream: *mut c_void) -> i32;
+    pub fn dxtlt_transform_batch_host(items: *const DxtltBatchItem, count: usize) -> i32;
+
+    // ---- one array over every GPU of the node ------------------------------------------------------------------------
+    pub fn dxtlt_transform_sharded(format: i32, inverse: bool, input_ptr: *const u8, output_ptr: *mut u8, len: usize,
+        decorrelation_mode: u8, split_alpha_endpoints: bool, split_colour_endpoints: bool, num_devices: i32) -> i32;
+
+    pub fn dxtlt_last_error() -> *const c_char;
+    pub fn dxtlt_device_count() -> i32;
+    pub fn dxtlt_release_thread_resources();
+}

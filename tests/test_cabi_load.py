@@ -132,3 +132,26 @@ def test_new_entry_points_validate_without_a_device(pkg):
     l.dxtlt_transform_bc7_sharded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32]
     assert l.dxtlt_transform_bc7_sharded(p, p, 24, 2) == 1
     assert l.dxtlt_transform_bc7_sharded(p, p, 0, 2) == 0
+
+
+def test_rust_sys_crate_declares_only_exported_symbols(pkg):
+    """rust/dxt-lossless-transform-gfx950-sys/src/lib.rs (source only: no Rust toolchain here) must not drift from the
+    library: every `pub fn` of its extern block is an exported symbol, and every argument list has the C prototype's
+    number of parameters."""
+    import ctypes
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rust", "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read()
+    header = open(os.path.join(root, "include", "dxtlt_gfx950.h")).read()
+    lib = ctypes.CDLL(pkg._lib.lib_path())
+    decls = re.findall(r"pub fn (dxtlt_\w+)\(([^)]*)\)", src)
+    assert len(decls) >= 20
+    for name, args in decls:
+        assert hasattr(lib, name), name
+        m = re.search(r"\b" + name + r"\(([^)]*)\)", header)
+        assert m, name
+        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        rust_args = [a for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(rust_args), (name, len(c_args), len(rust_args))

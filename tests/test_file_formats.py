@@ -189,6 +189,48 @@ def test_dds_roundtrip_all_settings(lib, oracle, fmt):
         assert np.array_equal(r, d)
 
 
+def reference_integration_test_dds() -> np.ndarray:
+    """The synthetic BC1 DDS the reference's own integration test builds (api/dxt-lossless-transform-file-formats-api/
+    tests/integration_test.rs:10-57): a 128-byte legacy header (flags CAPS | HEIGHT | WIDTH | PIXELFORMAT | LINEARSIZE,
+    4 x 4 pixels, FourCC DXT1 -- it leaves the pixel-format size field zero) and ONE block: red, green, zero indices."""
+    d = bytearray(0x80 + 8)
+    d[0:4] = b"DDS "
+    struct.pack_into("<I", d, 4, 124)
+    struct.pack_into("<I", d, 8, 0x1 | 0x2 | 0x4 | 0x1000 | 0x80000)
+    struct.pack_into("<II", d, 0x0C, 4, 4)
+    struct.pack_into("<I", d, 0x50, 0x4)
+    d[0x54:0x58] = b"DXT1"
+    d[0x80:0x88] = bytes([0x00, 0xF8, 0xE0, 0x07, 0, 0, 0, 0])
+    return np.frombuffer(bytes(d), dtype=np.uint8).copy()
+
+
+def test_reference_integration_fixture_is_recognised(lib):
+    """integration_test.rs:94-105 (test_handler_detection): the handler takes the synthetic DDS, refuses 128 zero bytes."""
+    d = reference_integration_test_dds()
+    assert lib.is_dds(d.ctypes.data, d.size)
+    info = lib.parse_dds(d.ctypes.data, d.size)
+    assert (info.Format, info.DataOffset, info.DataLength) == (BC1, 128, 8)
+    zeros = np.zeros(128, dtype=np.uint8)
+    assert not lib.is_dds(zeros.ctypes.data, zeros.size)
+    out = np.zeros(128, dtype=np.uint8)
+    assert lib.dxtlt_dds_transform(zeros.ctypes.data, zeros.size, out.ctypes.data, out.size, 1, False, True) != 0
+
+
+@pytest.mark.gpu
+def test_reference_integration_fixture_round_trip(lib, oracle):
+    """integration_test.rs:59-92 (test_dds_bc1_transform_roundtrip): transform with the default BC1 settings
+    (TransformBundle::default_all), the magic must change; untransform restores it -- and here the whole file."""
+    d = reference_integration_test_dds()
+    t = np.zeros_like(d)
+    assert lib.dxtlt_dds_transform(d.ctypes.data, d.size, t.ctypes.data, t.size, 1, False, True) == 0
+    assert t[:4].tobytes() != d[:4].tobytes()
+    assert np.array_equal(t[4:128], d[4:128])
+    assert np.array_equal(t[128:], oracle.transform("bc1", d[128:], 1, True))
+    r = np.zeros_like(d)
+    assert lib.dxtlt_dds_untransform(t.ctypes.data, t.size, r.ctypes.data, r.size) == 0
+    assert r[:4].tobytes() == b"DDS " and np.array_equal(r, d)
+
+
 @pytest.mark.gpu
 def test_dds_auto_transform(lib, oracle):
     from oracle import oracle_auto
