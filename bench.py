@@ -156,6 +156,9 @@ def parse_args():
     p.add_argument("--host-array-gib", type=float, default=None,
                    help="size of the host-resident array of the sharded_host_array leg (default: --size-gib for "
                         "bc1/bc2/bc3 buffers; 0 = skip)")
+    p.add_argument("--archive-split", default="texture", choices=["texture", "range"],
+                   help="--workload archive: 'texture' = every rank owns a contiguous byte range of the archive (whole "
+                        "textures); 'range' = every texture's block range is cut over the ranks (range calls)")
     p.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
@@ -371,12 +374,17 @@ def bc7_main(args) -> None:
 
 
 def archive_main(args) -> None:
-    """BASELINE.json configs[4]: an archive of alternating 256 MiB BC1 and BC3 textures, each transformed with its
-    format's default settings; the archive is split over the ranks by texture (contiguous ranges of whole textures: rank
-    r holds textures [r*K, (r+1)*K)), no collective, the host places each rank's result at its offset.  A step transforms
-    and restores every texture of the rank.  Verified per texture (exact round trip, an oracle window) and, since random
-    blocks compress to ratio 1, the compression-ratio half of the config is checked on the reference's real 256x256 test
-    textures: GPU output == CPU output byte for byte, so the ratios are equal, and both are reported."""
+    """BASELINE.json configs[4]: an archive of alternating 256 MiB BC1 and BC3 textures (--size-gib per GPU: 64 GiB over
+    8 GPUs), each transformed with its format's default settings, no collective.  Two ways to cut it over the ranks:
+      --archive-split texture  rank r owns the contiguous byte range [r, r + 1) * size of the archive, which is K whole
+                               textures (the boundaries fall on texture boundaries); each is transformed whole
+      --archive-split range    every texture's block range is cut into `world` contiguous ranges and rank r transforms
+                               range r of EVERY texture with dxtlt_transform_range_device (AoS slice <-> its slices of
+                               the texture's whole transformed buffer)
+    A step transforms and restores every texture (slice) of the rank.  Verified per texture (exact round trip, an oracle
+    window) and, since random blocks compress to ratio 1, the compression-ratio half of the config is checked on the
+    reference's real 256x256 test textures with zlib level 6 (the image has no zstd binding; zlib stands in for the
+    config's zstd): GPU output == CPU output byte for byte, so the ratios are equal, and both are reported."""
     import zlib
 
     import numpy as np
@@ -390,24 +398,46 @@ def archive_main(args) -> None:
     pkg.load()
     tex_bytes = 256 << 20
     per_gpu = int((args.size_gib if args.size_gib else 8.0) * (1 << 30))
-    k = max(2, per_gpu // tex_bytes // 2 * 2)           # textures per rank, BC1 and BC3 alternating
-    fmts = ["bc1" if i % 2 == 0 else "bc3" for i in range(k)]
+    by_range = args.archive_split == "range"
     st = {"bc1": pkg.Bc1TransformSettings(), "bc3": pkg.Bc3TransformSettings()}
     fwd = {f: getattr(pkg, f"transform_{f}_with_settings") for f in st}
     inv = {f: getattr(pkg, f"untransform_{f}_with_settings") for f in st}
-    xs = [torch.empty(tex_bytes, dtype=torch.uint8, device=dev) for _ in range(k)]
-    ys = [torch.empty_like(x) for x in xs]
-    zs = [torch.empty_like(x) for x in xs]
-    for i, x in enumerate(xs):
-        pkg.fill_splitmix64(x, 0x0A5C0005, (rank * k + i) * (tex_bytes // 8))   # one logical 64 GiB stream of blocks
+    if by_range:
+        # every texture of the archive; this rank's block range of each (AoS slice, whole SoA buffer per texture)
+        k = max(2, per_gpu * world // tex_bytes // 2 * 2)
+        fmts = ["bc1" if i % 2 == 0 else "bc3" for i in range(k)]
+        plans = [pkg.plan_shards(tex_bytes // pkg.BLOCK_BYTES[f], world)[rank] for f in fmts]
+        xs = [torch.empty(n * pkg.BLOCK_BYTES[f], dtype=torch.uint8, device=dev) for f, (_, n) in zip(fmts, plans)]
+        ys = [torch.empty(tex_bytes, dtype=torch.uint8, device=dev) for _ in range(k)]
+        zs = [torch.empty_like(x) for x in xs]
+        for i, x in enumerate(xs):
+            first = plans[i][0]
+            pkg.fill_splitmix64(x, 0x0A5C0005, i * (tex_bytes // 8) + first * pkg.BLOCK_BYTES[fmts[i]] // 8)
+
+        def step():
+            for i in range(k):
+                total = tex_bytes // pkg.BLOCK_BYTES[fmts[i]]
+                pkg.transform_range(fmts[i], False, xs[i], ys[i], total, plans[i][0], plans[i][1], st[fmts[i]])
+            for i in range(k):
+                total = tex_bytes // pkg.BLOCK_BYTES[fmts[i]]
+                pkg.transform_range(fmts[i], True, ys[i], zs[i], total, plans[i][0], plans[i][1], st[fmts[i]])
+    else:
+        k = max(2, per_gpu // tex_bytes // 2 * 2)           # textures per rank, BC1 and BC3 alternating
+        fmts = ["bc1" if i % 2 == 0 else "bc3" for i in range(k)]
+        plans = [(0, tex_bytes // pkg.BLOCK_BYTES[f]) for f in fmts]
+        xs = [torch.empty(tex_bytes, dtype=torch.uint8, device=dev) for _ in range(k)]
+        ys = [torch.empty_like(x) for x in xs]
+        zs = [torch.empty_like(x) for x in xs]
+        for i, x in enumerate(xs):
+            pkg.fill_splitmix64(x, 0x0A5C0005, (rank * k + i) * (tex_bytes // 8))   # one logical 64 GiB stream of blocks
+
+        def step():
+            for i in range(k):
+                fwd[fmts[i]](xs[i], ys[i], st[fmts[i]])
+            for i in range(k):
+                inv[fmts[i]](ys[i], zs[i], st[fmts[i]])
 
     barrier = R.barrier
-
-    def step():
-        for i in range(k):
-            fwd[fmts[i]](xs[i], ys[i], st[fmts[i]])
-        for i in range(k):
-            inv[fmts[i]](ys[i], zs[i], st[fmts[i]])
 
     for _ in range(args.warmup):
         step()
@@ -428,8 +458,9 @@ def archive_main(args) -> None:
         f = fmts[i]
         B = pkg.BLOCK_BYTES[f]
         blocks = tex_bytes // B
-        first = blocks // 3 + 17
-        xin = xs[i][first * B:(first + win) * B].cpu().numpy()
+        lf = min(plans[i][1] // 3 + 17, plans[i][1] - win)      # inside this rank's slice of the texture
+        first = plans[i][0] + lf
+        xin = xs[i][lf * B:(lf + win) * B].cpu().numpy()
         want = oracle_c.transform(f, xin, 1, True, True)
         got = np.empty_like(want)
         for off, w in pkg.stream_table(f, st[f]):
@@ -454,22 +485,25 @@ def archive_main(args) -> None:
     if rank != 0:
         R.finish()
         return
-    total = 2 * k * tex_bytes * args.steps * world
+    rank_bytes = sum(int(x.numel()) for x in xs)          # block bytes this rank feeds to one direction per step
+    total = 2 * rank_bytes * args.steps * world
+    archive_gib = rank_bytes * world / 2**30
     out = {
         "metric": "GiB/s BC blocks transformed (fwd+inv)", "value": round(total / elapsed / 2**30, 2), "unit": "GiB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {
-            "workload": f"BC1+BC3 mixed archive, {k} alternating 256 MiB textures per GPU ({k * world * tex_bytes / 2**30:g} GiB "
-                        "in all), default settings per format, split over the ranks by texture, no collective "
-                        "(BASELINE.json configs[4])",
-            "textures_per_gpu": k, "texture_bytes": tex_bytes, "seed": "0xa5c0005",
+            "workload": f"BC1+BC3 mixed archive, {archive_gib:g} GiB of alternating 256 MiB textures, default settings per format, "
+                        + ("every texture's block range cut over the ranks (dxtlt_transform_range_device), " if by_range else
+                           "contiguous byte range of the archive per rank = whole textures, ")
+                        + "no collective (BASELINE.json configs[4]; compression ratios with zlib-6 in place of zstd)",
+            "archive_split": args.archive_split, "textures_touched_per_gpu": k, "texture_bytes": tex_bytes, "seed": "0xa5c0005",
             "bit_exact_roundtrip_and_oracle_windows": ok,
             "zlib6_ratio_on_real_textures": ratios,
         },
         "roofline": {"bound": "hbm", "kernel": "fwd_tiled + inv_tiled over the archive", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "achieved": round(2 * (2 * k * tex_bytes * args.steps) / elapsed / 1e9, 1),
-                     "frac": round(2 * (2 * k * tex_bytes * args.steps) / elapsed / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "achieved": round(2 * (2 * rank_bytes * args.steps) / elapsed / 1e9, 1),
+                     "frac": round(2 * (2 * rank_bytes * args.steps) / elapsed / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                      "note": "wall clock of the whole step per GPU (launch gaps included), algorithmic 2 * bytes per direction"},
     }
     print(json.dumps(out), flush=True)

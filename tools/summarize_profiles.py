@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 CSV output (gpurun_out/prof_*) into the small summaries committed under profiles/.
 
-    python tools/summarize_profiles.py <tag>      # e.g. r01_e
+    python tools/summarize_profiles.py <tag> [<dir under gpurun_out>]      # e.g. r02_z r02_final/bc1
 
-Inputs (produced on the GPU box, see profiles/README.md for the exact commands):
+Inputs (produced on the GPU box by tools/r02_measure.sh, see profiles/README.md for the exact commands), under
+gpurun_out/ or the given sub-directory:
   gpurun_out/prof_kt     --kernel-trace --stats            of `python3 bench.py --steps 20 --warmup 3`
   gpurun_out/prof_fetch  --pmc FETCH_SIZE --kernel-trace   of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`
   gpurun_out/prof_write  --pmc WRITE_SIZE --kernel-trace   (same command)
@@ -36,9 +37,9 @@ def one(pattern: str) -> str:
 
 
 def short(name: str):
-    if "fwd_tiled" in name:
-        return "fwd_tiled"
-    if "inv_tiled" in name:
+    if "fwd_tiled" in name or "bc7_forward" in name:
+        return "fwd_tiled"      # the forward kernel of the format benched (bc7: bc7_forward)
+    if "inv_tiled" in name or "bc7_inverse" in name:
         return "inv_tiled"
     return None
 
@@ -54,7 +55,10 @@ def counters(dirname: str):
 
 
 def main() -> None:
+    global SRC
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    if len(sys.argv) > 2:
+        SRC = os.path.join(SRC, sys.argv[2])
     stats_rows = []
     with open(one("prof_kt/*/*_kernel_stats.csv")) as f:
         for r in csv.DictReader(f):
@@ -98,9 +102,10 @@ def main() -> None:
     with open(os.path.join(OUT, f"{tag}_pmc.json"), "w") as f:
         json.dump(detail, f, indent=1)
         f.write("\n")
-    with open(os.path.join(OUT, "pmc_traffic.json"), "w") as f:
-        json.dump(rec, f, indent=1)
-        f.write("\n")
+    if rec["format"] == "bc1":   # what bench.py quotes (labelled) as roofline.traffic for the headline workload
+        with open(os.path.join(OUT, "pmc_traffic.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+            f.write("\n")
     print(json.dumps(rec))
     for r in stats_rows:
         print(r["Name"][:60], r["Calls"], r["AverageNs"])
