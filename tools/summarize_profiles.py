@@ -45,13 +45,40 @@ def short(name: str):
 
 
 def counters(dirname: str):
-    agg = collections.defaultdict(list)
+    """per-launch averages over the FULL-SIZE dispatches of each kernel (bench.py's checks also launch the kernels on
+    small samples: those rows have a smaller grid and are left out)"""
+    rows = []
     with open(one(f"{dirname}/*/*_counter_collection.csv")) as f:
         for r in csv.DictReader(f):
             k = short(r["Kernel_Name"])
             if k:
-                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                rows.append((k, r["Counter_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])))
+    biggest = collections.defaultdict(int)
+    for k, _, g, _ in rows:
+        biggest[k] = max(biggest[k], g)
+    agg = collections.defaultdict(list)
+    for k, c, g, v in rows:
+        if g == biggest[k]:
+            agg[(k, c)].append(v)
     return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def full_size_durations():
+    """average duration (ns) of the full-size dispatches of the forward / inverse kernel, from the kernel trace"""
+    rows = []
+    with open(one("prof_kt/*/*_kernel_trace.csv")) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            if k:
+                rows.append((k, int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    biggest = collections.defaultdict(int)
+    for k, g, _ in rows:
+        biggest[k] = max(biggest[k], g)
+    out = {}
+    for k in biggest:
+        d = [t for kk, g, t in rows if kk == k and g == biggest[k]]
+        out[k] = {"launches": len(d), "average_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+    return out
 
 
 def main() -> None:
@@ -97,6 +124,11 @@ def main() -> None:
             "write_bytes_from_WRREQ_x64": (c.get((k, "TCC_EA0_WRREQ_sum")) or 0) * 64,
             "algorithmic_bytes": 2 * nbytes, "traffic_over_algorithmic": (read_b + write_b) / (2 * nbytes),
         }
+    dur = full_size_durations()
+    for k in ("fwd_tiled", "inv_tiled"):
+        detail[k]["rocprofv3_full_size_launches"] = dur.get(k)
+        if dur.get(k):
+            detail[k]["fraction_of_8TBps_on_algorithmic_bytes"] = round(2 * nbytes / (dur[k]["average_ns"] * 1e-9) / 8e12, 4)
     rec["fwd_hbm_bytes_per_launch"] = int(detail["fwd_tiled"]["hbm_bytes"])
     rec["inv_hbm_bytes_per_launch"] = int(detail["inv_tiled"]["hbm_bytes"])
     with open(os.path.join(OUT, f"{tag}_pmc.json"), "w") as f:
