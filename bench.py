@@ -510,7 +510,7 @@ def archive_main(args) -> None:
     R.finish()
 
 
-def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev) -> dict:
+def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, want_devices: int) -> dict:
     """north_star's multi-GPU statement as ONE call: a host-resident block array is split by contiguous block range over
     every visible device and each shard's slice of every stream lands at its final host offset (dxtlt_transform_sharded;
     the reference side of the contract is one call over the whole array, transform_with_settings.rs:31-72).  Host
@@ -523,7 +523,7 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev) -
     block = pkg.BLOCK_BYTES[fmt]
     nbytes -= nbytes % (block * 2048)
     blocks = nbytes // block
-    n_dev = pkg.load().dxtlt_device_count()
+    n_dev = max(1, min(int(want_devices), pkg.load().dxtlt_device_count()))   # as many devices as the job has ranks
     t0 = time.perf_counter()
     h_in = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
     h_soa = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
@@ -544,7 +544,7 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev) -
         best = None
         for _ in range(3):
             t = time.perf_counter()
-            pkg.transform_sharded(fmt, inverse, src, dst, settings, 0)
+            pkg.transform_sharded(fmt, inverse, src, dst, settings, n_dev)
             dt = time.perf_counter() - t
             best = dt if best is None else min(best, dt)
         return best
@@ -760,7 +760,7 @@ def main() -> None:
     if host_gib > 0 and not args.drop_blocks:
         del y, z
         torch.cuda.empty_cache()
-        out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev)
+        out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev, world)
     R.cpu_barrier()
     if world == 1 and not args.no_cpu_baseline:
         s = (int(settings.decorrelation_mode), bool(getattr(settings, "split_alpha_endpoints", True)),

@@ -46,8 +46,8 @@ int32_t device_range(bool inverse, const void* d_src, void* d_dst, uint64_t tota
         return fail(kInvalidArgument, "NULL device buffer");
     hipError_t e = dxtlt::bc7::launch_range(inverse, d_src, d_dst, total, first, num, (hipStream_t)stream);
     if (e == hipErrorInvalidValue)
-        return fail(kInvalidArgument, "BC7: device buffers must be 16-byte aligned; a range starts on a sort granule (1024 "
-                                      "blocks) and ends on one or at the end of the array");
+        return fail(kInvalidArgument, "BC7: a range starts on a sort granule (1024 blocks) and ends on one or at the end of the "
+                                      "array");
     if (e != hipSuccess)
         return fail(kDevice, "BC7 kernel launch", e);
     return kOk;

@@ -86,6 +86,17 @@ __device__ __forceinline__ void gstore16(void* p, u32x4 v)
 #endif
 }
 
+// AoS-side store of the inverse kernels: the write-through streaming store when the block array is 16-byte aligned (a
+// tile's 4 KiB are whole lines); plain `nt` when it is not -- every tile then shares its first and last line with its
+// neighbours, and write-through on shared lines is what collapsed to 0.39-0.50 in round 1
+__device__ __forceinline__ void gstore16_aos(uint8_t* aos_base, void* p, u32x4 v)
+{
+    if ((reinterpret_cast<uintptr_t>(aos_base) & 15) == 0)   // uniform
+        gstore16(p, v);
+    else
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+}
+
 __host__ __device__ constexpr int fmt_block(int fmt) { return fmt == kBc1 ? 8 : 16; }
 // one 16-byte vector per lane: a THREADS-wide workgroup owns THREADS*16 bytes of blocks
 __host__ __device__ constexpr int tile_blocks(int fmt, int threads) { return threads * 16 / fmt_block(fmt); }
@@ -299,7 +310,7 @@ inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t t
     lds_at<u32x4>(lds, t * 16) = gload16(soa + o);
     __syncthreads();
     const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC, T>(lds, t);
-    gstore16(aos + tile * (THREADS * 16) + t * 16, q);
+    gstore16_aos(aos, aos + tile * (THREADS * 16) + t * 16, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,7 +322,8 @@ inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t t
 // leaves (arrives) as aligned 16-byte vectors, and only the first and last 16-byte segment of a slice are
 // partial; those are moved with 1/2/4/8-byte accesses that touch exactly the slice's own bytes, so the
 // neighbouring tile (which owns the rest of that 16-byte segment) never races with it.
-// Precondition: the AoS pointer is 16-byte aligned.  256-thread tiles.
+// The AoS pointer is 16-byte aligned in the common case; any other address works (unaligned vector accesses), a little
+// slower.  256-thread tiles.
 // ------------------------------------------------------------------------------------------------
 struct Shifts {
     int d[6];
@@ -911,7 +923,7 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
     for (int j = 0; j < R; ++j) {
         const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t + 256 * j, base)
                                    : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t + 256 * j, base);
-        gstore16(aos + tile * (4096 * R) + (t + 256 * j) * 16, q);
+        gstore16_aos(aos, aos + tile * (4096 * R) + (t + 256 * j) * 16, q);
     }
 }
 
@@ -1385,7 +1397,12 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     //   shifted tiles: AoS pointer 16-byte aligned, stream bases anywhere
     //   element kernel: everything else, and the tail that does not fill a tile
     const Streams S = make_streams(fmt, sa, sc);
-    const bool aos_ok = (reinterpret_cast<uintptr_t>(aos) & 15) == 0;
+    // The AoS side may sit at any byte address: 16-byte vector loads / stores at unaligned addresses are exact on gfx950
+    // under ROCm's default memory mode and cost little (tools/unaligned_lab.hip: a streaming copy at 0.845 of peak drops
+    // to 0.81-0.83 with misaligned loads, 0.78-0.79 with misaligned stores) -- far less than the element kernel, which
+    // round 1 sent such buffers to (0.4-0.7).  A DDS file that lies whole in HBM has its payload at byte 128 or 148.
+    // Experiment switch 0x1000 restores the round-1 rule (tiles only for a 16-byte aligned AoS pointer).
+    const bool aos_ok = (reinterpret_cast<uintptr_t>(aos) & 15) == 0 || !(force_bits_early(tuning) & 0x1000);
     Shifts sh{};
     bool any_shift = false;
     for (int i = 0; i < S.n; ++i) {
@@ -1485,8 +1502,9 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)
     for (int i = 0; i < 6; ++i)
         e.shift[i] = i < S.n ? (uint8_t)((reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * e.blocks) & 15) : 0;
     const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
-    // tiles need a 16-byte aligned AoS pointer; anything else goes through the element path block by block
-    const uint64_t tiles = (reinterpret_cast<uintptr_t>(aos) & 15) == 0 ? e.blocks / T : 0;
+    // any AoS alignment: unaligned 16-byte vector accesses are exact and cheap on gfx950 (launch_transform)
+    (void)aos;
+    const uint64_t tiles = e.blocks / T;
     const uint64_t tail_wgs = (e.blocks - tiles * T + 255) / 256;
     e.tile_wgs = (uint32_t)tiles;
     return (uint32_t)(tiles + tail_wgs);

@@ -632,7 +632,7 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 {
     g_tile_threads.store(tile_threads);
     // bits 8..9 of force_path carry the XCD-remap experiment switch: 0x100 = off, 0x200 = on, 0 = default
-    g_force_generic.store(force_generic & 0xCFF);  // 0x400: first form of the forward shifted tiles (no halo)
+    g_force_generic.store(force_generic & 0x1CFF);  // 0x400: first form of the forward shifted tiles (no halo)
     g_xcd_remap.store((force_generic & 0x100) ? 0 : (force_generic & 0x200) ? 1 : -1);
 }
 

@@ -9,7 +9,8 @@
  * Parity: exact round trip and GPU == oracle/dxtlt_oracle_bc7.c only.
  *
  * Contract: len is a multiple of 16; output length == input length; buffers must not overlap; returns DXTLT_* status
- * codes of dxtlt_gfx950.h.  Device-pointer calls need 16-byte aligned buffers; they enqueue one kernel (two when the
+ * codes of dxtlt_gfx950.h.  Device-pointer calls take any pointer alignment (16-byte aligned buffers are the fast case);
+ * they enqueue one kernel (two when the
  * block count is not a multiple of 1024) on the stream, use no scratch memory and do not synchronise, so they can be
  * captured into a HIP graph.
  */

@@ -185,6 +185,27 @@ def test_gpu_equals_oracle(pkg, bc7, oracle, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shift", [1, 4, 8, 20])
+def test_gpu_misaligned_device_pointers(bc7, oracle, shift):
+    """Both pointers off 16-byte alignment (a whole DDS file in HBM has its payload at byte 148): unaligned vector
+    accesses, same bytes, nothing written before or behind the output."""
+    dev = torch.device("cuda:0")
+    for n in (5, 1024, 3 * 1024 + 77):
+        x = make_blocks(oracle, n, "skewed", n + shift)
+        xd = torch.zeros(x.size + shift, dtype=torch.uint8, device=dev)
+        xd[shift:] = torch.from_numpy(x).to(dev)
+        yd = torch.full((x.size + shift + 32,), 0x5A, dtype=torch.uint8, device=dev)
+        bc7.transform_bc7(xd[shift:], yd[shift:shift + x.size])
+        zd = torch.full((x.size + shift + 32,), 0x5A, dtype=torch.uint8, device=dev)
+        bc7.untransform_bc7(yd[shift:shift + x.size], zd[shift:shift + x.size])
+        torch.cuda.synchronize()
+        assert np.array_equal(yd[shift:shift + x.size].cpu().numpy(), oracle.transform_bc7(x)), (n, shift)
+        assert np.array_equal(zd[shift:shift + x.size].cpu().numpy(), x), (n, shift)
+        for t in (yd, zd):
+            assert bool((t[:shift] == 0x5A).all()) and bool((t[shift + x.size:] == 0x5A).all()), (n, shift)
+
+
+@pytest.mark.gpu
 def test_gpu_real_bc7_texture(bc7, oracle):
     import os
 

@@ -72,3 +72,57 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+# ---- on the GPU box: the bench itself, small -----------------------------------------------------------------------
+import pytest  # noqa: E402
+
+
+def _run_bench(extra, env=None, timeout=600):
+    import json
+
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--size-gib", "0.25", *extra], capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields_and_the_host_array_leg():
+    d = _run_bench(["--host-array-gib", "0.25"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "u8" and d["vs_baseline"] is None
+    assert d["config"]["bit_exact_roundtrip_and_oracle_window"] is True
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    # a 0.25 GiB run is not the workload of profiles/pmc_traffic.json: no carried traffic figure
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"] is None
+    h = d["sharded_host_array"]
+    assert h["devices"] >= 1 and h["bit_exact_roundtrip_and_oracle_windows_across_shard_boundaries"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_self_launched_on_one_gpu(scaling):
+    """`python bench.py --gpus 2` from a bare shell: the parent starts the ranks; here they share the one GPU over gloo.
+    Strong scaling = one array, each rank its block range through dxtlt_transform_range_device."""
+    d = _run_bench(["--gpus", "2", "--scaling", scaling, "--host-array-gib", "0"], env={"DXTLT_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling
+    assert d["config"]["bit_exact_roundtrip_and_oracle_window"] is True
+    total = d["config"]["total_blocks"]
+    assert total == (d["config"]["blocks_per_gpu"] * 2)      # strong: the array split in two; weak: two shards of one array
+    assert ("ONE logical" in d["config"]["workload"]) == (scaling == "strong")
+
+
+@pytest.mark.gpu
+def test_bench_bc7_and_archive_lines():
+    d = _run_bench(["--format", "bc7"])
+    assert d["config"]["format"] == "bc7" and d["roofline"]["pipeline_bytes"] == d["roofline"]["algorithmic_bytes_per_launch"]
+    a = _run_bench(["--workload", "archive", "--size-gib", "1", "--gpus", "2", "--archive-split", "range"],
+                   env={"DXTLT_BENCH_BACKEND": "gloo"})
+    assert a["config"]["archive_split"] == "range" and a["config"]["bit_exact_roundtrip_and_oracle_windows"] is True
