@@ -749,9 +749,15 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
 // last tile's windows -- are records of the first 16 and of the last 16 + (num_blocks mod T) blocks of the range, which
 // the element kernel writes (launch_transform); where the two overlap they write the same values.
 // ------------------------------------------------------------------------------------------------
-constexpr int kHaloBlocks = 16;
+// Windows are moved back to a 64-BYTE boundary, not just a 16-byte one (d_s = stream base mod 64): two tiles that meet
+// inside a 128-byte line then each write whole 64-byte sectors of it, which is what the memory side writes without a
+// read-modify-write -- with 16-byte boundaries such lines had to meet in one L2 (XCD-contiguous tile order, itself worth
+// -0.04) or cost 0.08 (profiles/r02_b_shift_probe.txt).  The halo grows to at most 63 bytes per stream = at most 63
+// blocks for a 1-byte stream; only as many vectors as some stream needs are fetched (Shifts::halo_vecs).
+constexpr int kHaloBlocks = 64;
+constexpr int kHaloPad = 64;   // bytes between the stream regions of the LDS image: room for d_s
 template <int FMT>
-constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, 256) + kHaloBlocks) + 16 * 6; }
+constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, 256) + kHaloBlocks) + kHaloPad * 6; }
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -785,10 +791,11 @@ __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, co
         if constexpr (lo < wave_hi && hi > wave_lo) {
             constexpr bool only = lo <= wave_lo && hi >= wave_hi;   // the whole wave sits in this stream
             if (only || (o >= lo && o < hi)) {
-                la = S.off[s] * (T + H) + 16 * s + S.width[s] * H + (o - lo);
+                la = S.off[s] * (T + H) + kHaloPad * s + S.width[s] * H + (o - lo);
                 g = gb[s] + (uint64_t)(o - lo);
-                // no halo in front of the range: the element kernel writes the bytes of that first segment
-                skip = first_tile && o == lo && sh.d[s] > 0;
+                // no halo in front of the range: segments that start before the stream's first byte are left to the
+                // element kernel (it writes the records of the range's first 64 blocks)
+                skip = first_tile && (o - lo) < sh.d[s];
             }
         }
     });
@@ -811,17 +818,17 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint6
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256);
     constexpr int H = kHaloBlocks;
-    constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors: 16 (BC2 / BC3) or 8 (BC1)
+    constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors at most: 64 (BC2 / BC3) or 32 (BC1)
     __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
     const int t = threadIdx.x;
     const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     const uint64_t blk0 = first_block + tile * T;
-    // region of stream s: starts at off_s * (T + H) + 16 * s (16-byte aligned), holds the records of blocks
-    // [blk0 - H, blk0 + T) from byte d_s on; base[s] = address of the record of the tile's block 0
+    // region of stream s: starts at off_s * (T + H) + 64 * s (16-byte aligned), holds the records of blocks
+    // [blk0 - H, blk0 + T) from byte d_s on (d_s = 0..63); base[s] = address of the record of the tile's block 0
     int base[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s)
-        base[s] = s < S.n ? S.off[s] * (T + H) + 16 * s + sh.d[s] + S.width[s] * H : 0;
+        base[s] = s < S.n ? S.off[s] * (T + H) + kHaloPad * s + sh.d[s] + S.width[s] * H : 0;
 
     const uint8_t* tile_aos = aos + tile * 4096;
     const u32x4 q = gload16(tile_aos + t * 16);
@@ -1440,30 +1447,27 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     const uint64_t num_tiles = use_tiles ? r.num_blocks / T : 0;
     // forward shifted tiles take the halo form (whole segments only) unless experiment switch 0x400 asks for the first form
     const bool use_halo = use_shift && !inverse && ks.halo[0] != nullptr && !(force_bits & 0x400);
+    Shifts shh = sh;   // the halo tiles' own shifts: stream base mod 64
     if (use_halo) {
-        // Windows that all start on a 128-byte line share no line with the neighbouring tile: identity tile order and
-        // write-through stores, as for aligned tiles.  Otherwise two tiles complete each boundary line and should
-        // meet in one L2 (XCD-contiguous order: 0.74-0.75 against 0.67-0.69, profiles/r02_b_shift_probe.txt).
-        bool line_aligned = true;
+        int halo_blocks = 0;
         for (int i = 0; i < S.n; ++i) {
             const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
                                   (uint64_t)S.width[i] * r.first_block;
-            line_aligned = line_aligned && ((base - (base & 15)) & 127) == 0;
+            shh.d[i] = (int)(base & 63);
+            halo_blocks = std::max(halo_blocks, (shh.d[i] + S.width[i] - 1) / S.width[i]);
         }
-        if (remap_override < 0)
-            sh.xcd_remap = line_aligned ? 0 : 1;
-        if (line_aligned && sh.line_policy == 1 && !(force_bits & 0x800))
-            sh.line_policy = 3;
-        int halo_blocks = 0;
-        for (int i = 0; i < S.n; ++i)
-            halo_blocks = std::max(halo_blocks, (sh.d[i] + S.width[i] - 1) / S.width[i]);
+        shh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, shh.d);
+        // every window starts on a 64-byte sector: no line needs to meet its other half in one L2 -- identity tile order
+        // and, unless experiment switch 0x800 asks for plain nt, the write-through streaming stores of the aligned tiles
+        shh.xcd_remap = remap_override >= 0 ? remap_override : 0;
+        shh.line_policy = (force_bits & 0x800) ? 1 : 3;
         const int per_vec = 16 / fmt_block(fmt);
-        sh.halo_vecs = (halo_blocks + per_vec - 1) / per_vec;
+        shh.halo_vecs = (halo_blocks + per_vec - 1) / per_vec;
     }
     if (num_tiles > 0) {
         if (use_halo)
-            hipLaunchKernelGGL(ks.halo[sh.natural ? 1 : 0], dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8,
-                               r.total_blocks, r.first_block, sh);
+            hipLaunchKernelGGL(ks.halo[shh.natural ? 1 : 0], dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8,
+                               r.total_blocks, r.first_block, shh);
         else if (use_shift)
             hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
                                r.first_block, sh);
@@ -1484,8 +1488,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         return hipGetLastError();
     };
     if (use_halo && num_tiles > 0) {
-        // what the halo tiles' windows leave out: the head of every stream of the range (records of its first 16 blocks)
-        // and everything behind the last window (records of the last 16 blocks of the tiles, and the rest)
+        // what the halo tiles' windows leave out: the head of every stream of the range (records of its first 64 blocks)
+        // and everything behind the last window (records of the last 64 blocks of the tiles, and the rest)
         if (hipError_t e = element_range(0, kHaloBlocks); e != hipSuccess)
             return e;
         done -= kHaloBlocks;
