@@ -383,9 +383,11 @@ def archive_main(args) -> None:
                                the texture's whole transformed buffer)
     A step transforms and restores every texture (slice) of the rank.  Verified per texture (exact round trip, an oracle
     window) and, since random blocks compress to ratio 1, the compression-ratio half of the config is checked on the
-    reference's real 256x256 test textures with zlib level 6 (the image has no zstd binding; zlib stands in for the
-    config's zstd): GPU output == CPU output byte for byte, so the ratios are equal, and both are reported."""
+    reference's real 256x256 test textures with zstd levels 3 and 19 (the system libzstd through ctypes,
+    tools/zstd_ratio.py; zlib level 6 beside it, and alone when libzstd is absent): GPU output == CPU output byte for
+    byte, so the ratios are equal, and both are reported."""
     import zlib
+    from tools import zstd_ratio
 
     import numpy as np
     import torch
@@ -481,6 +483,11 @@ def archive_main(args) -> None:
             ratios[f] = {"plain_zlib6": round(tiled.size / len(zlib.compress(tiled.tobytes(), 6)), 4),
                          "transformed_gpu_zlib6": round(tiled.size / len(zlib.compress(gpu_out.tobytes(), 6)), 4),
                          "transformed_cpu_zlib6": round(tiled.size / len(zlib.compress(cpu_out.tobytes(), 6)), 4)}
+            if zstd_ratio.available():
+                for level in (3, 19):
+                    ratios[f][f"plain_zstd{level}"] = round(tiled.size / zstd_ratio.compressed_size(tiled, level), 4)
+                    ratios[f][f"transformed_gpu_zstd{level}"] = round(tiled.size / zstd_ratio.compressed_size(gpu_out, level), 4)
+                    ratios[f][f"transformed_cpu_zstd{level}"] = round(tiled.size / zstd_ratio.compressed_size(cpu_out, level), 4)
     assert ok, "GPU result differs from the oracle / round trip failed"
     if rank != 0:
         R.finish()
@@ -496,10 +503,10 @@ def archive_main(args) -> None:
             "workload": f"BC1+BC3 mixed archive, {archive_gib:g} GiB of alternating 256 MiB textures, default settings per format, "
                         + ("every texture's block range cut over the ranks (dxtlt_transform_range_device), " if by_range else
                            "contiguous byte range of the archive per rank = whole textures, ")
-                        + "no collective (BASELINE.json configs[4]; compression ratios with zlib-6 in place of zstd)",
+                        + "no collective (BASELINE.json configs[4]; compression ratios: zstd -3 / -19 of the system libzstd when present, zlib-6 beside them)",
             "archive_split": args.archive_split, "textures_touched_per_gpu": k, "texture_bytes": tex_bytes, "seed": "0xa5c0005",
             "bit_exact_roundtrip_and_oracle_windows": ok,
-            "zlib6_ratio_on_real_textures": ratios,
+            "ratio_on_real_textures": ratios, "zstd_version": zstd_ratio.version(),
         },
         "roofline": {"bound": "hbm", "kernel": "fwd_tiled + inv_tiled over the archive", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "achieved": round(2 * (2 * rank_bytes * args.steps) / elapsed / 1e9, 1),
