@@ -71,11 +71,17 @@ def bind(lib):
 
 def make_estimator(kind: str, log=None):
     """kind: 'dummy' (size = len, like the reference's C dummy estimator, bc1 c_api/transform_auto.rs:200-231),
-    'zlib' (zlib level 1 size), 'fail_max' / 'fail_est' (callback errors)."""
+    'zlib' (zlib level 1 size), 'zstd' (the system libzstd at level 1 through tools/zstd_ratio.py: what the reference's
+    estimator crate does, extensions/compressors/dxt-lossless-transform-zstd/src/lib.rs:146-200, with zstd 1.5.7),
+    'fail_max' / 'fail_est' (callback errors)."""
+    if kind == "zstd":
+        from tools import zstd_ratio
 
     def py_estimate(buf: bytes) -> int:
         if kind == "zlib":
             return len(zlib.compress(buf, 1))
+        if kind == "zstd":
+            return zstd_ratio.compressed_size(buf, 1) if buf else 0
         if kind == "crc":          # every byte of the section matters; the log records what the estimator was shown
             return zlib.crc32(buf) & 0xFFFFF
         return len(buf)
@@ -84,7 +90,7 @@ def make_estimator(kind: str, log=None):
     def max_fn(ctx, n, out):
         if kind == "fail_max":
             return 41
-        out[0] = n + 64 if kind in ("zlib", "crc") else (0 if kind == "dummy0" else n)
+        out[0] = n + 64 if kind in ("zlib", "crc", "zstd") else (0 if kind == "dummy0" else n)
         return 0
 
     @ESTFN

@@ -143,8 +143,9 @@ def test_stable_auto_builder(lib, oracle, n):
     fmt = FMT[n]
     p = f"dltbc{n}_"
     x = payload(fmt)
-    for use_all in (False, True):
-        est, py_est = cabi.make_estimator("zlib")
+    from tools import zstd_ratio
+    for use_all, kind in ((False, "zlib"), (True, "zlib")) + (((False, "zstd"), (True, "zstd")) if zstd_ratio.available() else ()):
+        est, py_est = cabi.make_estimator(kind)
         want_choice, want_out, _ = oracle_auto.transform_auto(fmt, x, lambda b: py_est(bytes(b)), use_all)
         ab = getattr(lib, p + "new_AutoTransformBuilder")(C.byref(est))
         assert getattr(lib, p + "AutoTransformBuilder_SetUseAllDecorrelationModes")(ab, use_all).ErrorCode == 0

@@ -492,7 +492,8 @@ def test_sharded_entry_point_on_one_gpu(pkg, oracle, dev, fmt):
 
 def test_randomised_dispatch(pkg, oracle, dev):
     """400 seeded random cases: format, settings, block count (0..40 000), and independent byte offsets of the input and
-    output device pointers (0..31) -- every combination of aligned-tile / shifted-tile / element-kernel dispatch with
+    output device pointers (0..127: the halo tiles move their windows back to 64-byte boundaries, so stream bases of
+    every residue mod 64 must come up) -- every combination of aligned-tile / shifted-tile / element-kernel dispatch with
     ragged tails -- forward bytes against the oracle, inverse against the input, and guard bytes on both sides."""
     rng = np.random.default_rng(0xD15BA7C4)
     for case in range(400):
@@ -500,15 +501,15 @@ def test_randomised_dispatch(pkg, oracle, dev):
         settings = list(all_settings(fmt))
         s = settings[int(rng.integers(0, len(settings)))]
         n = int(rng.integers(0, 40_001)) if case % 4 else int(rng.integers(0, 40)) * TILE[fmt]
-        a, b = int(rng.integers(0, 32)) if case % 3 else 0, int(rng.integers(0, 32)) if case % 5 else 0
+        a, b = int(rng.integers(0, 128)) if case % 3 else 0, int(rng.integers(0, 128)) if case % 5 else 0
         nbytes = n * BLOCK[fmt]
         x = oracle.fill_splitmix64(nbytes, 0xFA22 + case)
         st = pkg_settings(pkg, fmt, s)
-        xd = torch.full((nbytes + 64,), 0x11, dtype=torch.uint8, device=dev)
+        xd = torch.full((nbytes + 256,), 0x11, dtype=torch.uint8, device=dev)
         xd[a:a + nbytes] = torch.from_numpy(x).to(dev)
-        yd = torch.full((nbytes + 64,), 0x22, dtype=torch.uint8, device=dev)
+        yd = torch.full((nbytes + 256,), 0x22, dtype=torch.uint8, device=dev)
         getattr(pkg, f"transform_{fmt}_with_settings")(xd[a:a + nbytes], yd[b:b + nbytes], st)
-        zd = torch.full((nbytes + 64,), 0x33, dtype=torch.uint8, device=dev)
+        zd = torch.full((nbytes + 256,), 0x33, dtype=torch.uint8, device=dev)
         getattr(pkg, f"untransform_{fmt}_with_settings")(yd[b:b + nbytes], zd[a:a + nbytes], st)
         torch.cuda.synchronize()
         tag = (case, fmt, settings_id(s), n, a, b)

@@ -1,0 +1,171 @@
+"""Seeded random campaign, GPU against the oracle, for a time budget: whole-buffer calls and RANGE calls of BC1/2/3 with
+random settings, block counts (tiny, around tile multiples, up to a few million), first blocks, and byte offsets 0..191
+of both device pointers; BC7 whole buffers and granule ranges.  Guard bytes around every output.  Prints one line per
+100 cases and the failing case's parameters (re-runnable: `python tools/fuzz_gpu.py --seed S --only CASE`).
+Test tooling: imports oracle/.   usage: python tools/fuzz_gpu.py [--seconds 300] [--seed 1]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import dxt_lossless_transform_amd as pkg  # noqa: E402
+from dxt_lossless_transform_amd import bc7 as bc7mod  # noqa: E402
+from oracle import oracle_c  # noqa: E402
+
+BLOCK = {"bc1": 8, "bc2": 16, "bc3": 16}
+TILE = {"bc1": 512, "bc2": 256, "bc3": 256}
+
+
+def settings_of(fmt, rng):
+    v, sc, sa = int(rng.integers(0, 4)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    if fmt == "bc3":
+        return (v, sa, sc), pkg.Bc3TransformSettings(pkg.YCoCgVariant(v), sa, sc)
+    cls = pkg.Bc1TransformSettings if fmt == "bc1" else pkg.Bc2TransformSettings
+    return (v, False, sc), cls(pkg.YCoCgVariant(v), sc)
+
+
+def block_count(fmt, rng):
+    k = int(rng.integers(0, 10))
+    t = TILE[fmt]
+    if k < 3:
+        return int(rng.integers(0, 200))
+    if k < 6:
+        return max(0, int(rng.integers(1, 40)) * t + int(rng.integers(-70, 71)))
+    if k < 9:
+        return int(rng.integers(0, 60_000))
+    return int(rng.integers(500_000, 3_000_000))
+
+
+def guard_ok(h, lo, n, fill):
+    return bool((h[:lo] == fill).all() and (h[lo + n:] == fill).all())
+
+
+def bcn_case(case, rng, dev):
+    fmt = ("bc1", "bc2", "bc3")[int(rng.integers(0, 3))]
+    (v, sa, sc), st = settings_of(fmt, rng)
+    n = block_count(fmt, rng)
+    B = BLOCK[fmt]
+    a, b = int(rng.integers(0, 192)), int(rng.integers(0, 192))
+    if rng.integers(0, 4) == 0:
+        a = 0
+    if rng.integers(0, 4) == 0:
+        b = 0
+    x = oracle_c.fill_splitmix64(n * B, 0xF00D + case)
+    want = oracle_c.transform(fmt, x, v, sc, sa)
+    xd = torch.full((n * B + 256,), 0x11, dtype=torch.uint8, device=dev)
+    xd[a:a + n * B] = torch.from_numpy(x).to(dev)
+    yd = torch.full((n * B + 256,), 0x22, dtype=torch.uint8, device=dev)
+    zd = torch.full((n * B + 256,), 0x33, dtype=torch.uint8, device=dev)
+    ranged = bool(rng.integers(0, 2)) and n > 0
+    tag = dict(case=case, fmt=fmt, settings=(v, sa, sc), n=n, a=a, b=b, ranged=ranged)
+    if not ranged:
+        getattr(pkg, f"transform_{fmt}_with_settings")(xd[a:a + n * B], yd[b:b + n * B], st)
+        getattr(pkg, f"untransform_{fmt}_with_settings")(yd[b:b + n * B], zd[a:a + n * B], st)
+    else:
+        # cut [0, n) at random places; every piece is one range call, in a random order
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, size=int(rng.integers(1, 5)))]))
+        pieces = list(zip(cuts, cuts[1:]))
+        tag["cuts"] = cuts
+        for i in rng.permutation(len(pieces)):
+            lo, hi = pieces[int(i)]
+            pkg.transform_range(fmt, False, xd[a + lo * B:a + n * B], yd[b:b + n * B], n, lo, hi - lo, st)
+        torch.cuda.synchronize()
+        for i in rng.permutation(len(pieces)):
+            lo, hi = pieces[int(i)]
+            pkg.transform_range(fmt, True, yd[b:b + n * B], zd[a + lo * B:a + n * B], n, lo, hi - lo, st)
+    torch.cuda.synchronize()
+    yh, zh = yd.cpu().numpy(), zd.cpu().numpy()
+    ok = (np.array_equal(yh[b:b + n * B], want) and np.array_equal(zh[a:a + n * B], x)
+          and guard_ok(yh, b, n * B, 0x22) and guard_ok(zh, a, n * B, 0x33))
+    return ok, tag
+
+
+def bc7_blocks(n, rng, case):
+    x = oracle_c.fill_splitmix64(n * 16, 0xB7 + case).copy()
+    kind = int(rng.integers(0, 4))
+    if kind == 3:
+        return x                                   # raw bytes: modes by trailing zeros, reserved encoding included
+    v = x.reshape(-1, 16)
+    if kind == 0:
+        modes = rng.integers(0, 8, size=n)
+    elif kind == 1:
+        modes = rng.choice(8, size=n, p=[.02, .25, .02, .13, .02, .02, .52, .02])
+    else:
+        modes = np.repeat(rng.integers(0, 8, size=n // 97 + 1), 97)[:n]
+    m = modes.astype(np.int64)
+    v[:, 0] = (((v[:, 0].astype(np.int64) & ~((2 << m) - 1)) | (1 << m)) & 0xFF).astype(np.uint8)
+    return x
+
+
+def bc7_case(case, rng, dev):
+    k = int(rng.integers(0, 4))
+    n = int(rng.integers(0, 3000)) if k < 2 else int(rng.integers(1, 30)) * 1024 + int(rng.integers(-3, 4)) if k == 2 \
+        else int(rng.integers(100_000, 1_500_000))
+    n = max(n, 0)
+    a, b = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+    x = bc7_blocks(n, rng, case)
+    want = oracle_c.transform_bc7(x) if n else x
+    xd = torch.full((n * 16 + 128,), 0x11, dtype=torch.uint8, device=dev)
+    xd[a:a + n * 16] = torch.from_numpy(x).to(dev)
+    yd = torch.full((n * 16 + 128,), 0x22, dtype=torch.uint8, device=dev)
+    zd = torch.full((n * 16 + 128,), 0x33, dtype=torch.uint8, device=dev)
+    ranged = bool(rng.integers(0, 2)) and n >= 2048
+    tag = dict(case=case, fmt="bc7", n=n, a=a, b=b, ranged=ranged)
+    if not ranged:
+        bc7mod.transform_bc7(xd[a:a + n * 16], yd[b:b + n * 16])
+        bc7mod.untransform_bc7(yd[b:b + n * 16], zd[a:a + n * 16])
+    else:
+        g = n // 1024
+        cuts = sorted(set([0, n] + [1024 * int(c) for c in rng.integers(0, g + 1, size=int(rng.integers(1, 4)))]))
+        tag["cuts"] = cuts
+        for lo, hi in zip(cuts, cuts[1:]):
+            bc7mod.transform_bc7_range(False, xd[a + lo * 16:a + n * 16], yd[b:b + n * 16], n, lo, hi - lo)
+        torch.cuda.synchronize()
+        for lo, hi in zip(cuts, cuts[1:]):
+            bc7mod.transform_bc7_range(True, yd[b:b + n * 16], zd[a + lo * 16:a + n * 16], n, lo, hi - lo)
+    torch.cuda.synchronize()
+    yh, zh = yd.cpu().numpy(), zd.cpu().numpy()
+    ok = (np.array_equal(yh[b:b + n * 16], want) and np.array_equal(zh[a:a + n * 16], x)
+          and guard_ok(yh, b, n * 16, 0x22) and guard_ok(zh, a, n * 16, 0x33))
+    return ok, tag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1)
+    args = ap.parse_args()
+    pkg.load()
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    case = 0
+    counts = {"bcn": 0, "bcn_ranged": 0, "bc7": 0, "bc7_ranged": 0}
+    while time.time() - t0 < args.seconds:
+        rng = np.random.default_rng([args.seed, case])
+        if args.only >= 0 and case != args.only:
+            case += 1
+            continue
+        is7 = rng.integers(0, 4) == 0
+        ok, tag = (bc7_case if is7 else bcn_case)(case, rng, dev)
+        counts[("bc7" if is7 else "bcn") + ("_ranged" if tag["ranged"] else "")] += 1
+        if not ok:
+            print("FAIL", tag, flush=True)
+            sys.exit(1)
+        case += 1
+        if case % 100 == 0:
+            print(f"{case} cases ok, {time.time() - t0:.0f} s, {counts}", flush=True)
+        if args.only >= 0:
+            break
+    print(f"done: {case} cases, all exact, seed {args.seed}, {counts}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
