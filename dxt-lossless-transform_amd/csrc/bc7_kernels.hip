@@ -14,19 +14,24 @@
 // How it maps to the machine.
 //   * ONE pass: 16 bytes in, 16 bytes out per block, no workspace, no grand totals, no second read of the input
 //     (version 0 placed blocks by global per-mode prefix sums: histogram pass + scatter pass = 3 x len of traffic).
-//   * One workgroup of 1024 lanes = one granule = one block per lane.  Forward: coalesced 16-byte loads; class by
-//     trailing zeros; rank inside the class by a 4-ballot wave match + mbcnt, per-wave class counts through a 9 x 16
-//     table in LDS, one scan per wave (lanes 0..8, DPP row shifts) -> sorted position; the raw blocks go to LDS at their
-//     sorted positions ("per-mode wavefront dispatch": after the barrier lane j holds sorted block j, so a wave's 64
-//     blocks are of one mode except where two classes meet, and the mode switch below is wave-uniform -- the eight
-//     field permutations, 40-120 vector instructions each, are not executed eight times per wave); records are written
-//     into an LDS image laid out like the output; the image leaves as one aligned 16-byte streaming store per lane,
-//     every wave writing 1 KiB of ONE stream (8 waves Q8, 2 waves Q2, one wave per byte stream): no per-lane stream
-//     select at all.
-//   * Inverse: the mirror -- slices in (1 KiB per wave), classes from the F stream, the same ranks, F bytes to their
-//     sorted positions, records -> blocks in the sorted domain (wave-uniform modes again), blocks back to block order
-//     through LDS, coalesced 16-byte stores.
-//   * HBM-bound by design: 32 bytes of traffic per block; four workgroup barriers per granule.
+//   * One workgroup = one granule: 256 lanes x 4 blocks per lane (lane t owns blocks t, t + 256, ...: coalesced).
+//     Forward: 16-byte loads; class by trailing zeros; rank inside the class by a 3-ballot wave match + mbcnt per 64-block
+//     segment, per-segment class counts through a 9 x 16 table in LDS, one scan per wave for its four segments (16-lane
+//     rows, DPP row shifts) -> sorted position; the raw blocks go to LDS at their sorted positions ("per-mode wavefront
+//     dispatch": after the barrier lane j holds sorted block j, so a wave's 64 blocks are of one mode except where two
+//     classes meet, and the mode switch below is wave-uniform -- the eight field permutations, 40-90 vector instructions
+//     each, are not executed eight times per wave); records are written into an LDS image laid out like the output; the
+//     image leaves as one aligned 16-byte streaming store per lane, every wave-instruction writing 1 KiB of ONE stream
+//     (8 segments Q8, 2 Q2, one per byte stream): no per-lane stream select at all.
+//   * Inverse: the mirror -- slices in (1 KiB per wave instruction), classes from the F stream, the same ranks, F bytes
+//     to their sorted positions, records -> blocks in the sorted domain (wave-uniform modes again), blocks back to block
+//     order through LDS, coalesced 16-byte stores.
+//   * 19 KiB of LDS per workgroup (raw blocks and stream image share one region), so eight workgroups = eight granules
+//     in different phases per CU: the kernel's time does not depend on the mode mix any more --
+//     what bounds it is how much of a granule's life (load, five barriers, store) overlaps with its neighbours'.
+//     Persistent workgroups that prefetch the next granule were built three times (last: hand-kept vmcnt through inline
+//     asm, LDS-only barriers) and lost every time: 0.58 against 0.73-0.76.
+//   * 32 bytes of traffic per block, exactly (PMC).
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -53,13 +58,21 @@ static_assert(kT == 1024, "the copy-out assigns whole 64-block segments to strea
 //   off    0       8       10      11      12      13      14      15
 //   width  8       2       1       1       1       1       1       1
 
-// LDS: raw blocks at sorted positions | image of the output | per-class per-segment counts | per-segment class bases | sorted F
+// LDS.  Full granules: the raw blocks at their sorted positions and the image of the output's sorted streams (15 bytes per
+// block) take turns in ONE 16 KiB region -- every lane has its blocks / records in registers before the region changes
+// hands (one more barrier) -- and the F stream, which is written in block order while the raw blocks are being placed,
+// has a region of its own: 19 KiB per workgroup instead of 35, eight workgroups of 256 lanes per CU instead of four.
+//   data 16 KiB | F 1 KiB | per-class per-segment counts | per-segment class bases | sorted F 1 KiB (inverse)
+// Tail parts (one workgroup per call, n < 1024 blocks): the image is one contiguous run of 16 n bytes, F at byte 15 n,
+// in a region of its own behind the rest.
 constexpr int kLdsRaw = 0;
-constexpr int kLdsImage = kLdsRaw + kT * 16;
-constexpr int kLdsCounts = kLdsImage + kT * 16;                       // uint16_t [9][16]
+constexpr int kLdsF = kLdsRaw + kT * 16;                               // uint8_t [1024], block order
+constexpr int kLdsCounts = kLdsF + kT;                                // uint16_t [9][16]
 constexpr int kLdsBases = kLdsCounts + kClasses * kSegments * 2 + 32;  // uint16_t [16 segments][16]
 constexpr int kLdsSortedF = kLdsBases + kSegments * 16 * 2;           // uint8_t [1024] (inverse)
-constexpr int kLdsBytes = kLdsSortedF + kT;
+constexpr int kLdsTailImage = kLdsSortedF + kT;                       // 16 KiB, tail parts only
+template <bool TAIL>
+constexpr int lds_bytes() { return TAIL ? kLdsTailImage + kT * 16 : kLdsTailImage; }
 
 __device__ __forceinline__ u32x4 gload16(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 
@@ -165,10 +178,12 @@ bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t
 {
     constexpr int V = kT / LANES, WAVES = LANES / 64;
     static_assert(V >= 1 && V <= 4 && V * LANES == kT, "four 16-lane rows per wave: at most four segments per wave");
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_bytes<TAIL>()];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = TAIL ? n_tail : kT;
+    const int image = TAIL ? kLdsTailImage : kLdsRaw;            // sorted streams: record bytes 1..15
+    const int image_f = TAIL ? kLdsTailImage + 15 * n : kLdsF;   // F stream, block order
     const uint64_t granule = blockIdx.x;
     const uint8_t* src = aos + granule * (kT * 16);
 
@@ -203,28 +218,37 @@ bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t
             const int pos = (int)lds_at<uint16_t>(lds, kLdsBases + (v * WAVES + wave) * 32 + cls[v] * 2) + rank[v];
             const B128 b = {{q[v].x, q[v].y, q[v].z, q[v].w}};
             lds_at<u32x4>(lds, kLdsRaw + 16 * pos) = q[v];
-            lds_at<uint8_t>(lds, kLdsImage + 15 * n + v * LANES + t) = (uint8_t)record_byte0(b, cls[v]);   // F: block order
+            lds_at<uint8_t>(lds, image_f + v * LANES + t) = (uint8_t)record_byte0(b, cls[v]);   // F: block order
         }
     }
     __syncthreads();
 
     // sorted domain: lane t holds sorted blocks t, t + LANES, ...; the class is the same across a wave's 64 blocks except
     // where two classes meet
+    u32x4 sorted[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        sorted[v] = u32x4{0, 0, 0, 0};
+        if (!TAIL || j < n)
+            sorted[v] = lds_at<u32x4>(lds, kLdsRaw + 16 * j);
+    }
+    if constexpr (!TAIL)
+        __syncthreads();   // the raw blocks are in registers: their region becomes the image
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int j = v * LANES + t;
         if (!TAIL || j < n) {
-            const u32x4 s = lds_at<u32x4>(lds, kLdsRaw + 16 * j);
-            const B128 sb = {{s.x, s.y, s.z, s.w}};
-            const B128 r = record_of_block_any(sb, block_class(s.x));
+            const B128 sb = {{sorted[v].x, sorted[v].y, sorted[v].z, sorted[v].w}};
+            const B128 r = record_of_block_any(sb, block_class(sorted[v].x));
             // record bytes 1..8 -> Q8, 9..10 -> Q2, 11..15 -> B0..B4
-            lds_at<u32x2>(lds, kLdsImage + 8 * j) = u32x2{__builtin_amdgcn_alignbyte(r.d[1], r.d[0], 1), __builtin_amdgcn_alignbyte(r.d[2], r.d[1], 1)};
-            lds_at<uint16_t>(lds, kLdsImage + 8 * n + 2 * j) = (uint16_t)(r.d[2] >> 8);
-            lds_at<uint8_t>(lds, kLdsImage + 10 * n + j) = (uint8_t)(r.d[2] >> 24);
-            lds_at<uint8_t>(lds, kLdsImage + 11 * n + j) = (uint8_t)r.d[3];
-            lds_at<uint8_t>(lds, kLdsImage + 12 * n + j) = (uint8_t)(r.d[3] >> 8);
-            lds_at<uint8_t>(lds, kLdsImage + 13 * n + j) = (uint8_t)(r.d[3] >> 16);
-            lds_at<uint8_t>(lds, kLdsImage + 14 * n + j) = (uint8_t)(r.d[3] >> 24);
+            lds_at<u32x2>(lds, image + 8 * j) = u32x2{__builtin_amdgcn_alignbyte(r.d[1], r.d[0], 1), __builtin_amdgcn_alignbyte(r.d[2], r.d[1], 1)};
+            lds_at<uint16_t>(lds, image + 8 * n + 2 * j) = (uint16_t)(r.d[2] >> 8);
+            lds_at<uint8_t>(lds, image + 10 * n + j) = (uint8_t)(r.d[2] >> 24);
+            lds_at<uint8_t>(lds, image + 11 * n + j) = (uint8_t)r.d[3];
+            lds_at<uint8_t>(lds, image + 12 * n + j) = (uint8_t)(r.d[3] >> 8);
+            lds_at<uint8_t>(lds, image + 13 * n + j) = (uint8_t)(r.d[3] >> 16);
+            lds_at<uint8_t>(lds, image + 14 * n + j) = (uint8_t)(r.d[3] >> 24);
         }
     }
     __syncthreads();
@@ -235,10 +259,11 @@ bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t
         if constexpr (TAIL) {
             // the tail part is one contiguous run of 16 n bytes with the image's own layout
             if (j < n)
-                *reinterpret_cast<u32x4*>(soa + 16 * j) = lds_at<u32x4>(lds, kLdsImage + 16 * j);
+                *reinterpret_cast<u32x4*>(soa + 16 * j) = lds_at<u32x4>(lds, image + 16 * j);
         } else {
-            const uint64_t o = slice_offset(j, v * WAVES + wave, part_blocks, first_block + granule * kT);
-            store_streaming16(soa + o, lds_at<u32x4>(lds, kLdsImage + 16 * j));
+            const int segment = v * WAVES + wave;   // segment 15 is the F stream
+            const uint64_t o = slice_offset(j, segment, part_blocks, first_block + granule * kT);
+            store_streaming16(soa + o, lds_at<u32x4>(lds, segment == 15 ? kLdsF + 16 * (j - 15 * 64) : image + 16 * j));
         }
     }
 }
@@ -249,10 +274,12 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
 {
     constexpr int V = kT / LANES, WAVES = LANES / 64;
     static_assert(V >= 1 && V <= 4 && V * LANES == kT, "four 16-lane rows per wave: at most four segments per wave");
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_bytes<TAIL>()];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = TAIL ? n_tail : kT;
+    const int image = TAIL ? kLdsTailImage : kLdsRaw;
+    const int image_f = TAIL ? kLdsTailImage + 15 * n : kLdsF;
     const uint64_t granule = blockIdx.x;
 
     u32x4 in[V];
@@ -270,9 +297,15 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
     if (t < kClasses * kSegments)
         lds_at<uint16_t>(lds, kLdsCounts + 2 * t) = 0;
 #pragma unroll
-    for (int v = 0; v < V; ++v)
-        if (!TAIL || v * LANES + t < n)
-            lds_at<u32x4>(lds, kLdsImage + 16 * (v * LANES + t)) = in[v];
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        if constexpr (TAIL) {
+            if (j < n)
+                lds_at<u32x4>(lds, image + 16 * j) = in[v];
+        } else {
+            lds_at<u32x4>(lds, v * WAVES + wave == 15 ? kLdsF + 16 * (j - 15 * 64) : image + 16 * j) = in[v];
+        }
+    }
     __syncthreads();
 
     int cls[V], rank[V];
@@ -280,7 +313,7 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const bool live = !TAIL || v * LANES + t < n;
-        f[v] = live ? lds_at<uint8_t>(lds, kLdsImage + 15 * n + v * LANES + t) : 0u;
+        f[v] = live ? lds_at<uint8_t>(lds, image_f + v * LANES + t) : 0u;
         cls[v] = live ? block_class(f[v]) : kClasses;
         int count;
         rank_in_segment(cls[v], rank[v], count);
@@ -301,24 +334,34 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
     }
     __syncthreads();
 
+    // sorted domain: the record of sorted block j from the streams' image and the sorted F bytes
+    B128 rec[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int j = v * LANES + t;
+        rec[v] = B128{{0, 0, 0, 0}};
+        if (!TAIL || j < n) {
+            const uint32_t f2 = lds_at<uint8_t>(lds, kLdsSortedF + j);
+            const u32x2 q8 = lds_at<u32x2>(lds, image + 8 * j);
+            const uint32_t q2 = lds_at<uint16_t>(lds, image + 8 * n + 2 * j);
+            const uint32_t b0 = lds_at<uint8_t>(lds, image + 10 * n + j);
+            const uint32_t b1 = lds_at<uint8_t>(lds, image + 11 * n + j);
+            const uint32_t b2 = lds_at<uint8_t>(lds, image + 12 * n + j);
+            const uint32_t b3 = lds_at<uint8_t>(lds, image + 13 * n + j);
+            const uint32_t b4 = lds_at<uint8_t>(lds, image + 14 * n + j);
+            rec[v].d[0] = f2 | (q8.x << 8);
+            rec[v].d[1] = (q8.x >> 24) | (q8.y << 8);
+            rec[v].d[2] = (q8.y >> 24) | (q2 << 8) | (b0 << 24);
+            rec[v].d[3] = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
+        }
+    }
+    if constexpr (!TAIL)
+        __syncthreads();   // the records are in registers: the image's region takes the blocks
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int j = v * LANES + t;
         if (!TAIL || j < n) {
-            const uint32_t f2 = lds_at<uint8_t>(lds, kLdsSortedF + j);
-            const u32x2 q8 = lds_at<u32x2>(lds, kLdsImage + 8 * j);
-            const uint32_t q2 = lds_at<uint16_t>(lds, kLdsImage + 8 * n + 2 * j);
-            const uint32_t b0 = lds_at<uint8_t>(lds, kLdsImage + 10 * n + j);
-            const uint32_t b1 = lds_at<uint8_t>(lds, kLdsImage + 11 * n + j);
-            const uint32_t b2 = lds_at<uint8_t>(lds, kLdsImage + 12 * n + j);
-            const uint32_t b3 = lds_at<uint8_t>(lds, kLdsImage + 13 * n + j);
-            const uint32_t b4 = lds_at<uint8_t>(lds, kLdsImage + 14 * n + j);
-            B128 r;
-            r.d[0] = f2 | (q8.x << 8);
-            r.d[1] = (q8.x >> 24) | (q8.y << 8);
-            r.d[2] = (q8.y >> 24) | (q2 << 8) | (b0 << 24);
-            r.d[3] = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
-            const B128 blk = block_of_record_any(r, block_class(f2));
+            const B128 blk = block_of_record_any(rec[v], block_class(rec[v].d[0]));
             lds_at<u32x4>(lds, kLdsRaw + 16 * j) = u32x4{blk.d[0], blk.d[1], blk.d[2], blk.d[3]};
         }
     }
@@ -349,9 +392,9 @@ hipError_t launch_range(bool inverse, const void* src, void* dst, uint64_t total
     const uint8_t* aos = static_cast<const uint8_t*>(inverse ? dst : src);     // the range's first block
     const uint8_t* soa = static_cast<const uint8_t*>(inverse ? src : dst);     // byte 0 of the whole transformed buffer
     const uint64_t range_main = first_block >= main_blocks ? 0 : (first_block + num_blocks > main_blocks ? main_blocks : first_block + num_blocks) - first_block;
-    // Workgroup size: 512 lanes x 2 blocks per lane unless DXTLT_BC7_LANES says 256 or 1024 (experiments; DESIGN.md
+    // Workgroup size: 256 lanes x 4 blocks per lane unless DXTLT_BC7_LANES says 512 or 1024 (experiments; DESIGN.md
     // section 9 has the measurements).  A launch of 2^32 or more threads is refused: at most 2^21 granules per launch.
-    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 256 || x == 1024 ? x : 512; }();
+    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 512 || x == 1024 ? x : 256; }();
     using Kernel = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int);
     const Kernel fwd = lanes == 1024 ? bc7_forward<1024, false> : lanes == 512 ? bc7_forward<512, false> : bc7_forward<256, false>;
     const Kernel inv = lanes == 1024 ? bc7_inverse<1024, false> : lanes == 512 ? bc7_inverse<512, false> : bc7_inverse<256, false>;

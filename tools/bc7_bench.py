@@ -24,13 +24,17 @@ if dist == "uniform":
     m = r & 7
 elif dist == "mode6":
     m = torch.full_like(r, 6)
+elif dist == "reserved":   # byte 0 == 0 everywhere: class 8, records == blocks -- the sort and the streams without any bit-field work
+    m = torch.full_like(r, 8)
+elif dist == "mode0":
+    m = torch.full_like(r, 0)
 elif dist == "runs":   # texture-like: long runs of one mode (64 blocks), modes skewed
     rr = r.view(-1, 64)[:, :1].expand(-1, 64).reshape(-1)
     m = torch.where(rr < 140, 6, torch.where(rr < 200, 1, torch.where(rr < 230, 3, rr & 7))).to(torch.int32)
 else:  # texture-like skew: mode 6 > 1 > 3 > others
     m = torch.where(r < 140, 6, torch.where(r < 200, 1, torch.where(r < 230, 3, r & 7))).to(torch.int32)
 low = ((2 << m) - 1).to(torch.uint8)
-b[:, 0] = (b[:, 0] & ~low) | (1 << m).to(torch.uint8)
+b[:, 0] = (b[:, 0] & ~low) | ((1 << m) & 0xFF).to(torch.uint8)
 del r, low
 y, z = torch.empty_like(x), torch.empty_like(x)
 for _ in range(2):
