@@ -767,7 +767,11 @@ def main() -> None:
     if host_gib > 0 and not args.drop_blocks:
         del y, z
         torch.cuda.empty_cache()
-        out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev, world)
+        # an extra leg beside `value`: if it cannot run (a device this rank may not open, host memory), say so and keep the line
+        try:
+            out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev, world)
+        except Exception as e:  # noqa: BLE001
+            out["sharded_host_array"] = {"error": f"{type(e).__name__}: {e}"}
     R.cpu_barrier()
     if world == 1 and not args.no_cpu_baseline:
         s = (int(settings.decorrelation_mode), bool(getattr(settings, "split_alpha_endpoints", True)),
