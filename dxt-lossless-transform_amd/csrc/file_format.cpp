@@ -48,12 +48,25 @@ bool likely_dds(const uint8_t* p, size_t len) { return len >= kDdsHeaderSize && 
 // saturating u32 add (the reference uses u32::saturating_add on the running total; the products wrap)
 inline uint32_t sat_add(uint32_t a, uint32_t b) { return a + b < a ? 0xFFFFFFFFu : a + b; }
 
+// `levels` more levels of `level_bytes` each, added one by one with saturation -- in closed form.  The mip count comes
+// from the file (any u32); once a chain has reached 1 x 1 every further level adds the same few bytes, and a header
+// that claims four billion levels must not cost four billion iterations.
+inline uint32_t sat_add_repeated(uint32_t total, uint32_t level_bytes, uint32_t levels)
+{
+    const uint64_t sum = (uint64_t)total + (uint64_t)level_bytes * (uint64_t)levels;
+    return sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
+}
+
 bool pixel_length(uint32_t w, uint32_t h, uint32_t mips, uint32_t bpp, uint32_t* out)
 {
     if (bpp == 0)
         return false;
     uint32_t total = 0;
     for (uint32_t i = 0; i < mips; ++i) {
+        if (w == 1 && h == 1) {
+            total = sat_add_repeated(total, bpp, mips - i);
+            break;
+        }
         total = sat_add(total, w * h * bpp);
         w = w / 2 > 1 ? w / 2 : 1;
         h = h / 2 > 1 ? h / 2 : 1;
@@ -67,6 +80,10 @@ bool block_length(uint8_t fmt, uint32_t w, uint32_t h, uint32_t mips, uint32_t* 
     const uint32_t block = (fmt == BC1 || fmt == BC4) ? 8 : 16;
     uint32_t total = 0;
     for (uint32_t i = 0; i < mips; ++i) {
+        if (w == 1 && h == 1) {
+            total = sat_add_repeated(total, block, mips - i);
+            break;
+        }
         const uint32_t bw = w / 4 + (w % 4 != 0), bh = h / 4 + (h % 4 != 0);
         total = sat_add(total, bw * bh * block);
         w = w / 2 > 1 ? w / 2 : 1;

@@ -137,6 +137,59 @@ def test_block_data_length(lib, w, h, mips, fourcc, want):
     assert lib.parse_dds(d.ctypes.data, d.size).DataLength == want
 
 
+def model_block_length(w, h, mips, block):
+    """calculate_data_length_for_block_compression, level by level: u32 products wrap, the running total saturates
+    (parse_dds.rs:316-323); the 1 x 1 tail in closed form so that the model finishes for any mip count"""
+    total = 0
+    for i in range(mips):
+        if w == 1 and h == 1:
+            return min(total + block * (mips - i), 0xFFFFFFFF)
+        level = (((w + 3) // 4) * ((h + 3) // 4) * block) & 0xFFFFFFFF
+        total = min(total + level, 0xFFFFFFFF)
+        w, h = max(w // 2, 1), max(h // 2, 1)
+    return total
+
+
+def test_hostile_mip_counts_cost_nothing_and_saturate(lib):
+    import time
+    for w, h, mips, fourcc, block in [(4, 4, 0xFFFFFFFF, b"DXT1", 8), (256, 256, 0xFFFFFFFF, b"DXT5", 16),
+                                      (1, 1, 0x80000000, b"DXT3", 16), (65536, 65536, 0x7FFFFFFF, b"DXT1", 8),
+                                      (3, 1000, 123456789, b"DXT5", 16), (16384, 16384, 40, b"DXT1", 8)]:
+        d = np.frombuffer(bytes(legacy_header(fourcc, w, h, mips)) + bytes(16), dtype=np.uint8)
+        t = time.perf_counter()
+        got = lib.parse_dds(d.ctypes.data, d.size).DataLength
+        assert time.perf_counter() - t < 0.05                      # the file's mip count is not a loop bound
+        assert got == model_block_length(w, h, mips, block), (w, h, mips)
+    # the same for uncompressed pixels: 4 bytes per pixel, 1 x 1 forever
+    hd = legacy_header(b"\0\0\0\0", 2, 2, 0xFFFFFFFF, 0x41)
+    struct.pack_into("<IIIII", hd, 0x58, 32, 0xFF, 0xFF00, 0xFF0000, 0xFF000000)
+    d = np.frombuffer(bytes(hd) + bytes(64), dtype=np.uint8)
+    i = lib.parse_dds(d.ctypes.data, d.size)
+    assert (i.Format, i.DataLength) == (RGBA8888, 0xFFFFFFFF)
+
+
+def test_random_headers_never_read_past_the_header_and_match_the_model(lib):
+    """2 000 random 128 / 148-byte headers placed at the very end of a buffer (a read past the header would run into
+    the guard page of a separate mapping at best -- here the point is the length model, any size, any mip count)."""
+    rng = np.random.default_rng(0xDD5)
+    fourccs = [(b"DXT1", BC1, 8), (b"DXT3", BC2, 16), (b"DXT5", BC3, 16), (b"ATI1", BC4, 8), (b"BC5U", BC5, 16)]
+    for case in range(2000):
+        cc, code, block = fourccs[int(rng.integers(0, len(fourccs)))]
+        w = int(rng.choice([0, 1, 2, 3, 4, 5, 255, 256, 257, 4096, 65535, 65536, 0xFFFFFFFF, int(rng.integers(0, 1 << 20))]))
+        h = int(rng.choice([0, 1, 2, 3, 4, 7, 256, 1000, 65536, 0xFFFFFFFF, int(rng.integers(0, 1 << 20))]))
+        mips = int(rng.choice([0, 1, 2, 9, 13, 33, 1000, 0xFFFFFFFF, int(rng.integers(0, 1 << 32))]))
+        hd = legacy_header(cc, w, h, mips)
+        if case % 3 == 0:
+            struct.pack_into("<I", hd, 8, 0x1007)                  # DDSD_MIPMAPCOUNT clear: one level whatever the count says
+            mips_eff = 1
+        else:
+            mips_eff = max(mips, 1)
+        d = np.frombuffer(bytes(hd), dtype=np.uint8)
+        i = lib.parse_dds(d.ctypes.data, d.size)
+        assert (i.Format, i.DataOffset) == (code, 128), (case, cc)
+        assert i.DataLength == model_block_length(w, h, mips_eff, block), (case, w, h, mips)
+
+
 def test_uncompressed_formats(lib):
     def rgb(bits, masks, flags):
         hd = legacy_header(b"\0\0\0\0", 4, 2, 0, flags)
