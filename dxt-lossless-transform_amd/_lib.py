@@ -45,7 +45,8 @@ def _declare(l: C.CDLL) -> None:
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # DXTLT_LIB_PATH: another build of the same library (tools/asan_host_check.sh points it at the sanitizer build)
+    return os.environ.get("DXTLT_LIB_PATH") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:

@@ -19,7 +19,10 @@ OK, INVALID_LENGTH, OUTPUT_TOO_SMALL = 0, 1, 2
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (``make -C oracle``) if the .so is missing or stale."""
+    """Compile the oracle with gcc (``make -C oracle``) if the .so is missing or stale.  DXTLT_ORACLE_SO names another
+    build of the same sources instead (tools/asan_host_check.sh: the sanitizer build)."""
+    if os.environ.get("DXTLT_ORACLE_SO"):
+        return os.environ["DXTLT_ORACLE_SO"]
     srcs = [os.path.join(_HERE, f) for f in ("dxtlt_oracle.c", "dxtlt_oracle_bc7.c", "dxtlt_oracle_avx2.c",
                                              "dxtlt_oracle_norm.c", "dxtlt_oracle.h")]
     stale = (
