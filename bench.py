@@ -36,6 +36,7 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -63,10 +64,26 @@ def self_launch_if_needed(args) -> None:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    for line in child.stdout:          # rank 0's JSON line (and nothing else) arrives here; relay as it comes
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in child.stdout:          # rank 0's JSON line goes to stdout as it comes; anything else a library printed, to stderr
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     sys.exit(child.wait())
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 -> 2 for the duration: the gloo transport announces its connections on stdout from C++
+    ("[Gloo] Rank 0 is connected to ..."), and this program's stdout carries ONE JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class Ranks:
@@ -98,13 +115,15 @@ class Ranks:
             import torch.distributed as dist
 
             self.dist = dist
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
-                # waiting for rank 0's host-side legs must not park a spinning RCCL kernel on every GPU
-                self.cpu_group = dist.new_group(backend="gloo")
-            else:
-                dist.init_process_group(self.backend)
-                self.cpu_group = None
+            with stdout_to_stderr():
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.dev)
+                    # waiting for rank 0's host-side legs must not park a spinning RCCL kernel on every GPU
+                    self.cpu_group = dist.new_group(backend="gloo")
+                else:
+                    dist.init_process_group(self.backend)
+                    self.cpu_group = None
+                dist.barrier(group=self.cpu_group)   # connections are made (and announced) here at the latest
 
     def barrier(self) -> None:
         if self.dist is not None:

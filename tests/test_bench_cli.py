@@ -51,6 +51,29 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell():
     assert rec == {"rendezvous": "ok", "n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo"}
 
 
+def test_stdout_of_a_launcher_run_is_one_json_line():
+    """The driver's own shape for N > 1: `python -m torch.distributed.run ... bench.py --gpus N`.  The gloo transport
+    prints "[Gloo] Rank r is connected to ..." on stdout from C++; bench.py moves that to stderr, so stdout is the one
+    JSON line of rank 0 and nothing else.  Three ranks, --rendezvous-only (no GPU)."""
+    import json
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DXTLT_BENCH_BACKEND"] = "gloo"
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 3, "max_over_ranks": 3.0, "backend": "gloo"}
+
+
 def test_bench_self_launch_returns_the_childs_exit_code():
     """No GPU here: the ranks of a real run fail at 'bench.py needs a GPU'; the parent must report that failure."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
