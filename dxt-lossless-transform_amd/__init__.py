@@ -134,6 +134,16 @@ def set_tuning(tile_threads: int = 0, force_path: int = 0) -> None:
     load().dxtlt_set_tuning(int(tile_threads), int(force_path))
 
 
+def set_auto_estimator_threads(threads: int) -> None:
+    """Opt-in (process-wide): run the size estimator of the auto transforms on `threads` host threads, once per distinct
+    section (include/dxtlt_gfx950.h).  1 = the reference's sequence of calls.  The estimator must be thread-safe."""
+    load().dxtlt_set_auto_estimator_threads(int(threads))
+
+
+def get_auto_estimator_threads() -> int:
+    return int(load().dxtlt_get_auto_estimator_threads())
+
+
 # ------------------------------------------------------------------------------------------------------
 # buffer plumbing
 # ------------------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ def _declare(l: C.CDLL) -> None:
     l.dxtlt_device_count.argtypes, l.dxtlt_device_count.restype = [], i32
     l.dxtlt_set_tuning.argtypes, l.dxtlt_set_tuning.restype = [i32, i32], None
     l.dxtlt_version.argtypes, l.dxtlt_version.restype = [], C.c_char_p
+    l.dxtlt_set_auto_estimator_threads.argtypes, l.dxtlt_set_auto_estimator_threads.restype = [i32], None
+    l.dxtlt_get_auto_estimator_threads.argtypes, l.dxtlt_get_auto_estimator_threads.restype = [], i32
 
 
 def lib_path() -> str:

@@ -21,7 +21,11 @@
 // reference's bytes.  One transform launch with the winning settings and one download of the whole result finish the
 // call.  If the arena (2-4 x len) cannot be allocated the candidates are produced one full transform at a time, as in
 // round 1 (same results, len x 2 of traffic per candidate).
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <thread>
+#include <vector>
 
 #include "../../include/dxtlt_gfx950.h"
 #include "auto_launch.h"
@@ -97,9 +101,140 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Opt-in: the estimator on several host threads (dxtlt_set_auto_estimator_threads).  The reference evaluates its
+// candidates one after the other because each is a transform into the one output buffer; here every section a
+// candidate can show the estimator already sits in the arena, so the estimator -- the hot loop of this call
+// (transform/mod.rs:32-34: 265 MiB/s with zstd level 1, 1 GiB/s with LTU, one thread) -- can run on all of them at
+// once.  And every DISTINCT section is estimated once: BC3's 8 / 16 candidates are 2 alpha-endpoint sections x 4 / 8
+// colour sections = 6 / 10 estimator calls instead of 16 / 32.  Same candidates, same sizes, same order of
+// comparison and strict `<`: the same choice and the same bytes as the sequential flow -- what changes is the
+// sequence of callback invocations (concurrent, once per distinct section), which is why the caller has to ask for it:
+// the callbacks must be safe to call from several threads at once with the same Context.
+// ---------------------------------------------------------------------------------------------------------------
+std::atomic<int> g_estimator_threads{1};
+constexpr size_t kStageCapBytes = size_t(512) << 20;   // pinned staging per wave of sections (one section at least)
+
+struct HostStage {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    ~HostStage() { release(); }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    void* get(size_t bytes)
+    {
+        if (bytes > cap) {
+            release();
+            if (hipHostMalloc(&ptr, bytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                ptr = nullptr;
+                return nullptr;
+            }
+            cap = bytes;
+        }
+        return ptr;
+    }
+};
+thread_local HostStage g_stage;
+
+struct Section {
+    const uint8_t* d_src;   // in the arena
+    size_t len;
+    size_t size = 0;        // the estimator's answer
+    uint32_t rc = 0;        // the estimator's status
+    size_t slot = 0;        // byte offset in the staging buffer of its wave
+};
+
+// Estimates every section; false = a HIP call failed (*hip_error).  Estimator failures are recorded per section.
+bool estimate_sections_parallel(std::vector<Section>& sections, const DltSizeEstimator* est, size_t max_comp, int threads,
+                                hipStream_t st, hipError_t* hip_error)
+{
+    size_t largest = 0;
+    for (const Section& s : sections)
+        largest = std::max(largest, (s.len + 255) & ~size_t(255));
+    const size_t cap = std::max(largest, kStageCapBytes);
+    size_t want = 0, run = 0;
+    for (const Section& s : sections) {   // the largest wave the cap allows, in order
+        const size_t b = (s.len + 255) & ~size_t(255);
+        if (run + b > cap)
+            run = 0;
+        run += b;
+        want = std::max(want, run);
+    }
+    uint8_t* stage = static_cast<uint8_t*>(g_stage.get(want));
+    if (stage == nullptr) {
+        *hip_error = hipErrorOutOfMemory;
+        return false;
+    }
+    threads = std::max(1, std::min<int>(threads, (int)sections.size()));
+    std::vector<uint8_t*> scratch((size_t)threads, nullptr);
+    bool ok = true;
+    if (max_comp != 0)
+        for (auto& p : scratch) {
+            p = static_cast<uint8_t*>(std::aligned_alloc(64, (max_comp + 63) / 64 * 64));
+            ok = ok && p != nullptr;
+        }
+    *hip_error = ok ? hipSuccess : hipErrorOutOfMemory;
+    size_t first = 0;
+    while (ok && first < sections.size()) {
+        size_t last = first, used = 0;
+        while (last < sections.size() && (last == first || used + ((sections[last].len + 255) & ~size_t(255)) <= cap)) {
+            sections[last].slot = used;
+            used += (sections[last].len + 255) & ~size_t(255);
+            ++last;
+        }
+        for (size_t i = first; i < last && ok; ++i)
+            if (sections[i].len) {
+                *hip_error = hipMemcpyAsync(stage + sections[i].slot, sections[i].d_src, sections[i].len, hipMemcpyDeviceToHost, st);
+                ok = *hip_error == hipSuccess;
+            }
+        if (ok) {
+            *hip_error = hipStreamSynchronize(st);
+            ok = *hip_error == hipSuccess;
+        }
+        if (!ok)
+            break;
+        std::atomic<size_t> next{first};
+        auto worker = [&](int tid) {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= last)
+                    return;
+                Section& s = sections[i];
+                s.rc = est->EstimateCompressedSize(est->Context, stage + s.slot, s.len, scratch[(size_t)tid], max_comp, &s.size);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t)
+            pool.emplace_back(worker, t);
+        worker(0);
+        for (auto& t : pool)
+            t.join();
+        first = last;
+    }
+    for (auto p : scratch)
+        std::free(p);
+    return ok;
+}
+
 }  // namespace
 
-void dxtlt_host::release_auto_thread_arena() { g_arena.release(); }
+extern "C" void dxtlt_set_auto_estimator_threads(int32_t threads)
+{
+    g_estimator_threads.store(threads < 1 ? 1 : threads > 64 ? 64 : threads, std::memory_order_relaxed);
+}
+
+extern "C" int32_t dxtlt_get_auto_estimator_threads(void) { return g_estimator_threads.load(std::memory_order_relaxed); }
+
+void dxtlt_host::release_auto_thread_arena()
+{
+    g_arena.release();
+    g_stage.release();
+}
 
 int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* out, size_t len,
                                    const DltSizeEstimator* est, bool use_all, AutoChoice* choice)
@@ -167,7 +302,48 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
         count = use_all ? 8 : 4;
     }
 
-    for (int i = 0; i < count; ++i) {
+    const int est_threads = g_estimator_threads.load(std::memory_order_relaxed);
+    const bool parallel = est_threads > 1 && arena != nullptr && len > 0;
+    if (parallel) {
+        // distinct sections: colour (variant, split) pairs in the arena's order, then BC3's two alpha-endpoint sections
+        const int variants = use_all ? 4 : 2;
+        std::vector<Section> sections;
+        for (int m = 0; m < variants; ++m)
+            for (int sp = 0; sp < 2; ++sp)
+                sections.push_back(Section{arena + dxtlt::auto_section_offset((dxtlt::Format)format, blocks, m, sp != 0), colour_len});
+        const size_t alpha_first = sections.size();
+        if (format == 3)
+            for (int sp = 0; sp < 2; ++sp)
+                sections.push_back(Section{arena + dxtlt::auto_alpha_section_offset(blocks, sp != 0), alpha_len});
+        hipError_t herr = hipSuccess;
+        if (!estimate_sections_parallel(sections, est, max_comp, est_threads, st, &herr))
+            HIP_TRY_AUTO(herr == hipSuccess ? hipErrorUnknown : herr, "parallel estimation (staging / download)");
+        for (int i = 0; i < count; ++i) {
+            const Candidate c = order[i];
+            size_t total = 0;
+            uint32_t bad = 0;
+            if (format == 3) {   // the reference's order inside a candidate: alpha endpoints, then colour endpoints
+                const Section& a = sections[alpha_first + (c.split_alpha ? 1 : 0)];
+                bad = a.rc;
+                total = a.size;
+            }
+            const Section& col = sections[(size_t)c.mode * 2 + (c.split_colour ? 1 : 0)];
+            if (bad == 0)
+                bad = col.rc;
+            total += col.size;
+            if (bad != 0) {   // the sequential flow stops at the first candidate whose estimate fails
+                std::free(scratch);
+                choice->estimator_error = bad;
+                return fail(kEstimator, "size estimator: estimate_compressed_size failed");
+            }
+            if (total < best_size) {
+                best_size = total;
+                best = c;
+            }
+        }
+    }
+
+    for (int i = 0; i < count && !parallel; ++i) {
         const Candidate c = order[i];
         if (len > 0) {
             const uint8_t* alpha_src = (const uint8_t*)d_out;

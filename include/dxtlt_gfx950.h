@@ -96,6 +96,18 @@ int32_t dxtlt_transform_bc3_auto(const uint8_t *input_ptr, uint8_t *output_ptr, 
                                  uint8_t *out_decorrelation_mode, bool *out_split_alpha_endpoints,
                                  bool *out_split_colour_endpoints, uint32_t *out_estimator_error);
 
+/* Additive, opt-in: run the size estimator of dxtlt_transform_bcN_auto (and of everything built on it: the dltbcN auto
+ * builders, dxtlt_dds_transform_auto) on `threads` host threads at once (1..64; default 1 = the reference's sequence of
+ * calls, core/dxt-lossless-transform-bc1/src/transform/transform_auto.rs:200-270).  The estimator is the hot loop of
+ * the auto transform (transform/mod.rs:32-34) and every section a candidate can show it is on the device after ONE
+ * kernel, so with threads > 1 every DISTINCT section (4 / 8 colour sections, plus BC3's 2 alpha-endpoint sections: 6 / 10
+ * estimator calls for BC3's 8 / 16 candidates) is downloaded to pinned memory and estimated concurrently.  Same
+ * candidates, same sizes, same comparison order and strict `<`: the same settings and bytes as with one thread.  What
+ * changes is the callback traffic -- concurrent, once per distinct section -- so the estimator's callbacks must be safe
+ * to call from several threads with the same Context (each call gets its own scratch buffer).  Process-wide. */
+void dxtlt_set_auto_estimator_threads(int32_t threads);
+int32_t dxtlt_get_auto_estimator_threads(void);
+
 /* ---- device pointers, whole buffer, asynchronous on `hip_stream` (a hipStream_t; NULL = default) -- */
 int32_t dxtlt_transform_bc1_with_settings_device(const void *d_input, void *d_output, size_t len,
                                                  uint8_t decorrelation_mode, bool split_colour_endpoints,

@@ -71,6 +71,10 @@ extern "C" {
         out_decorrelation_mode: *mut u8, out_split_alpha_endpoints: *mut bool, out_split_colour_endpoints: *mut bool,
         out_estimator_error: *mut u32) -> i32;
 
+    /// opt-in: the estimator on `threads` host threads, every distinct section once (callbacks must be thread-safe)
+    pub fn dxtlt_set_auto_estimator_threads(threads: i32);
+    pub fn dxtlt_get_auto_estimator_threads() -> i32;
+
     // ---- data that already lives in HBM: device pointers, asynchronous on a HIP stream -----------------------------
     pub fn dxtlt_transform_bc1_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,
         decorrelation_mode: u8, split_colour_endpoints: bool, hip_stream: *mut c_void) -> i32;

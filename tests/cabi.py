@@ -106,3 +106,27 @@ def make_estimator(kind: str, log=None):
     est = DltSizeEstimator(None, max_fn, est_fn)
     est._keep = (max_fn, est_fn)
     return est, py_estimate
+
+
+def zstd_c_estimator(level: int = 1):
+    """(DltSizeEstimator, lib) over tests/cpp/zstd_estimator.c -- a thread-safe C estimator on the system libzstd that
+    counts its calls and its highest concurrency; None when gcc or libzstd is missing."""
+    import os
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, so = os.path.join(here, "cpp", "zstd_estimator.c"), os.path.join(here, "cpp", "libzest.so")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", so, "-ldl"])
+        lib = C.CDLL(so)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    lib.zest_init.restype = C.c_int
+    if lib.zest_init() != 0:
+        return None
+    max_fn = C.cast(lib.zest_max_compressed_size, MAXFN)
+    est_fn = C.cast(lib.zest_estimate, ESTFN)
+    est = DltSizeEstimator(C.c_void_p(level), max_fn, est_fn)
+    est._keep = (max_fn, est_fn, lib)
+    return est, lib

@@ -201,3 +201,72 @@ def test_release_thread_resources_between_calls(pkg, oracle):
         assert np.array_equal(yd.cpu().numpy(), oracle.transform("bc1", x1, 1, True))
         torch.cuda.synchronize()
         l.dxtlt_release_thread_resources()
+
+
+# ---- opt-in: the estimator on several host threads (dxtlt_set_auto_estimator_threads) --------------------------------
+@pytest.fixture
+def estimator_threads(pkg):
+    yield pkg.set_auto_estimator_threads
+    pkg.set_auto_estimator_threads(1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_parallel_estimator_makes_the_same_choice(lib, pkg, oracle, estimator_threads, n):
+    """threads > 1: every distinct section once, concurrently -- same settings and bytes as the reference's sequence
+    (oracle_auto), with an estimator that sees every byte (CRC) and with zlib."""
+    fmt = FMT[n]
+    out = CORE_S[n]()
+    rng = np.random.default_rng(40 + n)
+    for blocks in (1, 37, 4099):
+        x = rng.integers(0, 256, blocks * BLOCK[fmt], dtype=np.uint8)
+        for use_all in (False, True):
+            for kind in ("crc", "zlib"):
+                est, py_est = cabi.make_estimator(kind)
+                want_choice, want_out, _ = oracle_auto.transform_auto(fmt, x, lambda b: py_est(bytes(b)), use_all)
+                for threads in (1, 4):
+                    estimator_threads(threads)
+                    assert pkg.get_auto_estimator_threads() == threads
+                    y = np.zeros_like(x)
+                    r = getattr(lib, f"dltbc{n}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                                     cabi.AutoSettings(use_all), C.byref(out))
+                    assert r.ErrorCode == 0, (fmt, blocks, use_all, kind, threads)
+                    assert np.array_equal(y, want_out), (fmt, blocks, use_all, kind, threads)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_parallel_estimator_calls_once_per_distinct_section_and_concurrently(lib, pkg, estimator_threads, n):
+    made = cabi.zstd_c_estimator(1)
+    if made is None:
+        pytest.skip("no gcc / libzstd for the C estimator")
+    est, zlib_c = made
+    fmt = FMT[n]
+    out = CORE_S[n]()
+    x = np.tile(payload(fmt), 64)                     # 2-4 MiB: long enough estimator calls to overlap
+    results = {}
+    for use_all in (False, True):
+        for threads in (1, 6):
+            estimator_threads(threads)
+            zlib_c.zest_reset()
+            y = np.zeros_like(x)
+            r = getattr(lib, f"dltbc{n}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                             cabi.AutoSettings(use_all), C.byref(out))
+            assert r.ErrorCode == 0
+            results[(use_all, threads)] = (y.copy(), zlib_c.zest_calls(), zlib_c.zest_max_concurrency())
+        seq, par = results[(use_all, 1)], results[(use_all, 6)]
+        assert np.array_equal(seq[0], par[0]), (fmt, use_all)          # same choice, same bytes
+        candidates = (8 if use_all else 4) if n != 3 else (16 if use_all else 8)
+        assert seq[1] == candidates * (2 if n == 3 else 1) and seq[2] == 1
+        assert par[1] == (8 if use_all else 4) + (2 if n == 3 else 0)  # distinct sections only
+        assert par[2] > 1                                              # and they did overlap
+
+
+def test_parallel_estimator_reports_estimator_failures(lib, pkg, estimator_threads):
+    estimator_threads(4)
+    for n in (1, 3):
+        x = payload(FMT[n])
+        y = np.zeros_like(x)
+        out = CORE_S[n]()
+        est, _ = cabi.make_estimator("fail_est")
+        r = getattr(lib, f"dltbc{n}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                         cabi.AutoSettings(False), C.byref(out))
+        assert r.ErrorCode == 7  # SizeEstimationError
