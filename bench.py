@@ -287,7 +287,7 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
 
 def bc7_main(args) -> None:
     """BASELINE.json configs[3]: BC7 forward (+ inverse) on a synthetic mode-mixed buffer.  Same JSON contract; the
-    transform is this build's own format (docs/BC7_FORMAT.md, version 1; the reference has none), so parity is a round
+    transform is this build's own format (docs/BC7_FORMAT.md, version 2; the reference has none), so parity is a round
     trip plus the build's own CPU statement.  One kernel per direction, 2 * len of traffic."""
     import torch
 
@@ -370,7 +370,7 @@ def bc7_main(args) -> None:
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {
-            "workload": f"BC7 granule-sorted field split v1, forward+inverse (this build's own format, parity unpinned), {nbytes / 2**30:g} GiB "
+            "workload": f"BC7 granule-sorted field split v2, forward+inverse (this build's own format, parity unpinned), {nbytes / 2**30:g} GiB "
                         "synthetic mode-mixed buffer per GPU, modes 0-7 uniform (BASELINE.json configs[3])",
             "format": "bc7", "blocks_per_gpu": blocks, "bytes_per_gpu": nbytes, "seed": hex(seed),
             "sharding": "independent buffer per rank, no collective",

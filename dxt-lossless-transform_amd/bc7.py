@@ -1,4 +1,4 @@
-"""BC7 granule-sorted field split, version 1 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
+"""BC7 granule-sorted field split, version 2 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
 no BC7 transform.  Thin Python layer over include/dxtlt_bc7.h, same buffer conventions as the BC1-3 functions."""
 from __future__ import annotations
 
@@ -49,7 +49,7 @@ def _run(inverse: bool, input, output, workspace=None) -> None:
 
         with torch.cuda.device(src.device):
             stream = torch.cuda.current_stream().cuda_stream
-            rc = getattr(l, name + "_device")(src.ptr, dst.ptr, src.nbytes, None, 0, stream)   # version 1: no workspace
+            rc = getattr(l, name + "_device")(src.ptr, dst.ptr, src.nbytes, None, 0, stream)   # since version 1: no workspace
     if rc != _lib.OK:
         raise DeviceError(rc, _lib.last_error())
 

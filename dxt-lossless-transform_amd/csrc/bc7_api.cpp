@@ -1,4 +1,4 @@
-// bc7_api.cpp -- C ABI of the BC7 granule-sorted field split, version 1 (include/dxtlt_bc7.h, docs/BC7_FORMAT.md).
+// bc7_api.cpp -- C ABI of the BC7 granule-sorted field split, version 2 (include/dxtlt_bc7.h, docs/BC7_FORMAT.md).
 // A format of this build's own: the reference has no BC7 transform; parity unpinned.
 #include "../../include/dxtlt_bc7.h"
 
@@ -63,7 +63,7 @@ int32_t device_call(bool inverse, const void* d_in, void* d_out, size_t len, voi
 
 }  // namespace
 
-void dxtlt_host::release_bc7_thread_scratch() {}   // version 1 keeps no per-thread device scratch
+void dxtlt_host::release_bc7_thread_scratch() {}   // since version 1: no per-thread device scratch
 
 extern "C" {
 
@@ -78,7 +78,7 @@ int32_t dxtlt_untransform_bc7(const uint8_t* input_ptr, uint8_t* output_ptr, siz
 size_t dxtlt_bc7_workspace_bytes(size_t len)
 {
     (void)len;
-    return 0;   // version 1 is a single pass with no device scratch
+    return 0;   // since version 1: a single pass with no device scratch
 }
 int32_t dxtlt_transform_bc7_device(const void* d_input, void* d_output, size_t len, void* d_workspace,
                                    size_t workspace_bytes, void* hip_stream)

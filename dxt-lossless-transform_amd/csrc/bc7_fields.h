@@ -1,4 +1,4 @@
-// bc7_fields.h -- BC7 block <-> record (docs/BC7_FORMAT.md, version 1): the per-mode bit-field permutation, with every
+// bc7_fields.h -- BC7 block <-> record (docs/BC7_FORMAT.md, version 2): the per-mode bit-field permutation, with every
 // position a compile-time constant so that it compiles to v_bfe / v_lshl_or / v_alignbit on four dwords.
 // Shared by the kernels (bc7_kernels.hip) and, compiled for the host, by tests/cpp/bc7_fields_shim.cpp, which checks it
 // against the oracle's one-field-at-a-time statement.
@@ -99,36 +99,82 @@ BC7_HD void copy_bits(const B128& from, B128& to)
     }
 }
 
+// ---- endpoints ---------------------------------------------------------------------------------------------------
+// The n = n_rgb / 3 fields of one colour channel lie side by side (n * w <= 30 bits in every mode), so a channel is ONE
+// dword of n lanes of w bits, and version 2's colour decorrelation -- red and blue as differences to the green of the same
+// endpoint, modulo 2^w -- is one lane-wise (SWAR) subtraction per channel.  H = the top bit of every lane.
+constexpr int channel_fields(int m) { return kModeDesc[m].n_rgb / 3; }
+constexpr int channel_bits(int m) { return channel_fields(m) * kModeDesc[m].w_rgb; }
+constexpr int alpha_bits(int m) { return kModeDesc[m].n_a * kModeDesc[m].w_a; }
+constexpr uint32_t lane_tops(int m)
+{
+    uint32_t h = 0;
+    for (int i = 0; i < channel_fields(m); ++i)
+        h |= 1u << (i * kModeDesc[m].w_rgb + kModeDesc[m].w_rgb - 1);
+    return h;
+}
+static_assert(channel_bits(2) == 30 && channel_bits(3) == 28 && alpha_bits(7) == 20 && alpha_bits(5) == 16, "one dword per channel");
+
+// lane-wise x - y and x + y modulo 2^w (no carry or borrow crosses a lane: the top bits are set / cleared first and
+// put right afterwards)
+template <int M>
+BC7_HD uint32_t lanes_sub(uint32_t x, uint32_t y)
+{
+    constexpr uint32_t H = lane_tops(M);
+    return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);
+}
+template <int M>
+BC7_HD uint32_t lanes_add(uint32_t x, uint32_t y)
+{
+    constexpr uint32_t H = lane_tops(M);
+    return ((x & ~H) + (y & ~H)) ^ ((x ^ y) & H);
+}
+
+// field E of the block (block order: reds, greens, blues, alphas) sits in channel dword c[E / n] (alpha: c[3]) at lane
+// E % n
 template <int M, int E>
-BC7_HD void split_endpoints(const B128& b, B128& r)
+BC7_HD void split_endpoints(const uint32_t (&c)[4], B128& r)
 {
     if constexpr (E < n_endpoints(M)) {
-        constexpr int w = endpoint_width(M, E), p = endpoint_pos(M, E);
-        put_bits<low_pos(M, E), w - 4>(r, get_bits<p, w - 4>(b));
-        put_bits<highs_start(M) + 4 * E, 4>(r, get_bits<p + w - 4, 4>(b));
-        split_endpoints<M, E + 1>(b, r);
+        constexpr bool rgb = E < kModeDesc[M].n_rgb;
+        constexpr int w = endpoint_width(M, E);
+        constexpr int ch = rgb ? E / channel_fields(M) : 3;
+        constexpr int at = (rgb ? E % channel_fields(M) : E - kModeDesc[M].n_rgb) * w;
+        if constexpr (w > 4)
+            put_bits<low_pos(M, E), w - 4>(r, (c[ch] >> at) & ((1u << (w - 4)) - 1u));
+        put_bits<highs_start(M) + 4 * E, 4>(r, (c[ch] >> (at + w - 4)) & 15u);
+        split_endpoints<M, E + 1>(c, r);
     }
 }
 
 template <int M, int E>
-BC7_HD void join_endpoints(const B128& r, B128& b)
+BC7_HD void join_endpoints(const B128& r, uint32_t (&c)[4])
 {
     if constexpr (E < n_endpoints(M)) {
-        constexpr int w = endpoint_width(M, E), p = endpoint_pos(M, E);
-        put_bits<p, w - 4>(b, get_bits<low_pos(M, E), w - 4>(r));
-        put_bits<p + w - 4, 4>(b, get_bits<highs_start(M) + 4 * E, 4>(r));
-        join_endpoints<M, E + 1>(r, b);
+        constexpr bool rgb = E < kModeDesc[M].n_rgb;
+        constexpr int w = endpoint_width(M, E);
+        constexpr int ch = rgb ? E / channel_fields(M) : 3;
+        constexpr int at = (rgb ? E % channel_fields(M) : E - kModeDesc[M].n_rgb) * w;
+        if constexpr (w > 4)
+            c[ch] |= get_bits<low_pos(M, E), w - 4>(r) << at;
+        c[ch] |= get_bits<highs_start(M) + 4 * E, 4>(r) << (at + w - 4);
+        join_endpoints<M, E + 1>(r, c);
     }
 }
 
-// record, LSB first: marker and header | p-bits and index bits | low (w - 4) bits of every endpoint | high nibbles
+// record, LSB first: marker and header | p-bits and index bits | low (w - 4) bits of every endpoint | high nibbles,
+// the endpoints being R - G, G, B - G (lane-wise, modulo 2^w) and A
 template <int M>
 BC7_HD B128 record_of_block(const B128& b)
 {
     B128 r = {{0, 0, 0, 0}};
     copy_bits<0, 0, endpoints_start(M)>(b, r);
     copy_bits<endpoints_end(M), endpoints_start(M), tail_len(M)>(b, r);
-    split_endpoints<M, 0>(b, r);
+    constexpr int cb = channel_bits(M), e0 = endpoints_start(M);
+    const uint32_t g = get_bits<e0 + cb, cb>(b);
+    const uint32_t c[4] = {lanes_sub<M>(get_bits<e0, cb>(b), g), g, lanes_sub<M>(get_bits<e0 + 2 * cb, cb>(b), g),
+                           get_bits<e0 + 3 * cb, alpha_bits(M)>(b)};
+    split_endpoints<M, 0>(c, r);
     return r;
 }
 
@@ -138,7 +184,13 @@ BC7_HD B128 block_of_record(const B128& r)
     B128 b = {{0, 0, 0, 0}};
     copy_bits<0, 0, endpoints_start(M)>(r, b);
     copy_bits<endpoints_start(M), endpoints_end(M), tail_len(M)>(r, b);
-    join_endpoints<M, 0>(r, b);
+    uint32_t c[4] = {0, 0, 0, 0};
+    join_endpoints<M, 0>(r, c);
+    constexpr int cb = channel_bits(M), e0 = endpoints_start(M);
+    put_bits<e0, cb>(b, lanes_add<M>(c[0], c[1]));
+    put_bits<e0 + cb, cb>(b, c[1]);
+    put_bits<e0 + 2 * cb, cb>(b, lanes_add<M>(c[2], c[1]));
+    put_bits<e0 + 3 * cb, alpha_bits(M)>(b, c[3]);
     return b;
 }
 

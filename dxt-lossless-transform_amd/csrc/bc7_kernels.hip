@@ -1,4 +1,4 @@
-// bc7_kernels.hip -- gfx950 kernels of the BC7 granule-sorted field split, version 1 (docs/BC7_FORMAT.md).
+// bc7_kernels.hip -- gfx950 kernels of the BC7 granule-sorted field split, version 2 (docs/BC7_FORMAT.md).
 //
 // A format of this build's own: the reference has no BC7 transform (core/dxt-lossless-transform-bc7/src/lib.rs:1-13);
 // it documents the modes' bit fields (assets/research/dds-bc7-blocks.hexpat:286-654), which bc7_fields.h follows.

@@ -1,4 +1,4 @@
-// bc7_launch.h -- internal launch interface of the BC7 granule-sorted field split, version 1 (docs/BC7_FORMAT.md).
+// bc7_launch.h -- internal launch interface of the BC7 granule-sorted field split, version 2 (docs/BC7_FORMAT.md).
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>

@@ -198,7 +198,7 @@ int dds_to_bcn(uint8_t fmt) { return fmt == BC1 ? 1 : fmt == BC2 ? 2 : fmt == BC
 // refused on the way back.
 std::atomic<bool> g_bc7_enabled{false};
 constexpr uint32_t kBc7VendorTag = 0xD175u;    // data bits 27..12
-constexpr uint32_t kBc7FormatVersion = 1u;     // data bits 11..0: docs/BC7_FORMAT.md version
+constexpr uint32_t kBc7FormatVersion = 2u;     // data bits 11..0: docs/BC7_FORMAT.md version
 constexpr uint32_t kBc7PrivateHeader = (uint32_t)DXTLT_TF_BC7 | (((kBc7VendorTag << 12) | kBc7FormatVersion) << 4);
 
 int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* output, size_t output_len,
@@ -215,7 +215,7 @@ int32_t dds_transform_common(const uint8_t* input, size_t input_len, uint8_t* ou
     if (input_len < off + length)
         return DXTLT_FF_INPUT_TOO_SHORT;
     if (info.Format == BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
-        // no settings and nothing to estimate: version 1 of the format has one layout
+        // no settings and nothing to estimate: the format has one layout
         if (length % 16 != 0)
             return DXTLT_FF_INVALID_DATA_ALIGNMENT;
         std::memcpy(output, input, off);

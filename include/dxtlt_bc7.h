@@ -1,11 +1,11 @@
 /*
- * dxtlt_bc7.h -- BC7 granule-sorted field split, version 1: C ABI (libdxtlt_gfx950.so).
+ * dxtlt_bc7.h -- BC7 granule-sorted field split, version 2: C ABI (libdxtlt_gfx950.so).
  *
  * A FORMAT DEFINED BY THIS BUILD (docs/BC7_FORMAT.md).  The reference has no BC7 transform to be a drop-in for:
  * /root/reference/src/core/dxt-lossless-transform-bc7/src/lib.rs:1-13 holds two dead-code bit helpers, the BC7 API
  * crate is one line and `TransformBundle` has a placeholder for it.  What it does fix is
  * used: the bit fields of the eight modes (src/assets/research/dds-bc7-blocks.hexpat:286-654).  The entry points follow
- * the shape of the BC1-3 ones so that a future `transform_bc7_with_settings` could bind here; version 1 has no settings.
+ * the shape of the BC1-3 ones so that a future `transform_bc7_with_settings` could bind here; the format has no settings.
  * Parity: exact round trip and GPU == oracle/dxtlt_oracle_bc7.c only.
  *
  * Contract: len is a multiple of 16; output length == input length; buffers must not overlap; returns DXTLT_* status
@@ -28,7 +28,7 @@ extern "C" {
 int32_t dxtlt_transform_bc7(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len);
 int32_t dxtlt_untransform_bc7(const uint8_t *input_ptr, uint8_t *output_ptr, size_t len);
 
-/* Version 1 needs no device scratch: dxtlt_bc7_workspace_bytes returns 0 and the workspace arguments are ignored
+/* Since version 1 the transform needs no device scratch: dxtlt_bc7_workspace_bytes returns 0 and the workspace arguments are ignored
  * (NULL / 0 are fine); both are kept so that callers written against version 0 keep compiling. */
 size_t dxtlt_bc7_workspace_bytes(size_t len);
 int32_t dxtlt_transform_bc7_device(const void *d_input, void *d_output, size_t len, void *d_workspace,

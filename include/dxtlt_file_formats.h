@@ -105,7 +105,7 @@ int32_t dxtlt_dds_untransform(const uint8_t *input, size_t input_len, uint8_t *o
  * (handlers/dispatch.rs), which the three functions above reproduce (DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT).  With this
  * switch on (process-wide), BC7 DDS payloads go through this build's own format (dxtlt_bc7.h, docs/BC7_FORMAT.md) and
  * the header carries TransformFormat::Bc7 = 3 (embed/transform_format.rs:18) with the 28 data bits set to a vendor
- * tag (0xD175, bits 27..12) and this build's format version (1, bits 11..0) -- never all zeros, which is what
+ * tag (0xD175, bits 27..12) and this build's format version (2, bits 11..0) -- never all zeros, which is what
  * upstream's own first BC7 header version would be; dxtlt_dds_untransform then accepts exactly that word.  Only this
  * build can read such files back. */
 void dxtlt_file_formats_enable_bc7(bool enabled);

@@ -120,7 +120,7 @@ void oracle_bc23_simd_mt(int kind, int inverse, const uint8_t *in, uint8_t *out,
 void oracle_transform_range(int kind, int inverse, const uint8_t *in, uint8_t *out, size_t n_total, size_t first, size_t count,
                             int variant, int split_alpha, int split_colour);
 
-/* BC7 granule-sorted field split, version 1 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
+/* BC7 granule-sorted field split, version 2 -- a format defined by this build (docs/BC7_FORMAT.md); the reference has
  * no BC7 transform, so these are a definition, not a restatement: PARITY UNPINNED.  (dxtlt_oracle_bc7.c) */
 void oracle_transform_bc7(const uint8_t *in, uint8_t *out, size_t len);
 void oracle_untransform_bc7(const uint8_t *in, uint8_t *out, size_t len);

@@ -1,5 +1,5 @@
 /*
- * dxtlt_oracle_bc7.c -- CPU statement of the BC7 granule-sorted field split, version 1 (docs/BC7_FORMAT.md).
+ * dxtlt_oracle_bc7.c -- CPU statement of the BC7 granule-sorted field split, version 2 (docs/BC7_FORMAT.md).
  *
  * TEST INFRASTRUCTURE ONLY (see dxtlt_oracle.h).  PARITY UNPINNED: the reference has no BC7 transform
  * (/root/reference/src/core/dxt-lossless-transform-bc7/src/lib.rs:1-13); the format is defined by this build, and this
@@ -64,13 +64,33 @@ static inline void store128(uint8_t *p, u128 v)
 
 static inline u128 bits(u128 v, int pos, int len) { return len == 0 ? 0 : (v >> pos) & ((((u128)1) << len) - 1); }
 
-/* Block -> record (both 128 bits).  Record, LSB first: marker and header as they are; then the block's last fields
- * (p-bits and index bits); then the low (w - 4) bits of every endpoint field in block order; then the high 4 bits of
- * every endpoint field in block order. */
+/* Colour decorrelation of version 2, on the block's own bit layout: every red and every blue endpoint field becomes its
+ * difference to the green field of the same endpoint, modulo the field width (sign -1), or gets the green back (sign +1).
+ * Endpoint fields lie channel after channel: n reds, n greens, n blues (n = n_rgb / 3), then the alphas (untouched). */
+static u128 bc7_green(u128 b, int m, int sign)
+{
+    const Bc7Mode *d = &kModes[m];
+    const int e_start = m + 1 + d->hdr, n = d->n_rgb / 3, w = d->w_rgb;
+    const u128 mask = (((u128)1) << w) - 1;
+    for (int i = 0; i < n; ++i) {
+        const int pr = e_start + i * w, pg = e_start + (n + i) * w, pb = e_start + (2 * n + i) * w;
+        const u128 g = bits(b, pg, w);
+        const u128 r = sign < 0 ? (bits(b, pr, w) - g) & mask : (bits(b, pr, w) + g) & mask;
+        const u128 bl = sign < 0 ? (bits(b, pb, w) - g) & mask : (bits(b, pb, w) + g) & mask;
+        b = (b & ~(mask << pr)) | (r << pr);
+        b = (b & ~(mask << pb)) | (bl << pb);
+    }
+    return b;
+}
+
+/* Block -> record (both 128 bits).  First red and blue give up their green (bc7_green).  Record, LSB first: marker and
+ * header as they are; then the block's last fields (p-bits and index bits); then the low (w - 4) bits of every endpoint
+ * field in block order; then the high 4 bits of every endpoint field in block order. */
 static u128 bc7_record_of_block(u128 b, int m)
 {
     if (m == 8)
         return b;
+    b = bc7_green(b, m, -1);
     const Bc7Mode *d = &kModes[m];
     const int e_start = m + 1 + d->hdr;
     const int e_end = e_start + d->n_rgb * d->w_rgb + d->n_a * d->w_a;
@@ -121,7 +141,7 @@ static u128 bc7_block_of_record(u128 r, int m)
         hi_at += 4;
         pos += w;
     }
-    return b;
+    return bc7_green(b, m, +1);
 }
 
 /* One part of the transformed buffer: `n` blocks (a run of whole granules, or the last partial granule) whose streams

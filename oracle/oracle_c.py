@@ -227,7 +227,7 @@ def run_bc23_simd(kind: int, src: np.ndarray, dst: np.ndarray, inverse: bool, th
 
 
 def transform_bc7(data, inverse: bool = False) -> np.ndarray:
-    """BC7 granule-sorted field split v1 (docs/BC7_FORMAT.md) -- this build's own format, parity unpinned."""
+    """BC7 granule-sorted field split v2 (docs/BC7_FORMAT.md) -- this build's own format, parity unpinned."""
     a = np.ascontiguousarray(_as_u8(data))
     assert a.size % 16 == 0
     out = np.empty_like(a)

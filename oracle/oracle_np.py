@@ -181,7 +181,7 @@ def splitmix64(seed: int, first_qword: int, count: int) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------------------
-# BC7 granule-sorted field split, version 1 (docs/BC7_FORMAT.md) -- a format defined by this build; parity unpinned.
+# BC7 granule-sorted field split, version 2 (docs/BC7_FORMAT.md) -- a format defined by this build; parity unpinned.
 # Second, independently written statement: one block at a time as a Python integer, fields by name (slow: small cases).
 # ------------------------------------------------------------------------------------------------------------
 BC7_GRANULE = 1024
@@ -228,11 +228,25 @@ def _bc7_pack(pieces, start: int, value: int) -> int:
     return value
 
 
+def _bc7_green_out(fields, sign: int):
+    """Colour decorrelation of version 2: every red and blue endpoint field becomes its difference to the green field of
+    the same endpoint, modulo the field width (sign = -1), or gets it back (sign = +1).  Green and alpha stay."""
+    green = [v for n, v, w in fields if n == "G"]
+    out, seen = [], {"R": 0, "B": 0}
+    for n, v, w in fields:
+        if n in seen:
+            v = (v + sign * green[seen[n]]) & ((1 << w) - 1)
+            seen[n] += 1
+        out.append((n, v, w))
+    return out
+
+
 def bc7_record_of_block(b: int, m: int) -> int:
-    """marker | header | p-bits | index bits | low parts of the endpoints | high nibbles of the endpoints"""
+    """marker | header | p-bits | index bits | low parts of the endpoints | high nibbles of the endpoints, the endpoints
+    being R - G, G, B - G (modulo the field width) and A"""
     if m == 8:
         return b
-    f = _bc7_parse(b, m)
+    f = _bc7_green_out(_bc7_parse(b, m), -1)
     hdr = [(v, w) for n, v, w in f if n in _BC7_HEADER]
     pb = [(v, w) for n, v, w in f if n == "P"]
     idx = [(v, w) for n, v, w in f if n.startswith("idx")]
@@ -265,6 +279,9 @@ def bc7_block_of_record(r: int, m: int) -> int:
     highs = [take(4) for _ in widths["ep"]]
     assert pos == 128
     ep = [(h << (w - 4)) | l for h, l, w in zip(highs, lows, widths["ep"])]
+    # green back into red and blue (endpoint fields are in block order: all reds, all greens, all blues, alphas)
+    names = [name for name, count, width in layout if name in _BC7_ENDPOINTS for _ in range(count)]
+    ep = [v for _, v, _ in _bc7_green_out(list(zip(names, ep, widths["ep"])), +1)]
     # back into block order: header, endpoints, p-bits, indices
     b, at = 1 << m, m + 1
     for v, w in list(zip(hdr, widths["hdr"])) + list(zip(ep, widths["ep"])) + list(zip(pb, widths["pb"])) + list(zip(idx, widths["idx"])):

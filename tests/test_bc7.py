@@ -1,4 +1,4 @@
-"""BC7 granule-sorted field split, version 1 (docs/BC7_FORMAT.md) -- a format defined by this build; the reference has
+"""BC7 granule-sorted field split, version 2 (docs/BC7_FORMAT.md) -- a format defined by this build; the reference has
 no BC7 transform, so parity here means: the two CPU statements agree, the device header's compile-time
 field moves equal the oracle's, the GPU equals them bit for bit, and the round trip is exact.  Nothing in this file is
 checked against reference behaviour except the mode bit fields (hexpat:286-654), which the statements restate."""
@@ -42,12 +42,16 @@ def test_c_and_numpy_statements_agree(oracle, kind):
 
 def test_layout_by_hand(oracle):
     """Mode 6 by hand (hexpat:553-590): marker 0000001, R0 R1 G0 G1 B0 B1 A0 A1 (7 bits each), P0 P1, 63 index bits.
-    Record: marker | P0 P1 | index bits | low 3 bits of the eight endpoints | high nibbles of the eight endpoints."""
-    ep = [0x55, 0x2A, 0x7F, 0x00, 0x13, 0x64, 0x41, 0x3E]          # 7-bit values
+    Record: marker | P0 P1 | index bits | low 3 bits of the eight endpoints | high nibbles of the eight endpoints, the
+    endpoints of the record being R - G, G, B - G modulo 128 (version 2's colour decorrelation) and A."""
+    block_ep = [0x55, 0x2A, 0x7F, 0x00, 0x13, 0x64, 0x41, 0x3E]    # 7-bit values as the block holds them: R0 R1 G0 G1 B0 B1 A0 A1
+    r0, r1, g0, g1, b0, b1, a0, a1 = block_ep
+    ep = [(r0 - g0) & 127, (r1 - g1) & 127, g0, g1, (b0 - g0) & 127, (b1 - g1) & 127, a0, a1]   # as the record holds them
+    assert ep == [0x56, 0x2A, 0x7F, 0x00, 0x14, 0x64, 0x41, 0x3E]
     p0, p1 = 1, 0
     idx = 0x5A5A_F0F0_1234_5678 & ((1 << 63) - 1)
     b, at = 1 << 6, 7
-    for e in ep:
+    for e in block_ep:
         b |= e << at
         at += 7
     b |= p0 << at | p1 << (at + 1)

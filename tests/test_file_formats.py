@@ -304,7 +304,7 @@ def test_dds_auto_transform(lib, oracle):
         assert np.array_equal(r, d)
 
 
-BC7_PRIVATE_HEADER = 3 | ((0xD175 << 12 | 1) << 4)   # TransformFormat::Bc7, vendor tag 0xD175, format version 1
+BC7_PRIVATE_HEADER = 3 | ((0xD175 << 12 | 2) << 4)   # TransformFormat::Bc7, vendor tag 0xD175, format version 2
 
 
 def test_bc7_switch_is_off_by_default_and_needs_no_device(lib):
@@ -319,7 +319,8 @@ def test_bc7_switch_is_off_by_default_and_needs_no_device(lib):
     try:
         # this build's BC7 files carry a vendor tag and a format version in the data bits; all-zero data bits are
         # upstream's to assign and are refused, as is any other tag or version
-        for word in (3, 3 | (1 << 6), BC7_PRIVATE_HEADER ^ (1 << 4), BC7_PRIVATE_HEADER ^ (1 << 20)):
+        version1 = 3 | ((0xD175 << 12 | 1) << 4)   # files of the previous format version: no green decorrelation, refused
+        for word in (3, 3 | (1 << 6), version1, BC7_PRIVATE_HEADER ^ (1 << 4), BC7_PRIVATE_HEADER ^ (1 << 20)):
             bad = np.concatenate([np.frombuffer(struct.pack("<I", word), dtype=np.uint8), d[4:]])
             assert lib.dxtlt_dds_untransform(bad.ctypes.data, bad.size, out.ctypes.data, out.size) == 5, hex(word)
     finally:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[3]: BC7 granule-sorted field split, version 1 (this build's own format, docs/BC7_FORMAT.md) on a 4 GiB synthetic
+"""BASELINE.json configs[3]: BC7 granule-sorted field split, version 2 (this build's own format, docs/BC7_FORMAT.md) on a 4 GiB synthetic
 mode-mixed buffer, one MI355X.  Prints fwd / inv time and the fraction of the HBM peak on ALGORITHMIC bytes (2*len)."""
 import json
 import os
@@ -53,7 +53,7 @@ fwd = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
 inv = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
 nbytes = x.numel()
 print(json.dumps({
-    "workload": f"BC7 granule-sorted field split v1, {gib:g} GiB, modes {dist}", "roundtrip_exact": bool(torch.equal(z, x)),
+    "workload": f"BC7 granule-sorted field split v2, {gib:g} GiB, modes {dist}", "roundtrip_exact": bool(torch.equal(z, x)),
     "fwd_ms": round(fwd, 3), "inv_ms": round(inv, 3),
     "fwd_GiBps": round(nbytes / fwd / 1e-3 / 2**30, 1), "inv_GiBps": round(nbytes / inv / 1e-3 / 2**30, 1),
     "fwd_frac_of_8TBps_on_2len": round(2 * nbytes / (fwd * 1e-3) / 8e12, 4),

@@ -77,6 +77,53 @@ def order_hilo(m, f):                       # version 1
     return hdr + pb + idx + [lo(x, x[1] - 4) for x in ep if x[1] > 4] + [hi(x, 4) for x in ep]
 
 
+def green_out(f, how="sub"):
+    """colour decorrelation candidates on the endpoint fields of one block: 'sub' (version 2) = red and blue as differences
+    to the green of the same endpoint, modulo the field width; 'ycocg' = reversible YCoCg-R modulo the field width;
+    'delta' = the second endpoint of every subset as a difference to the first"""
+    ch = {c: [list(x) for x in f[c]] for c in "RGBA" if c in f}
+    n, w = len(ch["R"]), ch["R"][0][1]
+    M = (1 << w) - 1
+    if how == "delta":
+        for c in ch:
+            wc = ch[c][0][1]
+            for k in range(0, n, 2):
+                ch[c][k + 1][0] = (ch[c][k + 1][0] - ch[c][k][0]) & ((1 << wc) - 1)
+    for i in range(n):
+        r, g, b = ch["R"][i][0], ch["G"][i][0], ch["B"][i][0]
+        if how == "sub":
+            ch["R"][i][0], ch["B"][i][0] = (r - g) & M, (b - g) & M
+        elif how == "ycocg":
+            co = (r - b) & M
+            t = (b + (co >> 1)) & M
+            cg = (g - t) & M
+            ch["R"][i][0], ch["G"][i][0], ch["B"][i][0] = co, (t + (cg >> 1)) & M, cg
+    return [tuple(x) for c in "RGBA" if c in ch for x in ch[c]]
+
+
+def order_v2(m, f):                         # version 2: version 1's record over green-decorrelated endpoints
+    hdr, idx, ep, pb = split(m, f)
+    ep = green_out(f, "sub")
+    return hdr + pb + idx + [lo(x, x[1] - 4) for x in ep if x[1] > 4] + [hi(x, 4) for x in ep]
+
+
+def order_hilo_with(how):
+    def order(m, f):
+        hdr, idx, ep, pb = split(m, f)
+        ep = green_out(f, how)
+        return hdr + pb + idx + [lo(x, x[1] - 4) for x in ep if x[1] > 4] + [hi(x, 4) for x in ep]
+    return order
+
+
+def order_v2_high_nibbles_only(m, f):       # green taken out of the high nibbles only (cheaper on the device)
+    hdr, idx, ep, pb = split(m, f)
+    ch = {c: list(f[c]) for c in "RGBA" if c in f}
+    highs = {c: [hi(x, 4)[0] for x in ch[c]] for c in ch}
+    highs["R"] = [(a - g) & 15 for a, g in zip(highs["R"], highs["G"])]
+    highs["B"] = [(a - g) & 15 for a, g in zip(highs["B"], highs["G"])]
+    return hdr + pb + idx + [lo(x, x[1] - 4) for x in ep if x[1] > 4] + [(v, 4) for c in "RGBA" if c in highs for v in highs[c]]
+
+
 def order_hilo_by_channel(m, f):
     hdr, idx, ep, pb = split(m, f)
     ch = [c for c in "RGBA" if c in f]
@@ -163,16 +210,20 @@ def main():
             print(f"  {label:64s} " + "  ".join(f"{k} {100 * (v / base[k] - 1):+5.1f}%" for k, v in r.items()), flush=True)
 
         row("version 0 (bytes by mode, global head / tail streams)", version0(c))
-        v1 = oracle_c.transform_bc7(c[0])
-        assert bytes(v1) == bytes(assemble(c, order_hilo, v1_slots, 1024)), "lab statement of version 1 == the oracle"
-        row("VERSION 1 = hi/lo records, slots 8+2+1x5, granule 1024 (oracle)", v1)
-        row("  same records, global per-mode streams", assemble(c, order_hilo, v1_slots, placement="permode"))
+        row("version 1 = hi/lo records, slots 8+2+1x5, granule 1024", assemble(c, order_hilo, v1_slots, 1024))
+        v2 = oracle_c.transform_bc7(c[0])
+        assert bytes(v2) == bytes(assemble(c, order_v2, v1_slots, 1024)), "lab statement of version 2 == the oracle"
+        row("VERSION 2 = version 1 + red and blue minus green (oracle)", v2)
+        row("  same records, global per-mode streams", assemble(c, order_v2, v1_slots, placement="permode"))
         for T in (256, 2048, 4096):
-            row(f"  same records, granule {T}", assemble(c, order_hilo, v1_slots, T))
-        row("  no hi/lo split for endpoints of <= 5 bits", assemble(c, order_hilo_wide_only, v1_slots))
-        row("  high nibbles grouped by channel", assemble(c, order_hilo_by_channel, v1_slots))
+            row(f"  same records, granule {T}", assemble(c, order_v2, v1_slots, T))
+        row("  green out of the high nibbles only", assemble(c, order_v2_high_nibbles_only, v1_slots))
+        row("  YCoCg-R modulo the field width instead", assemble(c, order_hilo_with("ycocg"), v1_slots))
+        row("  second endpoint of a subset minus the first instead", assemble(c, order_hilo_with("delta"), v1_slots))
+        row("  version 1 records: no hi/lo split for endpoints of <= 5 bits", assemble(c, order_hilo_wide_only, v1_slots))
+        row("  version 1 records: high nibbles grouped by channel", assemble(c, order_hilo_by_channel, v1_slots))
         for slots in ((8, 4, 2, 1), (8, 4, 1, 1, 1), (4, 4, 4, 2, 1), (4, 4, 2, 2, 1, 1, 1), (15,)):
-            row(f"  hi/lo records, slots {slots}", assemble(c, order_hilo, slots))
+            row(f"  version 1 records, slots {slots}", assemble(c, order_hilo, slots))
         row("fields in block order, slots 8+2+1x5", assemble(c, order_natural, v1_slots))
         row("header, p-bits, indices, endpoints whole, slots 8+2+1x5", assemble(c, order_hdr_p_idx_ep, v1_slots))
 
