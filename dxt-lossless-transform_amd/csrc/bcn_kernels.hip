@@ -1459,10 +1459,15 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         shh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, shh.d);
         // every window starts on a 64-byte sector: no line needs to meet its other half in one L2 -- identity tile order
         // and, unless experiment switch 0x800 asks for plain nt, the write-through streaming stores of the aligned tiles
-        shh.xcd_remap = remap_override >= 0 ? remap_override : 0;
         shh.line_policy = (force_bits & 0x800) ? 1 : 3;
         const int per_vec = 16 / fmt_block(fmt);
         shh.halo_vecs = (halo_blocks + per_vec - 1) / per_vec;
+        // The halo is read again by the next tile.  In the identity order that tile runs on another XCD: the re-read comes
+        // from HBM, and a halo of h vectors costs h * 16 / 4096 of extra traffic -- up to 25 % for BC3's one-byte streams
+        // (0.80 of peak falls to 0.72).  In the XCD-contiguous order the neighbour's L2 still holds those lines and the rate
+        // is 0.765 whatever the halo -- but that order itself costs 0.035.  Measured crossover (profiles/r02_b): 24 vectors.
+        const bool big_halo = shh.halo_vecs * 16 * 11 > 4096;
+        shh.xcd_remap = remap_override >= 0 ? remap_override : (big_halo ? 1 : 0);
     }
     if (num_tiles > 0) {
         if (use_halo)
