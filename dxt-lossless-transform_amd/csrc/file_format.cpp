@@ -5,6 +5,9 @@
 
 #include <atomic>
 #include <cstring>
+#include <vector>
+
+#include "../../include/dxtlt_gfx950.h"
 
 #include "host_common.h"
 #include "../../include/dxtlt_bc7.h"
@@ -386,6 +389,101 @@ int32_t dxtlt_dds_untransform(const uint8_t* input, size_t input_len, uint8_t* o
     if (input_len > off + length)
         std::memcpy(output + off + length, input + off + length, input_len - off - length);
     return DXTLT_FF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Many DDS files per call: the file-after-file loop of the reference's CLI (tools/dxt-lossless-transform-cli/src/
+// commands/transform/mod.rs:154-199) with ONE upload / launch / download pipeline under it (dxtlt_transform_batch_host)
+// instead of a PCIe round trip per file.  Every item is checked exactly like the single-file calls and gets their
+// status; items that pass have their header and trailing bytes copied, their payloads go through the batch together,
+// and their TransformHeader (or 'DDS ' magic) is written once the batch has succeeded.
+// ---------------------------------------------------------------------------------------------------------------
+size_t dxtlt_dds_transform_batch(DxtltDdsBatchItem* items, size_t count, bool inverse)
+{
+    if (items == nullptr)
+        return count;
+    struct Pending {
+        size_t item;
+        uint32_t first_word;   // what goes into bytes 0..3 of the output once the payload is done
+    };
+    std::vector<DxtltBatchItem> batch;
+    std::vector<Pending> pending;
+    size_t failed = 0;
+    for (size_t i = 0; i < count; ++i) {
+        DxtltDdsBatchItem& it = items[i];
+        auto reject = [&](int32_t st) {
+            it.status = st;
+            ++failed;
+        };
+        if (it.input == nullptr || it.output == nullptr) { reject(DXTLT_FF_NULL_POINTER); continue; }
+        if (inverse && it.input_len < DXTLT_TRANSFORM_HEADER_SIZE) { reject(DXTLT_FF_INPUT_TOO_SHORT); continue; }
+        if (it.output_len < it.input_len) { reject(DXTLT_FF_OUTPUT_TOO_SMALL); continue; }
+        DdsInfo info;
+        if ((!inverse && !likely_dds(it.input, it.input_len)) || !parse_ignore_magic(it.input, it.input_len, &info)) {
+            reject(DXTLT_FF_INVALID_INPUT_HEADER);
+            continue;
+        }
+        const size_t off = info.DataOffset, length = info.DataLength;
+        if (it.input_len < off + length) { reject(DXTLT_FF_INPUT_TOO_SHORT); continue; }
+        int bcn;
+        uint8_t mode = it.decorrelation_mode;
+        bool sa = it.split_alpha_endpoints, sc = it.split_colour_endpoints;
+        uint32_t first_word;
+        if (!inverse) {
+            bcn = dds_to_bcn(info.Format);
+            if (bcn == 0) {   // BC7 (opt-in, this build's own format) and everything else: one at a time, as the single call does it
+                it.status = dxtlt_dds_transform(it.input, it.input_len, it.output, it.output_len, mode, sa, sc);
+                failed += it.status != DXTLT_FF_OK;
+                continue;
+            }
+            if (length % (bcn == 1 ? 8 : 16) != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
+            if (mode > 3) { reject(DXTLT_FF_CORRUPTED_EMBEDDED_DATA); continue; }
+            if (bcn != 3)
+                sa = false;
+            first_word = dxtlt_transform_header_pack(bcn - 1, mode, sa, sc);
+        } else {
+            const uint32_t header = rd32(it.input);
+            if ((header & 0xF) > DXTLT_TF_BC3) {   // BC7 when enabled, unknown formats: the single call's answer
+                it.status = dxtlt_dds_untransform(it.input, it.input_len, it.output, it.output_len);
+                failed += it.status != DXTLT_FF_OK;
+                continue;
+            }
+            int32_t tf = 0;
+            const int32_t rc = dxtlt_transform_header_unpack(header, &tf, &mode, &sa, &sc);
+            if (rc != DXTLT_FF_OK) { reject(rc); continue; }
+            bcn = tf + 1;
+            if (length % (bcn == 1 ? 8 : 16) != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
+            first_word = kDdsMagic;
+        }
+        // everything around the payload; bytes 0..3 stay the input's until the payload has been transformed
+        std::memcpy(it.output, it.input, off);
+        if (it.input_len > off + length)
+            std::memcpy(it.output + off + length, it.input + off + length, it.input_len - off - length);
+        it.status = DXTLT_FF_OK;
+        pending.push_back({i, first_word});
+        if (length != 0) {
+            DxtltBatchItem b{};
+            b.d_input = it.input + off;
+            b.d_output = it.output + off;
+            b.len = length;
+            b.format = (uint8_t)bcn;
+            b.inverse = inverse ? 1 : 0;
+            b.decorrelation_mode = mode;
+            b.split_alpha_endpoints = sa ? 1 : 0;
+            b.split_colour_endpoints = sc ? 1 : 0;
+            batch.push_back(b);
+        }
+    }
+    const int32_t st = batch.empty() ? dxtlt_host::kOk : dxtlt_transform_batch_host(batch.data(), batch.size());
+    for (const Pending& p : pending) {
+        if (st == dxtlt_host::kOk) {
+            wr32(items[p.item].output, p.first_word);
+        } else {
+            items[p.item].status = map_device_status(st);
+            ++failed;
+        }
+    }
+    return failed;
 }
 
 }  // extern "C"

@@ -110,6 +110,27 @@ int32_t dxtlt_dds_untransform(const uint8_t *input, size_t input_len, uint8_t *o
  * build can read such files back. */
 void dxtlt_file_formats_enable_bc7(bool enabled);
 
+/* ADDITIVE: many DDS files per call -- the file-after-file loop of the reference's CLI
+ * (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:154-199) over ONE pinned upload / launch / download
+ * pipeline (dxtlt_transform_batch_host, dxtlt_gfx950.h) instead of a PCIe round trip per file.  Every item is checked
+ * exactly like dxtlt_dds_transform / dxtlt_dds_untransform would check it and receives that call's status in `status`;
+ * the items that pass are transformed together.  inverse = false: `decorrelation_mode` / `split_*` are the settings to
+ * apply (as in dxtlt_dds_transform); inverse = true: the settings come from each file's TransformHeader and those fields
+ * are ignored.  BC7 files (with the switch above on) are handled one at a time inside the call.  Returns the number of
+ * items whose status is not DXTLT_FF_OK (0 = all done).  If the shared device pipeline fails, every item that was in it
+ * gets DXTLT_FF_TRANSFORM_FAILED and its output is unspecified. */
+typedef struct DxtltDdsBatchItem {
+    const uint8_t *input;
+    size_t input_len;
+    uint8_t *output;
+    size_t output_len;               /* >= input_len */
+    uint8_t decorrelation_mode;      /* core numbering; forward only */
+    bool split_alpha_endpoints;      /* BC3, forward only */
+    bool split_colour_endpoints;     /* forward only */
+    int32_t status;                  /* out: DXTLT_FF_* */
+} DxtltDdsBatchItem;
+size_t dxtlt_dds_transform_batch(DxtltDdsBatchItem *items, size_t count, bool inverse);
+
 #ifdef __cplusplus
 }
 #endif

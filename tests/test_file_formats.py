@@ -346,3 +346,106 @@ def test_bc7_dds_roundtrip_when_enabled(lib, oracle):
         assert np.array_equal(r, d)
     finally:
         lib.dxtlt_file_formats_enable_bc7(False)
+
+
+# ---- many DDS files per call (additive): dxtlt_dds_transform_batch ---------------------------------------------------
+class DdsBatchItem(C.Structure):
+    _fields_ = [("input", C.c_void_p), ("input_len", C.c_size_t), ("output", C.c_void_p), ("output_len", C.c_size_t),
+                ("decorrelation_mode", C.c_uint8), ("split_alpha_endpoints", C.c_bool), ("split_colour_endpoints", C.c_bool),
+                ("status", C.c_int32)]
+
+
+def bind_batch(lib):
+    lib.dxtlt_dds_transform_batch.argtypes = [C.POINTER(DdsBatchItem), C.c_size_t, C.c_bool]
+    lib.dxtlt_dds_transform_batch.restype = C.c_size_t
+    return lib.dxtlt_dds_transform_batch
+
+
+def make_items(files, outs, settings):
+    items = (DdsBatchItem * len(files))()
+    for it, f, o, (m, a, c) in zip(items, files, outs, settings):
+        it.input, it.input_len = f.ctypes.data if f is not None else None, f.size if f is not None else 0
+        it.output, it.output_len = o.ctypes.data, o.size
+        it.decorrelation_mode, it.split_alpha_endpoints, it.split_colour_endpoints = m, a, c
+        it.status = -1
+    return items
+
+
+def test_dds_batch_rejects_item_by_item_without_a_device(lib):
+    """Items that fail validation get the single call's status and never reach the device."""
+    batch = bind_batch(lib)
+    good = dds_file("bc1")
+    not_dds = np.zeros(200, dtype=np.uint8)
+    short_payload = good[:1000].copy()                              # header says 32 KiB of blocks, 872 bytes follow
+    unknown = np.frombuffer(bytes(legacy_header(b"ATI2", 8, 8)) + bytes(64), dtype=np.uint8)      # BC5: no transform for it
+    files = [None, not_dds, short_payload, unknown, good]
+    outs = [np.zeros(max(64, 0 if f is None else f.size), dtype=np.uint8) for f in files]
+    outs[4] = np.zeros(10, dtype=np.uint8)                          # output too small
+    items = make_items(files, outs, [(1, False, True)] * len(files))
+    assert batch(items, len(files), False) == len(files)
+    assert [it.status for it in items] == [9, 2, 3, 4, 1]           # NULL, invalid header, too short, unknown format, output too small
+    assert batch(None, 3, False) == 3
+    assert batch(items, 0, False) == 0
+
+
+@pytest.mark.gpu
+def test_dds_batch_equals_one_call_per_file(lib, oracle):
+    batch = bind_batch(lib)
+    rng = np.random.default_rng(0xDD5B)
+    files, settings = [], []
+    for k in range(40):
+        fmt = ("bc1", "bc2", "bc3")[k % 3]
+        if k % 5 == 0:
+            f = dds_file(fmt)                                       # the reference's textures
+        else:                                                       # synthetic: w x h blocks, some with mip chains and trailing bytes
+            w, h, mips = int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(0, 6))
+            hd = legacy_header({"bc1": b"DXT1", "bc2": b"DXT3", "bc3": b"DXT5"}[fmt], w, h, mips)
+            probe = np.frombuffer(bytes(hd), dtype=np.uint8)
+            length = lib.parse_dds(probe.ctypes.data, probe.size).DataLength
+            f = np.concatenate([probe, rng.integers(0, 256, length + int(rng.integers(0, 9)), dtype=np.uint8)])
+        files.append(np.ascontiguousarray(f))
+        settings.append((int(rng.integers(0, 4)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    files.insert(7, np.zeros(300, dtype=np.uint8))                  # one bad apple in the middle: the rest must not care
+    settings.insert(7, (1, False, True))
+    outs = [np.zeros_like(f) for f in files]
+    items = make_items(files, outs, settings)
+    assert batch(items, len(files), False) == 1
+    for i, (f, o, (m, a, c)) in enumerate(zip(files, outs, settings)):
+        if i == 7:
+            assert items[i].status == 2                             # DXTLT_FF_INVALID_INPUT_HEADER
+            continue
+        assert items[i].status == 0
+        want = np.zeros_like(f)
+        assert lib.dxtlt_dds_transform(f.ctypes.data, f.size, want.ctypes.data, want.size, m, a, c) == 0
+        assert np.array_equal(o, want), i
+    # and back: settings from every file's own TransformHeader
+    backs = [np.zeros_like(f) for f in files]
+    inv = make_items(outs, backs, [(0, False, False)] * len(files))
+    failed = batch(inv, len(files), True)
+    # the all-zero "file" reads as TransformFormat::Bc1 with an empty payload: whatever the single call says, the batch says
+    single = np.zeros_like(outs[7])
+    assert inv[7].status == lib.dxtlt_dds_untransform(outs[7].ctypes.data, outs[7].size, single.ctypes.data, single.size)
+    assert failed == (1 if inv[7].status else 0) and np.array_equal(backs[7], single)
+    for i, (f, b) in enumerate(zip(files, backs)):
+        if i != 7:
+            assert inv[i].status == 0 and np.array_equal(b, f), i
+
+
+@pytest.mark.gpu
+def test_dds_batch_handles_bc7_files_when_enabled(lib, oracle):
+    batch = bind_batch(lib)
+    lib.dxtlt_file_formats_enable_bc7.argtypes, lib.dxtlt_file_formats_enable_bc7.restype = [C.c_bool], None
+    files = [dds_file("bc7"), dds_file("bc1"), dds_file("bc7")]
+    outs = [np.zeros_like(f) for f in files]
+    items = make_items(files, outs, [(1, False, True)] * 3)
+    assert batch(items, 3, False) == 2 and [it.status for it in items] == [4, 0, 4]      # refused as upstream refuses them
+    lib.dxtlt_file_formats_enable_bc7(True)
+    try:
+        items = make_items(files, outs, [(1, False, True)] * 3)
+        assert batch(items, 3, False) == 0
+        assert struct.unpack("<I", outs[0][:4].tobytes())[0] == BC7_PRIVATE_HEADER
+        backs = [np.zeros_like(f) for f in files]
+        assert batch(make_items(outs, backs, [(0, False, False)] * 3), 3, True) == 0
+        assert all(np.array_equal(b, f) for b, f in zip(backs, files))
+    finally:
+        lib.dxtlt_file_formats_enable_bc7(False)
