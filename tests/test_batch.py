@@ -122,3 +122,71 @@ def test_host_batch_equals_oracle_item_by_item(pkg, oracle):
     y = np.zeros_like(x)
     batch.transform_batch_host([("bc1", False, x, y, pkg.Bc1TransformSettings())])
     assert np.array_equal(y, oracle.transform("bc1", x, 1, True))
+
+
+@pytest.mark.gpu
+def test_concurrent_host_batches_and_parallel_auto_transforms(pkg, oracle):
+    """Four threads at once: two host batches (each with its own pinned arenas, copy threads and streams), one auto
+    transform with the estimator on four threads, one plain host call -- every result equal to the oracle's."""
+    import threading
+
+    from dxt_lossless_transform_amd import batch
+    from oracle import oracle_auto
+    import cabi
+
+    lib = cabi.bind(C.CDLL(pkg._lib.lib_path()))
+    errors = []
+
+    def guarded(fn):
+        def run():
+            try:
+                fn()
+            except BaseException as e:  # noqa: BLE001
+                errors.append(repr(e))
+        return run
+
+    def host_batch(seed):
+        rng = np.random.default_rng(seed)
+        items, expect = [], []
+        for k in range(120):
+            fmt = FORMATS[k % 3]
+            blocks = int(rng.integers(0, 40_000))
+            v, sa, sc = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            x = oracle.fill_splitmix64(blocks * pkg.BLOCK_BYTES[fmt], seed + k)
+            y = np.zeros_like(x)
+            items.append((fmt, False, x, y, settings_for(pkg, fmt, v, sa, sc)))
+            expect.append((oracle.transform(fmt, x, v, bool(sc), bool(sa)), y))
+        for _ in range(3):
+            batch.transform_batch_host(items)
+        for k, (want, y) in enumerate(expect):
+            assert np.array_equal(y, want), (seed, k)
+
+    def auto_parallel():
+        x = np.tile(np.fromfile(__import__("os").path.join(__import__("helpers").GOLDEN, "r2-256-bc3.payload.bin"), dtype=np.uint8), 8)
+        est, py_est = cabi.make_estimator("zlib")
+        want_choice, want_out, _ = oracle_auto.transform_auto("bc3", x, lambda b: py_est(bytes(b)), True)
+        out = cabi.CoreSettings3()
+        for _ in range(3):
+            y = np.zeros_like(x)
+            r = lib.dltbc3core_transform_auto(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est), cabi.AutoSettings(True), C.byref(out))
+            assert r.ErrorCode == 0 and np.array_equal(y, want_out)
+
+    def plain_host_calls():
+        x = oracle.fill_splitmix64(8 * 300_001, 99)
+        want = oracle.transform("bc1", x, 1, True)
+        for _ in range(6):
+            y = np.zeros_like(x)
+            pkg.transform_bc1_with_settings(x, y)
+            assert np.array_equal(y, want)
+
+    pkg.set_auto_estimator_threads(4)
+    try:
+        threads = [threading.Thread(target=guarded(f)) for f in (lambda: host_batch(0xBA7C0), lambda: host_batch(0xBA7C1), auto_parallel,
+                                                                 plain_host_calls)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        pkg.set_auto_estimator_threads(1)
+    assert not errors, errors
