@@ -1,11 +1,22 @@
 """Many device-resident buffers in one call (dxtlt_transform_batch_device, include/dxtlt_gfx950.h): one kernel launch per
-(format, direction) present in the batch, enqueued on torch's current stream."""
+(format, direction) present in the batch, enqueued on torch's current stream.  fmt "bc7" (this build's own format,
+docs/BC7_FORMAT.md; settings ignored, pass None) rides along: its granules in one launch, its tail parts in another."""
 from __future__ import annotations
 
 import ctypes as C
 from typing import Sequence, Tuple
 
 from . import _lib
+
+
+def _item_fields(fmt, settings):
+    """(format id, block bytes, mode, split_alpha, split_colour) of one batch item"""
+    from . import _FMT_ID, BLOCK_BYTES, _settings_tuple
+
+    if fmt == "bc7":
+        return 7, 16, 0, False, False
+    mode, sa, sc = _settings_tuple(fmt, settings)
+    return _FMT_ID[fmt], BLOCK_BYTES[fmt], mode, sa, sc
 
 
 class DxtltBatchItem(C.Structure):
@@ -18,7 +29,7 @@ def transform_batch(items: Sequence[Tuple[str, bool, object, object, object]]) -
     """items: (fmt, inverse, input tensor, output tensor, settings) with CUDA uint8 tensors on one device."""
     import torch
 
-    from . import (_FMT_ID, BLOCK_BYTES, DeviceError, InvalidLength, OutputBufferTooSmall, _Buf, _settings_tuple)
+    from . import DeviceError, InvalidLength, OutputBufferTooSmall, _Buf
 
     if not items:
         return
@@ -31,13 +42,13 @@ def transform_batch(items: Sequence[Tuple[str, bool, object, object, object]]) -
         device = s.device if device is None else device
         if s.device != device or d.device != device:
             raise ValueError("all tensors of a batch must live on one device")
-        if s.nbytes % BLOCK_BYTES[fmt] != 0:
+        fid, block, mode, sa, sc = _item_fields(fmt, settings)
+        if s.nbytes % block != 0:
             raise InvalidLength(s.nbytes)
         if d.nbytes < s.nbytes:
             raise OutputBufferTooSmall(s.nbytes, d.nbytes)
-        mode, sa, sc = _settings_tuple(fmt, settings)
         arr[k].d_input, arr[k].d_output, arr[k].len = s.ptr, d.ptr, s.nbytes
-        arr[k].format, arr[k].inverse, arr[k].decorrelation_mode = _FMT_ID[fmt], int(bool(inverse)), mode
+        arr[k].format, arr[k].inverse, arr[k].decorrelation_mode = fid, int(bool(inverse)), mode
         arr[k].split_alpha_endpoints, arr[k].split_colour_endpoints = int(bool(sa)), int(bool(sc))
     l = _lib.load()
     l.dxtlt_transform_batch_device.argtypes = [C.POINTER(DxtltBatchItem), C.c_size_t, C.c_void_p]
@@ -50,7 +61,7 @@ def transform_batch(items: Sequence[Tuple[str, bool, object, object, object]]) -
 
 def prepare_batch_host(items: Sequence[Tuple[str, bool, object, object, object]]):
     """The C item array of a host batch (and the buffers it points into), for callers that run the same batch again."""
-    from . import (_FMT_ID, BLOCK_BYTES, InvalidLength, OutputBufferTooSmall, _Buf, _settings_tuple)
+    from . import InvalidLength, OutputBufferTooSmall, _Buf
 
     arr = (DxtltBatchItem * len(items))()
     keep = []
@@ -58,13 +69,13 @@ def prepare_batch_host(items: Sequence[Tuple[str, bool, object, object, object]]
         s, d = _Buf(src, False), _Buf(dst, True)
         if s.device is not None or d.device is not None:
             raise TypeError("transform_batch_host takes host buffers")
-        if s.nbytes % BLOCK_BYTES[fmt] != 0:
+        fid, block, mode, sa, sc = _item_fields(fmt, settings)
+        if s.nbytes % block != 0:
             raise InvalidLength(s.nbytes)
         if d.nbytes < s.nbytes:
             raise OutputBufferTooSmall(s.nbytes, d.nbytes)
-        mode, sa, sc = _settings_tuple(fmt, settings)
         arr[k].d_input, arr[k].d_output, arr[k].len = s.ptr, d.ptr, s.nbytes
-        arr[k].format, arr[k].inverse, arr[k].decorrelation_mode = _FMT_ID[fmt], int(bool(inverse)), mode
+        arr[k].format, arr[k].inverse, arr[k].decorrelation_mode = fid, int(bool(inverse)), mode
         arr[k].split_alpha_endpoints, arr[k].split_colour_endpoints = int(bool(sa)), int(bool(sc))
         keep.append((s, d))
     return arr, keep

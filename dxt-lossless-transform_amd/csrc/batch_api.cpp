@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/dxtlt_gfx950.h"
+#include "bc7_launch.h"
 #include "bcn_launch.h"
 #include "host_common.h"
 
@@ -112,16 +113,70 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
     // validate everything first: a batch is enqueued whole or not at all
     for (size_t i = 0; i < count; ++i) {
         const DxtltBatchItem& it = items[i];
-        if (it.format < 1 || it.format > 3)
-            return fail(kInvalidArgument, "batch item: format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
+        if ((it.format < 1 || it.format > 3) && it.format != 7)
+            return fail(kInvalidArgument, "batch item: format must be 1 (BC1), 2 (BC2), 3 (BC3) or 7 (BC7, this build's own format)");
         if (it.len % (it.format == 1 ? 8u : 16u) != 0)
             return fail(kInvalidLength, "batch item: len is not a multiple of the block size");
-        if (it.decorrelation_mode > 3)
+        if (it.decorrelation_mode > 3 && it.format != 7)
             return fail(kInvalidArgument, "batch item: decorrelation_mode must be 0..3");
         if (it.len > 0 && (it.d_input == nullptr || it.d_output == nullptr))
             return fail(kInvalidArgument, "batch item: NULL device buffer with len > 0");
     }
     hipStream_t user = static_cast<hipStream_t>(hip_stream);
+
+    // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one
+    for (int inverse = 0; inverse < 2; ++inverse) {
+        std::vector<dxtlt::bc7::BatchEntry> entries, tails;
+        uint64_t wgs = 0;
+        for (size_t i = 0; i < count; ++i) {
+            const DxtltBatchItem& it = items[i];
+            if (it.format != 7 || it.len == 0 || (it.inverse != 0) != (inverse != 0))
+                continue;
+            const uint64_t blocks = it.len / 16, tail = blocks % 1024, main = blocks - tail;
+            const uint8_t* src = static_cast<const uint8_t*>(it.d_input);
+            uint8_t* dst = static_cast<uint8_t*>(it.d_output);
+            if (main != 0) {
+                entries.push_back({src, dst, main, (uint32_t)wgs, 0});
+                wgs += main / 1024;
+            }
+            if (tail != 0)
+                tails.push_back({src + main * 16, dst + main * 16, 0, 0, (uint32_t)tail});
+            if (wgs > 0x7FFFFFFFull)
+                return fail(kInvalidArgument, "batch too large for one launch (32 TiB or more of BC7 in one direction)");
+        }
+        if (entries.empty() && tails.empty())
+            continue;
+        const size_t coarse_n = ((size_t)wgs + 63) / 64;
+        const size_t entry_bytes = entries.size() * sizeof(dxtlt::bc7::BatchEntry), tail_bytes = tails.size() * sizeof(dxtlt::bc7::BatchEntry);
+        const size_t bytes = entry_bytes + tail_bytes + coarse_n * sizeof(uint32_t);
+        TableSlot* slot = nullptr;
+        hipError_t e = g_ring.acquire(bytes, &slot);
+        if (e != hipSuccess)
+            return fail(kDevice, "batch table staging", e);
+        uint8_t* h = static_cast<uint8_t*>(slot->host);
+        if (entry_bytes) std::memcpy(h, entries.data(), entry_bytes);
+        if (tail_bytes) std::memcpy(h + entry_bytes, tails.data(), tail_bytes);
+        uint32_t* coarse = reinterpret_cast<uint32_t*>(h + entry_bytes + tail_bytes);
+        size_t cur = 0;
+        for (size_t k = 0; k < coarse_n; ++k) {
+            while (cur + 1 < entries.size() && entries[cur + 1].first_wg <= (uint32_t)(k * 64))
+                ++cur;
+            coarse[k] = (uint32_t)cur;
+        }
+        const uint8_t* d = static_cast<const uint8_t*>(slot->dev);
+        e = hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, user);
+        if (e == hipSuccess)
+            e = dxtlt::bc7::launch_batch(inverse != 0, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d),
+                                         reinterpret_cast<const uint32_t*>(d + entry_bytes + tail_bytes), (uint32_t)entries.size(),
+                                         (uint32_t)wgs, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d + entry_bytes),
+                                         (uint32_t)tails.size(), user);
+        hipError_t ev = hipEventRecord(slot->done, user);
+        slot->pending = ev == hipSuccess;
+        if (e != hipSuccess)
+            return fail(kDevice, "BC7 batch table copy / launch", e);
+        if (ev != hipSuccess)
+            return fail(kDevice, "batch event", ev);
+    }
 
     // one table per (format, direction) group; groups are launched one after the other on the caller's stream
     struct Group {
@@ -131,7 +186,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
     Group groups[6];
     for (size_t i = 0; i < count; ++i) {
         const DxtltBatchItem& it = items[i];
-        if (it.len == 0)
+        if (it.len == 0 || it.format == 7)
             continue;
         if (it.len >= (size_t(64) << 30))
             return fail(kInvalidArgument, "batch item of 64 GiB or more: use the single-buffer entry point");
@@ -283,11 +338,11 @@ extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_
     uint64_t total = 0;
     for (size_t i = 0; i < count; ++i) {
         const DxtltBatchItem& it = items[i];
-        if (it.format < 1 || it.format > 3)
-            return fail(kInvalidArgument, "batch item: format must be 1 (BC1), 2 (BC2) or 3 (BC3)");
+        if ((it.format < 1 || it.format > 3) && it.format != 7)
+            return fail(kInvalidArgument, "batch item: format must be 1 (BC1), 2 (BC2), 3 (BC3) or 7 (BC7, this build's own format)");
         if (it.len % (it.format == 1 ? 8u : 16u) != 0)
             return fail(kInvalidLength, "batch item: len is not a multiple of the block size");
-        if (it.decorrelation_mode > 3)
+        if (it.decorrelation_mode > 3 && it.format != 7)
             return fail(kInvalidArgument, "batch item: decorrelation_mode must be 0..3");
         if (it.len > 0 && (it.d_input == nullptr || it.d_output == nullptr))
             return fail(kInvalidArgument, "batch item: NULL buffer with len > 0");

@@ -167,14 +167,11 @@ __device__ __forceinline__ uint64_t slice_offset(int j, int segment, uint64_t pa
     return (uint64_t)off * part_blocks + (uint64_t)width * first_block_of_granule + (uint64_t)(16 * j - off * kT);
 }
 
-// Forward.  LANES lanes per workgroup, V = 1024 / LANES blocks per lane: lane t owns blocks t, t + LANES, ... of the
-// granule (coalesced).  aos: the range's first block.  Full granules (TAIL = false): soa = byte 0 of the part's streams,
-// part_blocks = blocks of the part (a multiple of 1024), first_block = the range's first block inside the part (a
-// multiple of 1024), gridDim.x = granules of the range.  TAIL: one workgroup, n = blocks of the tail part (< 1024),
-// soa = its first byte.
+// One granule, forward.  src = the granule's first block; soa, part_blocks as below; granule_first = the granule's first
+// block inside the part (a multiple of 1024).
 template <int LANES, bool TAIL>
-__global__ void __launch_bounds__(LANES)
-bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t part_blocks, uint64_t first_block, int n_tail)
+__device__ __forceinline__ void bc7_forward_granule(const uint8_t* __restrict__ src, uint8_t* __restrict__ soa,
+                                                    uint64_t part_blocks, uint64_t granule_first, int n_tail)
 {
     constexpr int V = kT / LANES, WAVES = LANES / 64;
     static_assert(V >= 1 && V <= 4 && V * LANES == kT, "four 16-lane rows per wave: at most four segments per wave");
@@ -184,8 +181,6 @@ bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t
     const int n = TAIL ? n_tail : kT;
     const int image = TAIL ? kLdsTailImage : kLdsRaw;            // sorted streams: record bytes 1..15
     const int image_f = TAIL ? kLdsTailImage + 15 * n : kLdsF;   // F stream, block order
-    const uint64_t granule = blockIdx.x;
-    const uint8_t* src = aos + granule * (kT * 16);
 
     u32x4 q[V];
 #pragma unroll
@@ -262,15 +257,16 @@ bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t
                 *reinterpret_cast<u32x4*>(soa + 16 * j) = lds_at<u32x4>(lds, image + 16 * j);
         } else {
             const int segment = v * WAVES + wave;   // segment 15 is the F stream
-            const uint64_t o = slice_offset(j, segment, part_blocks, first_block + granule * kT);
+            const uint64_t o = slice_offset(j, segment, part_blocks, granule_first);
             store_streaming16(soa + o, lds_at<u32x4>(lds, segment == 15 ? kLdsF + 16 * (j - 15 * 64) : image + 16 * j));
         }
     }
 }
 
+// One granule, inverse: dst = where the granule's first block goes.
 template <int LANES, bool TAIL>
-__global__ void __launch_bounds__(LANES)
-bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t part_blocks, uint64_t first_block, int n_tail)
+__device__ __forceinline__ void bc7_inverse_granule(const uint8_t* __restrict__ soa, uint8_t* __restrict__ dst,
+                                                    uint64_t part_blocks, uint64_t granule_first, int n_tail)
 {
     constexpr int V = kT / LANES, WAVES = LANES / 64;
     static_assert(V >= 1 && V <= 4 && V * LANES == kT, "four 16-lane rows per wave: at most four segments per wave");
@@ -280,7 +276,6 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
     const int n = TAIL ? n_tail : kT;
     const int image = TAIL ? kLdsTailImage : kLdsRaw;
     const int image_f = TAIL ? kLdsTailImage + 15 * n : kLdsF;
-    const uint64_t granule = blockIdx.x;
 
     u32x4 in[V];
 #pragma unroll
@@ -291,7 +286,7 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
             if (j < n)
                 in[v] = *reinterpret_cast<const u32x4*>(soa + 16 * j);
         } else {
-            in[v] = gload16(soa + slice_offset(j, v * WAVES + wave, part_blocks, first_block + granule * kT));
+            in[v] = gload16(soa + slice_offset(j, v * WAVES + wave, part_blocks, granule_first));
         }
     }
     if (t < kClasses * kSegments)
@@ -370,7 +365,57 @@ bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t
 #pragma unroll
     for (int v = 0; v < V; ++v)
         if (cls[v] < kClasses)
-            store_streaming16(aos + (granule * kT + (uint64_t)(v * LANES + t)) * 16, lds_at<u32x4>(lds, kLdsRaw + 16 * pos[v]));
+            store_streaming16(dst + (uint64_t)(v * LANES + t) * 16, lds_at<u32x4>(lds, kLdsRaw + 16 * pos[v]));
+}
+
+// Forward.  LANES lanes per workgroup, V = 1024 / LANES blocks per lane.  aos: the range's first block.  Full granules
+// (TAIL = false): soa = byte 0 of the part's streams, part_blocks = blocks of the part (a multiple of 1024), first_block =
+// the range's first block inside the part (a multiple of 1024), gridDim.x = granules of the range.  TAIL: one workgroup,
+// n = blocks of the tail part (< 1024), soa = its first byte.
+template <int LANES, bool TAIL>
+__global__ void __launch_bounds__(LANES)
+bc7_forward(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t part_blocks, uint64_t first_block, int n_tail)
+{
+    const uint64_t granule = blockIdx.x;
+    bc7_forward_granule<LANES, TAIL>(aos + granule * (kT * 16), soa, part_blocks, first_block + granule * kT, n_tail);
+}
+
+template <int LANES, bool TAIL>
+__global__ void __launch_bounds__(LANES)
+bc7_inverse(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t part_blocks, uint64_t first_block, int n_tail)
+{
+    const uint64_t granule = blockIdx.x;
+    bc7_inverse_granule<LANES, TAIL>(soa, aos + granule * (kT * 16), part_blocks, first_block + granule * kT, n_tail);
+}
+
+// Many buffers per launch (dxtlt_transform_batch_device / _host with format 7): workgroup b finds its buffer in the
+// table -- `coarse[b / 64]` is the entry of workgroup 64 * (b / 64), a short scan from there -- and runs one of its
+// granules; the tail parts of all buffers (one workgroup each) go in a second launch over `tails`.
+template <bool INVERSE>
+__global__ void __launch_bounds__(256)
+bc7_batch_granules(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries)
+{
+    const uint32_t b = blockIdx.x;
+    uint32_t i = coarse[b >> 6];
+    while (i + 1 < n_entries && entries[i + 1].first_wg <= b)
+        ++i;
+    const BatchEntry e = entries[i];
+    const uint64_t granule = b - e.first_wg;
+    if constexpr (INVERSE)
+        bc7_inverse_granule<256, false>(e.src, e.dst + granule * (kT * 16), e.main_blocks, granule * kT, 0);
+    else
+        bc7_forward_granule<256, false>(e.src + granule * (kT * 16), e.dst, e.main_blocks, granule * kT, 0);
+}
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(256)
+bc7_batch_tails(const BatchEntry* __restrict__ tails)
+{
+    const BatchEntry e = tails[blockIdx.x];   // src / dst: the tail part's first byte on both sides
+    if constexpr (INVERSE)
+        bc7_inverse_granule<256, true>(e.src, e.dst, e.tail, 0, (int)e.tail);
+    else
+        bc7_forward_granule<256, true>(e.src, e.dst, e.tail, 0, (int)e.tail);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,6 +472,27 @@ hipError_t launch_range(bool inverse, const void* src, void* dst, uint64_t total
 hipError_t launch(bool inverse, const void* src, void* dst, uint64_t n_blocks, hipStream_t stream)
 {
     return launch_range(inverse, src, dst, n_blocks, 0, n_blocks, stream);
+}
+
+hipError_t launch_batch(bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
+                        uint32_t granule_wgs, const BatchEntry* d_tails, uint32_t n_tails, hipStream_t stream)
+{
+    if (granule_wgs > 0) {
+        if (inverse)
+            hipLaunchKernelGGL(bc7_batch_granules<true>, dim3(granule_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries);
+        else
+            hipLaunchKernelGGL(bc7_batch_granules<false>, dim3(granule_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess)
+            return e;
+    }
+    if (n_tails > 0) {
+        if (inverse)
+            hipLaunchKernelGGL(bc7_batch_tails<true>, dim3(n_tails), dim3(256), 0, stream, d_tails);
+        else
+            hipLaunchKernelGGL(bc7_batch_tails<false>, dim3(n_tails), dim3(256), 0, stream, d_tails);
+        return hipGetLastError();
+    }
+    return hipSuccess;
 }
 
 }  // namespace bc7

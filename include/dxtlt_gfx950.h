@@ -152,7 +152,8 @@ typedef struct DxtltBatchItem {
     const void *d_input;
     void *d_output;
     uint64_t len;                   /* bytes, a multiple of the block size */
-    uint8_t format;                 /* 1, 2, 3 = BC1, BC2, BC3 */
+    uint8_t format;                 /* 1, 2, 3 = BC1, BC2, BC3; 7 = BC7 in this build's own format (dxtlt_bc7.h; settings ignored):
+                                       its granules go in one launch per direction, its tail parts in a second one */
     uint8_t inverse;                /* 0 = transform, 1 = untransform */
     uint8_t decorrelation_mode;     /* core numbering */
     uint8_t split_alpha_endpoints;  /* BC3 only */

@@ -36,7 +36,7 @@ pub struct DxtltBatchItem {
     pub d_input: *const c_void,
     pub d_output: *mut c_void,
     pub len: u64,
-    pub format: u8,  // 1, 2, 3 = BC1, BC2, BC3
+    pub format: u8,  // 1, 2, 3 = BC1, BC2, BC3; 7 = BC7 (this build's own format, settings ignored)
     pub inverse: u8, // 0 = transform, 1 = untransform
     pub decorrelation_mode: u8,
     pub split_alpha_endpoints: u8,

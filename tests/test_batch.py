@@ -190,3 +190,46 @@ def test_concurrent_host_batches_and_parallel_auto_transforms(pkg, oracle):
     finally:
         pkg.set_auto_estimator_threads(1)
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_bc7_items_ride_along_in_both_batch_calls(pkg, oracle):
+    """format 7 in dxtlt_transform_batch_device and dxtlt_transform_batch_host: BC7 buffers of every size class (empty,
+    tail part only, whole granules, both) next to BC1-3 items, forward and inverse, against the oracle."""
+    from dxt_lossless_transform_amd import batch
+
+    rng = np.random.default_rng(0xB7BA)
+    dev = torch.device("cuda:0")
+    sizes7 = [0, 1, 500, 1023, 1024, 1025, 2048, 3 * 1024 + 77, 40 * 1024, 40 * 1024 + 1, 200_003]
+    host_items, dev_items, expect = [], [], []
+    for k in range(60):
+        if k % 3 == 0:
+            fmt, blocks = FORMATS[(k // 3) % 3], int(rng.integers(0, 30_000))
+            v, sa, sc = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            x = oracle.fill_splitmix64(blocks * pkg.BLOCK_BYTES[fmt], 0xB7BA + k)
+            inverse = bool(k % 2)
+            want = oracle.transform(fmt, x, v, bool(sc), bool(sa), inverse=inverse)
+            settings = settings_for(pkg, fmt, v, sa, sc)
+        else:
+            fmt, blocks = "bc7", int(sizes7[k % len(sizes7)])
+            x = rng.integers(0, 256, 16 * blocks, dtype=np.uint8)      # raw bytes: every class, the reserved one included
+            inverse = bool((k // 3) % 2)
+            if inverse:
+                x = oracle.transform_bc7(x) if blocks else x
+            want = oracle.transform_bc7(x, inverse=inverse) if blocks else x
+            settings = None
+        y = np.full(x.size + 16, 0x5A, dtype=np.uint8)
+        host_items.append((fmt, inverse, x, y[: x.size], settings))
+        xd = torch.from_numpy(x.copy()).to(dev)
+        yd = torch.full((x.size + 16,), 0x5A, dtype=torch.uint8, device=dev)
+        dev_items.append((fmt, inverse, xd, yd[: x.size], settings))
+        expect.append((want, y, yd, x.size))
+    batch.transform_batch_host(host_items)
+    batch.transform_batch(dev_items)
+    torch.cuda.synchronize()
+    for k, (want, y, yd, n) in enumerate(expect):
+        assert np.array_equal(y[:n], want) and (y[n:] == 0x5A).all(), ("host", k, host_items[k][0], n)
+        h = yd.cpu().numpy()
+        assert np.array_equal(h[:n], want) and (h[n:] == 0x5A).all(), ("device", k, dev_items[k][0], n)
+    with pytest.raises(pkg.InvalidLength):
+        batch.transform_batch_host([("bc7", False, np.zeros(24, np.uint8), np.zeros(24, np.uint8), None)])
