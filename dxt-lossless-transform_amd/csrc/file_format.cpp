@@ -396,7 +396,8 @@ int32_t dxtlt_dds_untransform(const uint8_t* input, size_t input_len, uint8_t* o
 // commands/transform/mod.rs:154-199) with ONE upload / launch / download pipeline under it (dxtlt_transform_batch_host)
 // instead of a PCIe round trip per file.  Every item is checked exactly like the single-file calls and gets their
 // status; items that pass have their header and trailing bytes copied, their payloads go through the batch together,
-// and their TransformHeader (or 'DDS ' magic) is written once the batch has succeeded.
+// and their TransformHeader (or 'DDS ' magic) is written once the batch has succeeded.  BC7 files (with the switch on)
+// ride in the same batch as format 7.
 // ---------------------------------------------------------------------------------------------------------------
 size_t dxtlt_dds_transform_batch(DxtltDdsBatchItem* items, size_t count, bool inverse)
 {
@@ -431,28 +432,36 @@ size_t dxtlt_dds_transform_batch(DxtltDdsBatchItem* items, size_t count, bool in
         uint32_t first_word;
         if (!inverse) {
             bcn = dds_to_bcn(info.Format);
-            if (bcn == 0) {   // BC7 (opt-in, this build's own format) and everything else: one at a time, as the single call does it
-                it.status = dxtlt_dds_transform(it.input, it.input_len, it.output, it.output_len, mode, sa, sc);
-                failed += it.status != DXTLT_FF_OK;
-                continue;
+            if (info.Format == BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
+                bcn = 7;   // opt-in: this build's own format, no settings; rides in the same batch
+                if (length % 16 != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
+                mode = 0;
+                sa = sc = false;
+                first_word = kBc7PrivateHeader;
+            } else {
+                if (bcn == 0) { reject(DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT); continue; }
+                if (length % (bcn == 1 ? 8 : 16) != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
+                if (mode > 3) { reject(DXTLT_FF_CORRUPTED_EMBEDDED_DATA); continue; }
+                if (bcn != 3)
+                    sa = false;
+                first_word = dxtlt_transform_header_pack(bcn - 1, mode, sa, sc);
             }
-            if (length % (bcn == 1 ? 8 : 16) != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
-            if (mode > 3) { reject(DXTLT_FF_CORRUPTED_EMBEDDED_DATA); continue; }
-            if (bcn != 3)
-                sa = false;
-            first_word = dxtlt_transform_header_pack(bcn - 1, mode, sa, sc);
         } else {
             const uint32_t header = rd32(it.input);
-            if ((header & 0xF) > DXTLT_TF_BC3) {   // BC7 when enabled, unknown formats: the single call's answer
-                it.status = dxtlt_dds_untransform(it.input, it.input_len, it.output, it.output_len);
-                failed += it.status != DXTLT_FF_OK;
-                continue;
+            if ((header & 0xF) == DXTLT_TF_BC7 && g_bc7_enabled.load(std::memory_order_relaxed)) {
+                if (header != kBc7PrivateHeader) { reject(DXTLT_FF_CORRUPTED_EMBEDDED_DATA); continue; }
+                if (length % 16 != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
+                bcn = 7;
+                mode = 0;
+                sa = sc = false;
+            } else {
+                if ((header & 0xF) > DXTLT_TF_BC3) { reject(DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT); continue; }
+                int32_t tf = 0;
+                const int32_t rc = dxtlt_transform_header_unpack(header, &tf, &mode, &sa, &sc);
+                if (rc != DXTLT_FF_OK) { reject(rc); continue; }
+                bcn = tf + 1;
+                if (length % (bcn == 1 ? 8 : 16) != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
             }
-            int32_t tf = 0;
-            const int32_t rc = dxtlt_transform_header_unpack(header, &tf, &mode, &sa, &sc);
-            if (rc != DXTLT_FF_OK) { reject(rc); continue; }
-            bcn = tf + 1;
-            if (length % (bcn == 1 ? 8 : 16) != 0) { reject(DXTLT_FF_INVALID_DATA_ALIGNMENT); continue; }
             first_word = kDdsMagic;
         }
         // everything around the payload; bytes 0..3 stay the input's until the payload has been transformed

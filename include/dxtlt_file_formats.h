@@ -116,7 +116,7 @@ void dxtlt_file_formats_enable_bc7(bool enabled);
  * exactly like dxtlt_dds_transform / dxtlt_dds_untransform would check it and receives that call's status in `status`;
  * the items that pass are transformed together.  inverse = false: `decorrelation_mode` / `split_*` are the settings to
  * apply (as in dxtlt_dds_transform); inverse = true: the settings come from each file's TransformHeader and those fields
- * are ignored.  BC7 files (with the switch above on) are handled one at a time inside the call.  Returns the number of
+ * are ignored.  BC7 files (with the switch above on) ride in the same pipeline.  Returns the number of
  * items whose status is not DXTLT_FF_OK (0 = all done).  If the shared device pipeline fails, every item that was in it
  * gets DXTLT_FF_TRANSFORM_FAILED and its output is unspecified. */
 typedef struct DxtltDdsBatchItem {
