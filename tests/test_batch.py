@@ -225,7 +225,8 @@ def test_bc7_items_ride_along_in_both_batch_calls(pkg, oracle):
         dev_items.append((fmt, inverse, xd, yd[: x.size], settings))
         expect.append((want, y, yd, x.size))
     batch.transform_batch_host(host_items)
-    batch.transform_batch(dev_items)
+    prepared = batch.prepare_batch(dev_items)            # the reusable form of transform_batch
+    batch.run_prepared_batch(prepared)
     torch.cuda.synchronize()
     for k, (want, y, yd, n) in enumerate(expect):
         assert np.array_equal(y[:n], want) and (y[n:] == 0x5A).all(), ("host", k, host_items[k][0], n)
