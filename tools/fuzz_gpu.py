@@ -1,6 +1,7 @@
 """Seeded random campaign, GPU against the oracle, for a time budget: whole-buffer calls and RANGE calls of BC1/2/3 with
 random settings, block counts (tiny, around tile multiples, up to a few million), first blocks, and byte offsets 0..191
-of both device pointers; BC7 whole buffers and granule ranges.  Guard bytes around every output.  Prints one line per
+of both device pointers; BC7 whole buffers and granule ranges; batch calls over 1..40 buffers of mixed formats (BC7
+included), directions and pointer offsets.  Guard bytes around every output.  Prints one line per
 100 cases and the failing case's parameters (re-runnable: `python tools/fuzz_gpu.py --seed S --only CASE`).
 Test tooling: imports oracle/.   usage: python tools/fuzz_gpu.py [--seconds 300] [--seed 1]"""
 import argparse
@@ -137,6 +138,45 @@ def bc7_case(case, rng, dev):
     return ok, tag
 
 
+def batch_case(case, rng, dev):
+    """one dxtlt_transform_batch_device call over 1..40 buffers: formats BC1-3 and BC7 mixed, both directions, block
+    counts 0..20 000, every buffer at its own byte offset 0..63 on both sides"""
+    from dxt_lossless_transform_amd import batch
+
+    k = int(rng.integers(1, 41))
+    items, checks = [], []
+    for i in range(k):
+        fmt = ("bc1", "bc2", "bc3", "bc7")[int(rng.integers(0, 4))]
+        n = int(rng.integers(0, 20_001)) if rng.integers(0, 4) else int(rng.integers(0, 30))
+        inverse = bool(rng.integers(0, 2))
+        a, b = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+        if fmt == "bc7":
+            B, st = 16, None
+            x = bc7_blocks(n, rng, case * 64 + i)
+            if inverse and n:
+                x = oracle_c.transform_bc7(x)
+            want = oracle_c.transform_bc7(x, inverse=inverse) if n else x
+            tag_s = None
+        else:
+            B = BLOCK[fmt]
+            (v, sa, sc), st = settings_of(fmt, rng)
+            x = oracle_c.fill_splitmix64(n * B, 0xBA7 + case * 64 + i)
+            want = oracle_c.transform(fmt, x, v, sc, sa, inverse=inverse)
+            tag_s = (v, sa, sc)
+        xd = torch.full((n * B + 128,), 0x11, dtype=torch.uint8, device=dev)
+        xd[a:a + n * B] = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        yd = torch.full((n * B + 128,), 0x22, dtype=torch.uint8, device=dev)
+        items.append((fmt, inverse, xd[a:a + n * B], yd[b:b + n * B], st))
+        checks.append((want, yd, b, n * B, (fmt, inverse, n, a, b, tag_s)))
+    batch.transform_batch(items)
+    torch.cuda.synchronize()
+    for want, yd, b, nb, tag in checks:
+        h = yd.cpu().numpy()
+        if not (np.array_equal(h[b:b + nb], want) and guard_ok(h, b, nb, 0x22)):
+            return False, dict(case=case, kind="batch", item=tag, ranged=False)
+    return True, dict(case=case, kind="batch", ranged=False)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -147,15 +187,16 @@ def main():
     dev = torch.device("cuda:0")
     t0 = time.time()
     case = 0
-    counts = {"bcn": 0, "bcn_ranged": 0, "bc7": 0, "bc7_ranged": 0}
+    counts = {"bcn": 0, "bcn_ranged": 0, "bc7": 0, "bc7_ranged": 0, "batch": 0}
     while time.time() - t0 < args.seconds:
         rng = np.random.default_rng([args.seed, case])
         if args.only >= 0 and case != args.only:
             case += 1
             continue
-        is7 = rng.integers(0, 4) == 0
-        ok, tag = (bc7_case if is7 else bcn_case)(case, rng, dev)
-        counts[("bc7" if is7 else "bcn") + ("_ranged" if tag["ranged"] else "")] += 1
+        pick = int(rng.integers(0, 16))
+        is7, is_batch = pick < 4, pick == 15
+        ok, tag = (batch_case if is_batch else bc7_case if is7 else bcn_case)(case, rng, dev)
+        counts["batch" if is_batch else ("bc7" if is7 else "bcn") + ("_ranged" if tag["ranged"] else "")] += 1
         if not ok:
             print("FAIL", tag, flush=True)
             sys.exit(1)
