@@ -255,6 +255,12 @@ std::pair<Bc3TransformSettings, DetermineBestTransformError> transform_bc3_auto(
     return {Bc3TransformSettings{static_cast<YCoCgVariant>(mode), sa, sc}, detail_auto::map(rc)};
 }
 
+// Additive (dxtlt_gfx950.h): evaluate every distinct candidate section of the auto transforms concurrently on `threads`
+// host threads -- same settings and bytes; the estimator's max_compressed_size / estimate_compressed_size must then be
+// safe to call from several threads at once.  Process-wide; 1 restores the reference's sequence of calls.
+inline void set_auto_estimator_threads(int threads) { dxtlt_set_auto_estimator_threads(threads); }
+inline int auto_estimator_threads() { return dxtlt_get_auto_estimator_threads(); }
+
 // ---- dxt_lossless_transform_bc1::experimental::normalize_blocks (normalize.rs, transform.rs, mod.rs) ------------
 namespace experimental {
 

@@ -5,6 +5,7 @@
 // bc1-api transform/manual_transform_builder.rs and auto_transform_builder.rs tests.
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <vector>
 
 #include "../../include/dxt_lossless_transform.hpp"
@@ -40,6 +41,18 @@ struct DummyEstimator {  // bc1 test_prelude.rs:44-62: max 0, estimate = len
     int calls = 0;
     bool max_compressed_size(size_t, size_t& out) { out = 0; return true; }
     bool estimate_compressed_size(const uint8_t*, size_t len, uint8_t*, size_t, size_t& out) { ++calls; out = len; return true; }
+};
+struct SharedCounterEstimator {  // thread-safe: for dxtlt_set_auto_estimator_threads
+    std::atomic<int>* calls;
+    bool max_compressed_size(size_t len, size_t& out) { out = len; return true; }
+    bool estimate_compressed_size(const uint8_t* p, size_t len, uint8_t*, size_t, size_t& out)
+    {
+        calls->fetch_add(1);
+        size_t h = 0;
+        for (size_t i = 0; i < len; ++i) h = h * 131 + p[i];
+        out = h % 100000;   // depends on every byte shown
+        return true;
+    }
 };
 struct FailingEstimator {  // bc1 transform/mod.rs:120-138
     bool max_compressed_size(size_t, size_t& out) { out = 0; return true; }
@@ -136,6 +149,20 @@ static void gpu_tests()
     core::EstimateSettings<DummyEstimator> es{DummyEstimator{}, true};
     auto r3 = core::transform_bc3_auto(w.data(), w2.data(), w.size(), es);
     CHECK(r3.second.is_ok() && es.size_estimator.calls == 32);  // 16 candidates x (alpha + colour endpoints)
+    {
+    // opt-in parallel estimator: the same choice and bytes, every distinct section estimated once (8 colour + 2 alpha)
+    std::atomic<int> calls_seq{0}, calls_par{0};
+    std::vector<uint8_t> out_seq(w.size()), out_par(w.size());
+    core::EstimateSettings<SharedCounterEstimator> e1{SharedCounterEstimator{&calls_seq}, true}, e4{SharedCounterEstimator{&calls_par}, true};
+    auto seq = core::transform_bc3_auto(w.data(), out_seq.data(), w.size(), e1);
+    core::set_auto_estimator_threads(4);
+    CHECK(core::auto_estimator_threads() == 4);
+    auto par = core::transform_bc3_auto(w.data(), out_par.data(), w.size(), e4);
+    core::set_auto_estimator_threads(1);
+    CHECK(seq.second.is_ok() && par.second.is_ok() && calls_seq.load() == 32 && calls_par.load() == 10 && out_seq == out_par);
+    CHECK(seq.first.decorrelation_mode == par.first.decorrelation_mode && seq.first.split_alpha_endpoints == par.first.split_alpha_endpoints &&
+          seq.first.split_colour_endpoints == par.first.split_colour_endpoints);
+    }
 
     // experimental block normalisation: the reference's unit vectors (normalize.rs:508-598, 750-848)
     namespace ex = core::experimental;
