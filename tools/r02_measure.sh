@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 measurement set on the GPU box (run through gpurun from the repo root): bench lines, rocprofv3 kernel stats
+# Per-round measurement set on the GPU box (ROUND=r03 names the output directory; default r02) (run through gpurun from the repo root): bench lines, rocprofv3 kernel stats
 # and PMC traffic passes for the BC1 headline workload and the BC7 workload.  Output under gpurun_out/r02_final/;
 # tools/summarize_profiles.py condenses it into profiles/.
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r02_final
+O=$R/gpurun_out/${ROUND:-r02}_final
 mkdir -p $O
 step() { echo "== $*"; }
 
