@@ -343,9 +343,38 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
         }
     }
 
+    // Sequential mode with the arena: the sections of candidate i + 1 travel into the other half of a pinned staging buffer
+    // while the estimator works on candidate i -- the reference's sequence of calls and bytes, minus the wait for every
+    // download (and minus pageable-memory copies).  The estimator is shown the staged bytes, not the output buffer.
+    const size_t alpha_slot = (alpha_len + 255) & ~size_t(255), slot_bytes = alpha_slot + ((colour_len + 255) & ~size_t(255));
+    uint8_t* stage = nullptr;
+    if (!parallel && arena != nullptr && len > 0 && slot_bytes <= (size_t(512) << 20))
+        stage = static_cast<uint8_t*>(g_stage.get(2 * slot_bytes));
+    auto issue_sections = [&](int i) -> hipError_t {
+        const Candidate c = order[i];
+        uint8_t* slot = stage + (size_t)(i & 1) * slot_bytes;
+        hipError_t e = hipSuccess;
+        if (alpha_len)
+            e = hipMemcpyAsync(slot, arena + dxtlt::auto_alpha_section_offset(blocks, c.split_alpha), alpha_len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(slot + alpha_slot, arena + dxtlt::auto_section_offset((dxtlt::Format)format, blocks, c.mode, c.split_colour),
+                               colour_len, hipMemcpyDeviceToHost, st);
+        return e;
+    };
+    if (stage != nullptr)
+        HIP_TRY_AUTO(issue_sections(0), "D2H candidate sections");
+
     for (int i = 0; i < count && !parallel; ++i) {
         const Candidate c = order[i];
-        if (len > 0) {
+        const uint8_t* shown_alpha = out;
+        const uint8_t* shown_colour = out + colour_off;
+        if (stage != nullptr) {
+            HIP_TRY_AUTO(hipStreamSynchronize(st), "stream synchronize");   // candidate i has arrived
+            if (i + 1 < count)
+                HIP_TRY_AUTO(issue_sections(i + 1), "D2H candidate sections");
+            shown_alpha = stage + (size_t)(i & 1) * slot_bytes;
+            shown_colour = shown_alpha + alpha_slot;
+        } else if (len > 0) {
             const uint8_t* alpha_src = (const uint8_t*)d_out;
             const uint8_t* colour_src = (const uint8_t*)d_out + colour_off;
             if (arena != nullptr) {
@@ -371,17 +400,18 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
 
         size_t total = 0, part = 0;
         if (format == 3) {
-            rc_est = est->EstimateCompressedSize(est->Context, out, alpha_len, scratch, max_comp, &part);
+            rc_est = est->EstimateCompressedSize(est->Context, shown_alpha, alpha_len, scratch, max_comp, &part);
             if (rc_est == 0) {
                 total = part;
                 part = 0;
-                rc_est = est->EstimateCompressedSize(est->Context, out + colour_off, colour_len, scratch, max_comp, &part);
+                rc_est = est->EstimateCompressedSize(est->Context, shown_colour, colour_len, scratch, max_comp, &part);
                 total += part;
             }
         } else {
-            rc_est = est->EstimateCompressedSize(est->Context, out + colour_off, colour_len, scratch, max_comp, &total);
+            rc_est = est->EstimateCompressedSize(est->Context, shown_colour, colour_len, scratch, max_comp, &total);
         }
         if (rc_est != 0) {
+            if (st) (void)hipStreamSynchronize(st);   // a download of the next candidate may be in flight
             std::free(scratch);
             choice->estimator_error = rc_est;
             return fail(kEstimator, "size estimator: estimate_compressed_size failed");
