@@ -126,7 +126,7 @@ def zstd_c_estimator(level: int = 1):
     if lib.zest_init() != 0:
         return None
     max_fn = C.cast(lib.zest_max_compressed_size, MAXFN)
-    est_fn = C.cast(lib.zest_estimate, ESTFN)
-    est = DltSizeEstimator(C.c_void_p(level), max_fn, est_fn)
+    est_fn = C.cast(lib.zest_len_estimate if level is None else lib.zest_estimate, ESTFN)   # level None: size = len, in C
+    est = DltSizeEstimator(C.c_void_p(level or 0), max_fn, est_fn)
     est._keep = (max_fn, est_fn, lib)
     return est, lib

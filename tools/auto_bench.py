@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """transform_bcN_auto, device side: the fused candidate kernel (one read of the input -> every endpoint section) against
-one full transform per candidate (DXTLT_AUTO_FUSED=0).  256 MiB per format, a constant-time estimator (the callback
+one full transform per candidate (DXTLT_AUTO_FUSED=0).  256 MiB per format, a constant-time estimator in C (the callback
 returns the length), so what is left is upload + kernels + the per-candidate section downloads.  Run under
 `rocprofv3 --kernel-trace --stats` to see the kernel list; prints wall time per call.
 
@@ -28,7 +28,8 @@ x = oracle_c.fill_splitmix64(nbytes, 0xA070)
 y = np.zeros_like(x)
 for n in (1, 2, 3):
     for use_all in (False, True):
-        est, _ = cabi.make_estimator("dummy")
+        made = cabi.zstd_c_estimator(None)            # size = len, in C: a Python callback would copy every section it is shown
+        est = made[0] if made else cabi.make_estimator("dummy")[0]
         settings = {1: cabi.CoreSettings2, 2: cabi.CoreSettings2, 3: cabi.CoreSettings3}[n]()
         f = getattr(lib, f"dltbc{n}core_transform_auto")
         f(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est), cabi.AutoSettings(use_all), C.byref(settings))
