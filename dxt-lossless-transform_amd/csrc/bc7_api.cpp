@@ -18,6 +18,15 @@ int32_t host_call(bool inverse, const uint8_t* in, uint8_t* out, size_t len)
         return kOk;
     if (in == nullptr || out == nullptr)
         return fail(kInvalidArgument, "NULL buffer with len > 0");
+    // large buffers: the main part in chunks (upload, kernel and the eight per-stream downloads of consecutive chunks
+    // overlap), then the tail part -- a BC7 buffer of its own -- through the one-shot path below
+    const uint64_t blocks = len / 16, main_blocks = blocks - blocks % 1024;
+    int32_t prc = kOk;
+    if (pipelined_bc7_main(inverse, in, out, main_blocks, &prc)) {
+        if (prc != kOk || main_blocks == blocks)
+            return prc;
+        return host_call(inverse, in + main_blocks * 16, out + main_blocks * 16, (size_t)((blocks - main_blocks) * 16));
+    }
     void *d_in = nullptr, *d_out = nullptr;
     hipStream_t st = nullptr;
     int32_t rc = acquire_staging(len, &d_in, &d_out, &st);

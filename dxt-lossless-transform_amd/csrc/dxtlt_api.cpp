@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "bc7_launch.h"
 #include "bcn_launch.h"
 #include "host_common.h"
 
@@ -222,12 +223,38 @@ struct PipeJob {
 
 int32_t pipelined_range(const PipeJob& j)
 {
-    const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)j.format);
-    const dxtlt::Streams S = dxtlt::make_streams(j.format, j.format == 3 && j.sa, j.sc);
-    const uint64_t chunk_blocks = j.chunk_bytes / B;  // a multiple of every tile size
+    // format 7 = the main part of a BC7 buffer (include/dxtlt_bc7.h): eight streams over whole 1024-block granules, chunks
+    // are granule multiples, the kernels are the BC7 range launches; everything else is the same pipeline
+    const bool bc7 = j.format == 7;
+    const uint64_t B = bc7 ? 16 : (uint64_t)dxtlt::block_bytes((Format)j.format);
+    struct {
+        int n;
+        int off[8], width[8];
+    } S{};
+    if (bc7) {
+        const int off[8] = {0, 8, 10, 11, 12, 13, 14, 15}, width[8] = {8, 2, 1, 1, 1, 1, 1, 1};
+        S.n = 8;
+        for (int s = 0; s < 8; ++s) {
+            S.off[s] = off[s];
+            S.width[s] = width[s];
+        }
+    } else {
+        const dxtlt::Streams bs = dxtlt::make_streams(j.format, j.format == 3 && j.sa, j.sc);
+        S.n = bs.n;
+        for (int s = 0; s < bs.n; ++s) {
+            S.off[s] = bs.off[s];
+            S.width[s] = bs.width[s];
+        }
+    }
+    auto launch = [&](bool inv, const void* src, void* dst, uint64_t range_total, uint64_t range_first, uint64_t range_count) -> int32_t {
+        if (!bc7)
+            return device_range(j.format, inv, src, dst, range_total, range_first, range_count, j.mode, j.sa, j.sc, j.up, inv ? 0 : j.normalize);
+        const hipError_t e = dxtlt::bc7::launch_range(inv, src, dst, range_total, range_first, range_count, j.up);
+        return e == hipSuccess ? DXTLT_OK : fail(DXTLT_E_DEVICE, "BC7 kernel launch", e);
+    };
+    const uint64_t chunk_blocks = j.chunk_bytes / B;  // a multiple of every tile size (and of the BC7 granule)
     const int nchunks = (int)((j.count + chunk_blocks - 1) / chunk_blocks);
     const int dev = j.dev;
-    const int32_t format = j.format;
     const bool inverse = j.inverse;
     const uint64_t total = j.total, base = j.first, blocks = j.count;
     const uint8_t* in = j.in;
@@ -285,8 +312,7 @@ int32_t pipelined_range(const PipeJob& j)
             up_err = hipMemcpyAsync((uint8_t*)j.d_in + first * B, in + (base + first) * B, (size_t)(count * B),
                                     hipMemcpyHostToDevice, j.up);
             if (up_err == hipSuccess)
-                rc = device_range(format, false, (const uint8_t*)j.d_in + first * B, j.d_out, blocks, first, count,
-                                  j.mode, j.sa, j.sc, j.up, j.normalize);
+                rc = launch(false, (const uint8_t*)j.d_in + first * B, j.d_out, blocks, first, count);
         } else {
             for (int s = 0; s < S.n && up_err == hipSuccess; ++s) {
                 const uint64_t w = (uint64_t)S.width[s], off = (uint64_t)S.off[s];
@@ -294,8 +320,7 @@ int32_t pipelined_range(const PipeJob& j)
                                         (size_t)(w * count), hipMemcpyHostToDevice, j.up);
             }
             if (up_err == hipSuccess)
-                rc = device_range(format, true, j.d_in, (uint8_t*)j.d_out + first * B, blocks, first, count, j.mode, j.sa,
-                                  j.sc, j.up);
+                rc = launch(true, j.d_in, (uint8_t*)j.d_out + first * B, blocks, first, count);
         }
         if (up_err == hipSuccess && rc == DXTLT_OK)
             up_err = hipEventRecord(ev[(size_t)k], j.up);
@@ -337,6 +362,25 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
 }
 
 }  // namespace
+
+// The main part (whole granules) of a large BC7 host buffer through the chunked pipeline; false = too small / switched off
+bool dxtlt_host::pipelined_bc7_main(bool inverse, const uint8_t* in, uint8_t* out, uint64_t main_blocks, int32_t* rc)
+{
+    const uint64_t bytes = main_blocks * 16;
+    if (bytes < kPipelineMinBytes || g_host_pipeline.load(std::memory_order_relaxed) == 0)
+        return false;
+    HostCtx& c = g_host_ctx;
+    *rc = c.prepare((size_t)bytes);
+    if (*rc != DXTLT_OK)
+        return true;
+    // eight downloads per chunk, five of them a sixteenth of it: larger chunks than BC1-3 (16 MiB chunks lose to the
+    // one-shot path below 1 GiB; 32 MiB: 30 / 34 / 37 GiB/s at 128 / 256 / 512 MiB; 64 MiB: 40-41 from 1 GiB up;
+    // tools/bc7_host_bench.py)
+    const uint64_t chunk = kPipelineChunkOverride ? kPipelineChunkOverride : bytes >= (1ull << 30) ? (64ull << 20) : (32ull << 20);
+    PipeJob j{c.device, c.stream, c.d_in, c.d_out, 7, inverse, in, out, main_blocks, 0, main_blocks, 0, false, false, 0, chunk};
+    *rc = pipelined_range(j);
+    return true;
+}
 
 int32_t dxtlt_host::acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream)
 {

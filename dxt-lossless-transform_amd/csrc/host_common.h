@@ -31,6 +31,10 @@ int32_t transform(int32_t format, bool inverse, const uint8_t* in, uint8_t* out,
 // This thread's staging context on the current device: two device buffers of at least `bytes` and a stream.
 int32_t acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream);
 
+// Large BC7 host buffers: the main part (whole 1024-block granules) through the chunked upload | kernel | download
+// pipeline of the BC1-3 host path.  Returns false when the buffer is below the pipeline's threshold (nothing done).
+bool pipelined_bc7_main(bool inverse, const uint8_t* in, uint8_t* out, uint64_t main_blocks, int32_t* rc);
+
 // Enqueue one whole-buffer transform on device pointers.
 int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
                 bool split_alpha, bool split_colour, hipStream_t stream, uint8_t normalize = 0);

@@ -300,3 +300,25 @@ def test_four_gib_mode_mixed(pkg, bc7, oracle):
     bc7.transform_bc7(xs, ys)
     torch.cuda.synchronize()
     assert np.array_equal(ys.cpu().numpy(), oracle.transform_bc7(xs.cpu().numpy()))
+
+
+@pytest.mark.gpu
+def test_large_host_buffers_take_the_chunked_pipeline(pkg, bc7, oracle):
+    """>= 96 MiB through dxtlt_transform_bc7: the main part in chunks (upload | kernel | eight per-stream downloads
+    overlapped), the tail part as a buffer of its own -- equal to the device path on the same data, exact round trip."""
+    n = (130 << 20) // 16 + 777                       # main part of 8320 granules + a tail part
+    x = make_blocks(oracle, n, "uniform", 0xB16)
+    y, z = np.zeros_like(x), np.zeros_like(x)
+    bc7.transform_bc7(x, y)                           # host pointers
+    xd = torch.from_numpy(x).to("cuda:0")
+    yd = torch.empty_like(xd)
+    bc7.transform_bc7(xd, yd)                         # device pointers: one launch pair
+    assert np.array_equal(y, yd.cpu().numpy())
+    sample = slice(16 * 1024 * 4000, 16 * 1024 * 4003)  # three granules from the middle against the oracle's records
+    want = oracle.transform_bc7(x[sample])
+    main = n - n % 1024
+    for off, w in ((0, 8), (8, 2), (10, 1), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1)):
+        got = y[off * main + w * 1024 * 4000: off * main + w * 1024 * 4003]
+        assert np.array_equal(got, want[off * 3072: off * 3072 + w * 3072])
+    bc7.untransform_bc7(y, z)
+    assert np.array_equal(z, x)
