@@ -185,11 +185,14 @@ size_t env_bytes(const char* name, size_t fallback)
 // chunks: 40-42 GiB/s from 512 MiB up).
 const size_t kPipelineMinBytes = env_bytes("DXTLT_PIPELINE_MIN_BYTES", 96u << 20);
 const uint64_t kPipelineChunkOverride = env_bytes("DXTLT_PIPELINE_CHUNK_BYTES", 0) & ~(uint64_t)0xFFFF;
-inline uint64_t pipeline_chunk_bytes(uint64_t len)
+// Chunk size.  BC3's six streams include two of a sixteenth of the data each: with 16 MiB chunks their downloads are
+// 1 MiB copies and the pipeline falls to 22-30 GiB/s between 256 MiB and 1 GiB; 32 MiB chunks give 35-40 there
+// (tools/host_chunk_sweep.py, round 2).  BC1 / BC2 keep 16 MiB chunks below 256 MiB (one more GiB/s at 128 MiB).
+inline uint64_t pipeline_chunk_bytes(uint64_t len, int32_t format)
 {
     if (kPipelineChunkOverride)
         return kPipelineChunkOverride;
-    return len >= (1ull << 30) ? (32ull << 20) : (16ull << 20);
+    return (format == 3 || len >= (256ull << 20)) ? (32ull << 20) : (16ull << 20);
 }
 std::atomic<int> g_host_pipeline{1};
 
@@ -357,7 +360,7 @@ int32_t pipelined_transform(HostCtx& c, int32_t format, bool inverse, const uint
 {
     const uint64_t B = (uint64_t)dxtlt::block_bytes((Format)format);
     PipeJob j{c.device, c.stream, c.d_in, c.d_out, format, inverse, in, out, blocks, 0, blocks, mode, sa, sc, normalize,
-              pipeline_chunk_bytes(blocks * B)};
+              pipeline_chunk_bytes(blocks * B, format)};
     return pipelined_range(j);
 }
 
@@ -496,7 +499,7 @@ int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, u
     if (bytes >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0) {
         // large shard: upload, kernel and the per-stream downloads of consecutive chunks overlap
         PipeJob j{dev, st, d_a, d_b, format, inverse, in, out, total, sp.first, sp.count, mode, sa, sc, 0,
-                  pipeline_chunk_bytes(bytes)};
+                  pipeline_chunk_bytes(bytes, format)};
         return done(pipelined_range(j));
     }
     if (!inverse) {
