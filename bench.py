@@ -540,8 +540,9 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
     """north_star's multi-GPU statement as ONE call: a host-resident block array is split by contiguous block range over
     every visible device and each shard's slice of every stream lands at its final host offset (dxtlt_transform_sharded;
     the reference side of the contract is one call over the whole array, transform_with_settings.rs:31-72).  Host
-    buffers are pinned.  Checked: exact round trip of the whole array, oracle windows that straddle every shard
-    boundary."""
+    buffers are ordinary pageable memory, as a caller's are (DXTLT_BENCH_PINNED_HOST=1 pins them: measured SLOWER at this
+    size -- three 8 GiB pinned arrays move at 18-25 GiB/s where pageable ones move at 41-43, tools/pinned_host_probe.py).
+    Checked: exact round trip of the whole array, oracle windows that straddle every shard boundary."""
     import numpy as np
 
     from oracle import oracle_c
@@ -551,9 +552,13 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
     blocks = nbytes // block
     n_dev = max(1, min(int(want_devices), pkg.load().dxtlt_device_count()))   # as many devices as the job has ranks
     t0 = time.perf_counter()
-    h_in = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-    h_soa = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-    h_back = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    pinned = os.environ.get("DXTLT_BENCH_PINNED_HOST") == "1"
+    h_in = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
+    h_soa = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
+    h_back = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
+    if not pinned:
+        h_soa.zero_()      # first touch outside the timed calls
+        h_back.zero_()
     # the same logical array as the kernel legs, generated on the device in pieces and copied out
     piece = min(nbytes, 1 << 30)
     scratch = torch.empty(piece, dtype=torch.uint8, device=dev)
@@ -591,7 +596,7 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
     assert ok, "sharded host array: result differs from the oracle / round trip failed"
     return {
         "entry_point": "dxtlt_transform_sharded (one process, one host thread per device, chunked H2D | kernel | per-stream D2H)",
-        "array_bytes": nbytes, "devices": n_dev, "host_memory": "pinned",
+        "array_bytes": nbytes, "devices": n_dev, "host_memory": "pinned" if pinned else "pageable",
         "fwd_GiBps": round(nbytes / fwd_s / 2**30, 2), "inv_GiBps": round(nbytes / inv_s / 2**30, 2),
         "fwd_plus_inv_GiBps": round(2 * nbytes / (fwd_s + inv_s) / 2**30, 2),
         "bit_exact_roundtrip_and_oracle_windows_across_shard_boundaries": ok,

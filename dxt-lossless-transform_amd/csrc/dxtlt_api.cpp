@@ -473,6 +473,93 @@ std::vector<ShardPlan> plan_shards(uint64_t total_blocks, int shards, uint64_t a
     return p;
 }
 
+// Per-device shard contexts (a stream and a grow-only pair of device buffers), kept across dxtlt_transform_sharded calls:
+// the shard threads are new on every call, so thread-local staging as in the host-pointer path would be allocated and
+// freed each time -- two hipMalloc / hipFree of the shard's size per call cost a 4 GiB BC3 array 30 ms of its 130 (pinned
+// host memory) and far more with pageable memory (13 against 41 GiB/s through the single-buffer entry point;
+// tools/pinned_host_probe.py).  dxtlt_release_thread_resources() frees the idle ones.
+struct ShardCtx {
+    int dev = -1;
+    hipStream_t st = nullptr;
+    void* a = nullptr;
+    void* b = nullptr;
+    size_t cap = 0;
+    bool busy = false;
+};
+std::mutex g_shard_pool_mutex;
+std::vector<ShardCtx*> g_shard_pool;
+
+ShardCtx* shard_ctx_acquire(int dev, size_t bytes, hipError_t* err)
+{
+    ShardCtx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
+        for (ShardCtx* x : g_shard_pool)
+            if (!x->busy && x->dev == dev && (c == nullptr || x->cap > c->cap))
+                c = x;
+        if (c == nullptr) {
+            c = new ShardCtx();
+            c->dev = dev;
+            g_shard_pool.push_back(c);
+        }
+        c->busy = true;
+    }
+    *err = hipSuccess;
+    if (c->st == nullptr)
+        *err = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+    if (*err == hipSuccess && c->cap < bytes) {
+        if (c->a) (void)hipFree(c->a);
+        if (c->b) (void)hipFree(c->b);
+        c->a = c->b = nullptr;
+        c->cap = 0;
+        *err = hipMalloc(&c->a, bytes);
+        if (*err == hipSuccess)
+            *err = hipMalloc(&c->b, bytes);
+        if (*err == hipSuccess) {
+            c->cap = bytes;
+        } else {
+            if (c->a) (void)hipFree(c->a);
+            c->a = c->b = nullptr;
+        }
+    }
+    if (*err != hipSuccess) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
+        c->busy = false;
+        return nullptr;
+    }
+    return c;
+}
+
+void shard_ctx_release(ShardCtx* c)
+{
+    std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
+    c->busy = false;
+}
+
+void shard_pool_clear()
+{
+    std::vector<ShardCtx*> idle;
+    {
+        std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
+        std::vector<ShardCtx*> keep;
+        for (ShardCtx* x : g_shard_pool)
+            (x->busy ? keep : idle).push_back(x);
+        g_shard_pool.swap(keep);
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (ShardCtx* x : idle) {
+        if (hipSetDevice(x->dev) == hipSuccess) {
+            if (x->a) (void)hipFree(x->a);
+            if (x->b) (void)hipFree(x->b);
+            if (x->st) (void)hipStreamDestroy(x->st);
+        }
+        delete x;
+    }
+    (void)hipSetDevice(prev);
+}
+
 int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, uint8_t* out, uint64_t total,
                      ShardPlan sp, uint8_t mode, bool sa, bool sc)
 {
@@ -482,18 +569,17 @@ int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, u
     const size_t bytes = (size_t)(sp.count * B);
     const dxtlt::Streams S = dxtlt::make_streams(format, format == 3 && sa, sc);
     HIP_TRY(hipSetDevice(dev), "hipSetDevice");
-    hipStream_t st = nullptr;
-    void *d_a = nullptr, *d_b = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    hipError_t acquire_err = hipSuccess;
+    ShardCtx* ctx = shard_ctx_acquire(dev, bytes, &acquire_err);
+    if (ctx == nullptr)
+        return fail(DXTLT_E_DEVICE, "shard stream / buffers", acquire_err);
+    hipStream_t st = ctx->st;
+    void *d_a = ctx->a, *d_b = ctx->b;
     int32_t rc = DXTLT_OK;
-    auto done = [&](int32_t code) {
-        if (d_a) (void)hipFree(d_a);
-        if (d_b) (void)hipFree(d_b);
-        (void)hipStreamDestroy(st);
+    auto done = [&](int32_t code) {   // every path below has drained `st` before it gets here
+        shard_ctx_release(ctx);
         return code;
     };
-    if (hipMalloc(&d_a, bytes) != hipSuccess || hipMalloc(&d_b, bytes) != hipSuccess)
-        return done(fail(DXTLT_E_DEVICE, "hipMalloc(shard buffers)", hipGetLastError()));
 
     hipError_t e = hipSuccess;
     if (bytes >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0) {
@@ -688,6 +774,7 @@ const char* dxtlt_version(void) { return "dxtlt-gfx950 0.1.0"; }
 void dxtlt_release_thread_resources(void)
 {
     g_host_ctx.release();
+    shard_pool_clear();   // process-wide: the idle per-device contexts of dxtlt_transform_sharded
     dxtlt_host::release_bc7_thread_scratch();
     dxtlt_host::release_normalize_thread_flag();
     dxtlt_host::release_batch_thread_tables();
