@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <string>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -74,19 +75,42 @@ int32_t shard_worker(int dev, bool inverse, const uint8_t* in, uint8_t* out, uin
     hipError_t e = hipSetDevice(dev);
     if (e != hipSuccess)
         return fail(kDevice, "hipSetDevice", e);
-    hipStream_t st = nullptr;
-    void *d_a = nullptr, *d_b = nullptr;
-    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess)
-        return fail(kDevice, "hipStreamCreate", e);
+    // stream and buffers of this device are kept across calls (host_common.h): a fresh stream and two hipMallocs of the
+    // shard's size per call cost more than the transfers they serve
+    ShardBuffers sb{};
+    if (int32_t rc = acquire_shard_buffers(dev, bytes, &sb); rc != kOk)
+        return rc;
+    hipStream_t st = sb.stream;
+    void *d_a = sb.a, *d_b = sb.b;
     auto done = [&](int32_t code) {
-        (void)hipStreamSynchronize(st);   // nothing may still target the buffers freed below
-        if (d_a) (void)hipFree(d_a);
-        if (d_b) (void)hipFree(d_b);
-        (void)hipStreamDestroy(st);
+        (void)hipStreamSynchronize(st);   // nothing may still target the buffers the next call will reuse
+        release_shard_buffers(sb);
         return code;
     };
-    if (hipMalloc(&d_a, bytes) != hipSuccess || hipMalloc(&d_b, bytes) != hipSuccess)
-        return done(fail(kDevice, "hipMalloc(BC7 shard buffers)", hipGetLastError()));
+    // a large shard: its whole granules through the chunked pipeline (upload | kernel | eight per-stream downloads of
+    // consecutive chunks overlap), its share of the array's tail part -- the last shard only -- afterwards, one shot
+    const uint64_t main_total = total_blocks - total_blocks % 1024;
+    const uint64_t in_main = sh.first >= main_total ? 0 : std::min<uint64_t>(sh.first + sh.count, main_total) - sh.first;
+    int32_t prc = kOk;
+    if (in_main != 0 && pipelined_bc7_shard(sb, dev, inverse, in, out, main_total, sh.first, in_main, &prc)) {
+        if (prc != kOk)
+            return done(prc);
+        const uint64_t tail = sh.count - in_main;   // blocks of the array's tail part
+        if (tail != 0) {
+            const uint8_t* src = in + main_total * 16;
+            uint8_t* dst = out + main_total * 16;
+            e = hipMemcpyAsync(d_a, src, (size_t)tail * 16, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess)
+                e = dxtlt::bc7::launch(inverse, d_a, d_b, tail, st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(dst, d_b, (size_t)tail * 16, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
+            if (e != hipSuccess)
+                return done(fail(kDevice, "BC7 shard tail part", e));
+        }
+        return done(kOk);
+    }
     if (!inverse) {
         e = hipMemcpyAsync(d_a, in + sh.first * 16, bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess)

@@ -623,6 +623,31 @@ int32_t shard_worker(int dev, int32_t format, bool inverse, const uint8_t* in, u
 
 }  // namespace
 
+int32_t dxtlt_host::acquire_shard_buffers(int dev, size_t bytes, ShardBuffers* out)
+{
+    hipError_t err = hipSuccess;
+    ShardCtx* c = shard_ctx_acquire(dev, bytes, &err);
+    if (c == nullptr)
+        return fail(DXTLT_E_DEVICE, "shard stream / buffers", err);
+    *out = ShardBuffers{c->st, c->a, c->b, c};
+    return DXTLT_OK;
+}
+
+void dxtlt_host::release_shard_buffers(const ShardBuffers& sb) { shard_ctx_release(static_cast<ShardCtx*>(sb.handle)); }
+
+bool dxtlt_host::pipelined_bc7_shard(const ShardBuffers& sb, int dev, bool inverse, const uint8_t* in, uint8_t* out,
+                                     uint64_t total_main, uint64_t first, uint64_t count, int32_t* rc)
+{
+    const uint64_t bytes = count * 16;
+    if (bytes < kPipelineMinBytes || g_host_pipeline.load(std::memory_order_relaxed) == 0)
+        return false;
+    const uint64_t chunk = kPipelineChunkOverride ? kPipelineChunkOverride : bytes >= (1ull << 30) ? (64ull << 20) : (32ull << 20);
+    PipeJob j{dev, sb.stream, sb.a, sb.b, 7, inverse, in, out, total_main, first, count, 0, false, false, 0, chunk};
+    *rc = pipelined_range(j);
+    return true;
+}
+
+
 extern "C" {
 
 // ---- host pointers ------------------------------------------------------------------------------

@@ -35,6 +35,22 @@ int32_t acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* st
 // pipeline of the BC1-3 host path.  Returns false when the buffer is below the pipeline's threshold (nothing done).
 bool pipelined_bc7_main(bool inverse, const uint8_t* in, uint8_t* out, uint64_t main_blocks, int32_t* rc);
 
+// Per-device shard contexts of the sharded entry points (a stream and two device buffers of at least `bytes`), kept
+// across calls; the calling thread has made `dev` current.  release_shard_buffers hands the context back (the stream
+// must be drained).
+struct ShardBuffers {
+    hipStream_t stream;
+    void* a;
+    void* b;
+    void* handle;
+};
+int32_t acquire_shard_buffers(int dev, size_t bytes, ShardBuffers* out);
+void release_shard_buffers(const ShardBuffers& sb);
+// Blocks [first, first + count) of the main part (total_main blocks, whole granules) of a BC7 host array through the
+// chunked pipeline on the shard's buffers; false = below the pipeline's threshold (nothing done).
+bool pipelined_bc7_shard(const ShardBuffers& sb, int dev, bool inverse, const uint8_t* in, uint8_t* out, uint64_t total_main,
+                         uint64_t first, uint64_t count, int32_t* rc);
+
 // Enqueue one whole-buffer transform on device pointers.
 int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
                 bool split_alpha, bool split_colour, hipStream_t stream, uint8_t normalize = 0);
