@@ -576,9 +576,14 @@ def test_sharded_entry_point_many_shards_pipelined(pkg, oracle, dev, fmt, shards
     want = np.empty_like(x)
     oracle.run_mt(fmt, x, want, 1, True, True, False, 8)
     assert np.array_equal(y, want)
+    # the per-device shard contexts (stream + buffers) are kept across calls; releasing them in between must not matter
+    pkg.load().dxtlt_release_thread_resources()
     z = np.zeros_like(x)
     pkg.transform_sharded(fmt, True, y, z, st, shards)
     assert np.array_equal(z, x)
+    y2 = np.zeros_like(x)
+    pkg.transform_sharded(fmt, False, x, y2, st, max(1, shards - 1))      # reuse with another shard size
+    assert np.array_equal(y2, want)
 
 
 def test_sharded_entry_point_on_every_visible_device(pkg, oracle, dev):
