@@ -10,11 +10,13 @@ import torch  # noqa: E402
 import dxt_lossless_transform_amd as pkg  # noqa: E402
 
 extra = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+force = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0      # experiment switches of dxtlt_set_tuning (0x100: identity tile order)
 n = (1 << 26) + extra
 x = torch.empty(16 * n, dtype=torch.uint8, device="cuda:0")
 pkg.fill_splitmix64(x, 3)
 y = torch.empty_like(x)
 z = torch.empty_like(x)
+pkg.set_tuning(0, force)
 for _ in range(3):
     pkg.transform_bc3_with_settings(x, y)
     pkg.untransform_bc3_with_settings(y, z)
