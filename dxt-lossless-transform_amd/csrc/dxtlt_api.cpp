@@ -794,7 +794,7 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
     g_xcd_remap.store((force_generic & 0x100) ? 0 : (force_generic & 0x200) ? 1 : -1);
 }
 
-const char* dxtlt_version(void) { return "dxtlt-gfx950 0.1.0"; }
+const char* dxtlt_version(void) { return "dxtlt-gfx950 0.2.0"; }
 
 void dxtlt_release_thread_resources(void)
 {
