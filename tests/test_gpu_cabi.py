@@ -241,7 +241,7 @@ def test_parallel_estimator_calls_once_per_distinct_section_and_concurrently(lib
     est, zlib_c = made
     fmt = FMT[n]
     out = CORE_S[n]()
-    x = np.tile(payload(fmt), 64)                     # 2-4 MiB: long enough estimator calls to overlap
+    x = np.tile(payload(fmt), 512)                    # 16-32 MiB: estimator calls of milliseconds, long enough to overlap
     results = {}
     for use_all in (False, True):
         for threads in (1, 6):
@@ -257,7 +257,20 @@ def test_parallel_estimator_calls_once_per_distinct_section_and_concurrently(lib
         candidates = (8 if use_all else 4) if n != 3 else (16 if use_all else 8)
         assert seq[1] == candidates * (2 if n == 3 else 1) and seq[2] == 1
         assert par[1] == (8 if use_all else 4) + (2 if n == 3 else 0)  # distinct sections only
-        assert par[2] > 1                                              # and they did overlap
+        # and they did overlap (threads start tens of microseconds apart, every call takes milliseconds); a loaded box
+        # gets two more tries before this is called a failure
+        overlap = par[2]
+        for _ in range(2):
+            if overlap > 1:
+                break
+            estimator_threads(6)
+            zlib_c.zest_reset()
+            y = np.zeros_like(x)
+            r = getattr(lib, f"dltbc{n}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                             cabi.AutoSettings(use_all), C.byref(out))
+            assert r.ErrorCode == 0
+            overlap = zlib_c.zest_max_concurrency()
+        assert overlap > 1
 
 
 def test_parallel_estimator_reports_estimator_failures(lib, pkg, estimator_threads):
