@@ -831,7 +831,12 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint6
         base[s] = s < S.n ? S.off[s] * (T + H) + kHaloPad * s + sh.d[s] + S.width[s] * H : 0;
 
     const uint8_t* tile_aos = aos + tile * 4096;
-    const u32x4 q = gload16(tile_aos + t * 16);
+    // TEMPORAL load (no `nt`): the tile's last blocks are read a second time, as the next tile's halo, by a workgroup on
+    // another XCD; a line fetched with `nt` is gone by then and comes from HBM again (PMC: 1.25 x the algorithmic read with
+    // a 63-block halo), a line fetched temporally is still in the memory-side cache.  Found by accident -- the compiler
+    // merged an experiment's two loads and dropped the hint -- and worth 0.05-0.07 of peak on large halos
+    // (profiles/r02_b_shift_probe.txt); on small halos it costs nothing.
+    const u32x4 q = *reinterpret_cast<const u32x4*>(tile_aos + t * 16);
     // Only the blocks that have bytes inside a window are fetched: max over the streams of ceil(d_s / w_s) blocks, at
     // most 16 (the whole halo costs 0.02 of peak on BC3 -- 6 % more bytes read -- profiles/r02_b_shift_probe.txt).
     // skip_partial: timing experiment (wrong output)
@@ -1462,12 +1467,10 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         shh.line_policy = (force_bits & 0x800) ? 1 : 3;
         const int per_vec = 16 / fmt_block(fmt);
         shh.halo_vecs = (halo_blocks + per_vec - 1) / per_vec;
-        // The halo is read again by the next tile.  In the identity order that tile runs on another XCD: the re-read comes
-        // from HBM, and a halo of h vectors costs h * 16 / 4096 of extra traffic -- up to 25 % for BC3's one-byte streams
-        // (0.80 of peak falls to 0.72).  In the XCD-contiguous order the neighbour's L2 still holds those lines and the rate
-        // is 0.765 whatever the halo -- but that order itself costs 0.035.  Measured crossover (profiles/r02_b): 24 vectors.
-        const bool big_halo = shh.halo_vecs * 16 * 11 > 4096;
-        shh.xcd_remap = remap_override >= 0 ? remap_override : (big_halo ? 1 : 0);
+        // The halo is read again by the next tile, which runs on another XCD in the identity order: the kernel's temporal
+        // loads keep those lines in the memory-side cache for it, so the identity order (0.035 faster by itself than the
+        // XCD-contiguous one) is right for every halo size.
+        shh.xcd_remap = remap_override >= 0 ? remap_override : 0;
     }
     if (num_tiles > 0) {
         if (use_halo)

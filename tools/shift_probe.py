@@ -24,8 +24,8 @@ for fmt, B in (("bc3", 16), ("bc1", 8)):
                             ("odd", base + 1, 0), ("odd_first_form_partial_segments", base + 1, 0x400), ("odd_no_halo_load_WRONG_OUTPUT", base + 1, 0x10), ("odd_nt_stores_only", base + 1, 0x800), ("aligned128_forced_shift_no_halo_load", base, 2 | 0x10), ("aligned128_forced_shift_nt_only", base, 2 | 0x800), ("odd_generic_lds", base + 1, 0x20), ("odd_no_xcd_remap", base + 1, 0x100),
                             ("odd_no_line_policy", base + 1, 0x40), ("odd_plain_shared_lines", base + 1, 0x80),  ("odd_without_partial_segments_WRONG_OUTPUT", base + 1, 0x10), ("odd3", base + 3, 0), ("plus8", base + 8, 0),
                             ("plus24", base + 24, 0), ("plus40", base + 40, 0), ("plus63", base + 63, 0),
-                            ("plus24_xcd_contiguous", base + 24, 0x200), ("plus40_identity_order", base + 40, 0x100), ("plus63_identity_order", base + 63, 0x100),
-                            ("odd3_xcd_contiguous", base + 3, 0x200)):
+                            ("plus24_xcd_contiguous", base + 24, 0x200), ("plus40_identity_order", base + 40, 0x100), ("plus63_identity_order", base + 63, 0x100), ("plus8_identity_order", base + 8, 0x100),
+                            ("odd3_xcd_contiguous", base + 3, 0x200), ("plus63_xcd_contiguous", base + 63, 0x200), ("odd_identity_order", base + 1, 0x100)):
         x = torch.empty(n * B, dtype=torch.uint8, device=dev); pkg.fill_splitmix64(x, 1)
         y = torch.empty_like(x); z = torch.empty_like(x)
         pkg.set_tuning(0, force)
