@@ -34,6 +34,7 @@ constexpr int kSlots = 4;
 
 struct TableSlot {
     void* host = nullptr;
+    void* host_mapped = nullptr;   // the device-side address of `host`
     void* dev = nullptr;
     size_t cap = 0;
     hipEvent_t done = nullptr;
@@ -88,7 +89,9 @@ struct TableRing {
             s.host = s.dev = nullptr;
             s.cap = 0;
             const size_t want = bytes + bytes / 2 + 4096;
-            e = hipHostMalloc(&s.host, want, hipHostMallocDefault);
+            e = hipHostMalloc(&s.host, want, hipHostMallocMapped);
+            if (e == hipSuccess)
+                e = hipHostGetDevicePointer(&s.host_mapped, s.host, 0);
             if (e == hipSuccess)
                 e = hipMalloc(&s.dev, want);
             if (e != hipSuccess)
@@ -101,6 +104,17 @@ struct TableRing {
 };
 
 thread_local TableRing g_ring;
+
+// DXTLT_BATCH_TABLE_COPY=1: the table travels by hipMemcpyAsync (the first version; kept for the comparison in
+// profiles/r02_m_batch_kernel.txt)
+const bool kTableByCopyEngine = std::getenv("DXTLT_BATCH_TABLE_COPY") != nullptr && std::getenv("DXTLT_BATCH_TABLE_COPY")[0] == '1';
+
+hipError_t upload_table(TableSlot* slot, size_t bytes, hipStream_t stream)
+{
+    if (kTableByCopyEngine)
+        return hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, stream);
+    return dxtlt::launch_table_upload(slot->host_mapped, slot->dev, bytes, stream);
+}
 
 }  // namespace
 
@@ -148,7 +162,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             continue;
         const size_t coarse_n = ((size_t)wgs + 63) / 64;
         const size_t entry_bytes = entries.size() * sizeof(dxtlt::bc7::BatchEntry), tail_bytes = tails.size() * sizeof(dxtlt::bc7::BatchEntry);
-        const size_t bytes = entry_bytes + tail_bytes + coarse_n * sizeof(uint32_t);
+        const size_t bytes = (entry_bytes + tail_bytes + coarse_n * sizeof(uint32_t) + 15) & ~(size_t)15;
         TableSlot* slot = nullptr;
         hipError_t e = g_ring.acquire(bytes, &slot);
         if (e != hipSuccess)
@@ -164,7 +178,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             coarse[k] = (uint32_t)cur;
         }
         const uint8_t* d = static_cast<const uint8_t*>(slot->dev);
-        e = hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, user);
+        e = upload_table(slot, bytes, user);
         if (e == hipSuccess)
             e = dxtlt::bc7::launch_batch(inverse != 0, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d),
                                          reinterpret_cast<const uint32_t*>(d + entry_bytes + tail_bytes), (uint32_t)entries.size(),
@@ -215,7 +229,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         const size_t n = g.entries.size();
         const size_t coarse_n = ((size_t)g.wgs + 63) / 64;
         const size_t entry_bytes = (n * sizeof(BatchEntry) + 15) & ~(size_t)15;
-        const size_t bytes = entry_bytes + coarse_n * sizeof(uint32_t);
+        const size_t bytes = (entry_bytes + coarse_n * sizeof(uint32_t) + 15) & ~(size_t)15;
         TableSlot* slot = nullptr;
         hipError_t e = g_ring.acquire(bytes, &slot);
         if (e != hipSuccess)
@@ -229,7 +243,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
                 ++cur;
             coarse[k] = (uint32_t)cur;
         }
-        e = hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, user);
+        e = upload_table(slot, bytes, user);
         if (e == hipSuccess)
             e = dxtlt::launch_batch((dxtlt::Format)(gi / 2 + 1), (gi & 1) != 0, static_cast<const BatchEntry*>(slot->dev),
                                     reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(slot->dev) + entry_bytes),

@@ -278,16 +278,14 @@ __device__ __forceinline__ u32x4 normalize_vector(u32x4 q)
     return q;
 }
 
+// One aligned tile (the body of fwd_tiled / inv_tiled; the batch kernel runs it for buffers whose stream bases are aligned).
+// `lds`: THREADS * 16 bytes.
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
-__global__ void __launch_bounds__(THREADS)
-fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-          int xcd_remap)
+__device__ __forceinline__ void fwd_aligned_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
+                                                 uint64_t total_blocks, uint64_t first_block, uint64_t tile, uint8_t* lds)
 {
     constexpr int T = tile_blocks(FMT, THREADS);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
     const int t = threadIdx.x;
-    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-
     const u32x4 q = normalize_vector<FMT, NORM>(gload16(aos + tile * (THREADS * 16) + t * 16));
     scatter_to_image<FMT, VARIANT, SA, SC, T>(lds, t, q);
     __syncthreads();
@@ -297,20 +295,36 @@ fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t t
 }
 
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
-          int xcd_remap)
+__device__ __forceinline__ void inv_aligned_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
+                                                 uint64_t total_blocks, uint64_t first_block, uint64_t tile, uint8_t* lds)
 {
     constexpr int T = tile_blocks(FMT, THREADS);
-    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
     const int t = threadIdx.x;
-    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-
     const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
     lds_at<u32x4>(lds, t * 16) = gload16(soa + o);
     __syncthreads();
     const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC, T>(lds, t);
     gstore16_aos(aos, aos + tile * (THREADS * 16) + t * 16, q);
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
+__global__ void __launch_bounds__(THREADS)
+fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
+          int xcd_remap)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
+    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    fwd_aligned_tile<FMT, VARIANT, SA, SC, THREADS, NORM>(aos, soa, total_blocks, first_block, tile, lds);
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
+          int xcd_remap)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
+    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    inv_aligned_tile<FMT, VARIANT, SA, SC, THREADS>(soa, aos, total_blocks, first_block, tile, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -810,18 +824,17 @@ __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, co
         __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
 }
 
+// one halo tile; `lds`: halo_lds_bytes<FMT>() bytes
 template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
-__global__ void __launch_bounds__(256)
-fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-               Shifts sh)
+__device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
+                                              uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
+                                              uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256);
     constexpr int H = kHaloBlocks;
     constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors at most: 64 (BC2 / BC3) or 32 (BC1)
-    __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
     const int t = threadIdx.x;
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     const uint64_t blk0 = first_block + tile * T;
     // region of stream s: starts at off_s * (T + H) + 64 * s (16-byte aligned), holds the records of blocks
     // [blk0 - H, blk0 + T) from byte d_s on (d_s = 0..63); base[s] = address of the record of the tile's block 0
@@ -860,6 +873,16 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint6
     case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, first_tile, gb, sh); break;
     default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, first_tile, gb, sh); break;
     }
+}
+
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
+__global__ void __launch_bounds__(256)
+fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
+               Shifts sh)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
+    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    fwd_halo_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
 
 // one shifted tile, inverse
@@ -1146,8 +1169,8 @@ struct BatchView {
     uint8_t* dst;
     uint64_t blocks;
     uint32_t first_wg, tile_wgs;
-    uint32_t flags;       // variant | split_alpha << 8 | split_colour << 16
-    uint32_t shifts[2];   // shift[0..3], shift[4..5]
+    uint32_t flags;       // variant | split_alpha << 8 | split_colour << 16 | form << 24
+    uint32_t shifts[2];   // shift[0..3], shift[4..5] | halo_vecs << 16
 };
 
 __device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
@@ -1170,11 +1193,46 @@ __device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
 static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, variant) == 32 && offsetof(BatchEntry, shift) == 36,
               "load_batch_entry reads BatchEntry by dword offsets");
 
+// BatchEntry::form
+constexpr uint32_t kBatchAligned = 1, kBatchHalo = 2;   // 0: shifted tiles, first form
+
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
 __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, uint8_t* lds)
 {
     constexpr uint64_t T = tile_blocks(FMT, 256);
-    if (local < en.tile_wgs) {
+    const uint32_t form = en.flags >> 24;
+    if constexpr (!INVERSE) {
+        if (form == kBatchHalo) {
+            // stream bases off their lines, forward: halo tiles in launch order (as the single-buffer call), then one
+            // workgroup for the records of the first 64 blocks and the rest for everything behind the last window
+            if (local < en.tile_wgs) {
+                Shifts sh;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 63u);
+                sh.xcd_remap = 0;
+                sh.line_policy = 3;
+                sh.skip_partial = 0;
+                sh.natural = 1;
+                sh.halo_vecs = (int)(en.shifts[1] >> 16) & 0xFF;
+                fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+            } else if (local == en.tile_wgs) {
+                generic_block<FMT, VARIANT, SA, SC, false>(en.src, en.dst, en.blocks, 0, 0, kHaloBlocks, threadIdx.x);
+            } else {
+                const uint64_t done = (uint64_t)en.tile_wgs * T - kHaloBlocks;
+                generic_block<FMT, VARIANT, SA, SC, false>(en.src, en.dst, en.blocks, 0, done, en.blocks - done,
+                                                           (uint64_t)(local - en.tile_wgs - 1) * 256 + threadIdx.x);
+            }
+            return;
+        }
+    }
+    if (local < en.tile_wgs && form == kBatchAligned) {
+        // every stream base on a 128-byte line: the aligned tile, tiles in launch order (as the single-buffer call runs it)
+        if constexpr (INVERSE)
+            inv_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+        else
+            fwd_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+    } else if (local < en.tile_wgs) {
         Shifts sh;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -1217,13 +1275,18 @@ template <int FMT, bool INVERSE>
 __global__ void __launch_bounds__(256)
 batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    constexpr int kLds = (!INVERSE && halo_lds_bytes<FMT>() > kShiftLdsBytes) ? halo_lds_bytes<FMT>() : kShiftLdsBytes;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
     const uint32_t wg = blockIdx.x;
     // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each
+    // The entry and its successor's first workgroup are fetched together: two dependent scalar loads stand between the
+    // start of the workgroup and its tile's load, not three (a buffer of 64 workgroups or more never takes the loop twice).
     uint32_t e = coarse[wg >> 6];
-    while (e + 1 < n_entries && entries[e + 1].first_wg <= wg)
+    BatchView en = load_batch_entry(entries + e);
+    while (e + 1 < n_entries && entries[e + 1].first_wg <= wg) {
         ++e;
-    const BatchView en = load_batch_entry(entries + e);
+        en = load_batch_entry(entries + e);
+    }
     const uint32_t local = wg - en.first_wg;
     switch (en.flags & 0xFF) {
     case kNone: batch_splits<FMT, kNone, INVERSE>(en, local, lds); break;
@@ -1509,17 +1572,31 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)
 {
     const bool sa = fmt == kBc3 && e.split_alpha;
     const Streams S = make_streams(fmt, sa, e.split_colour != 0);
-    const void* aos = inverse ? (const void*)e.dst : (const void*)e.src;
     const void* soa = inverse ? (const void*)e.src : (const void*)e.dst;
-    for (int i = 0; i < 6; ++i)
-        e.shift[i] = i < S.n ? (uint8_t)((reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * e.blocks) & 15) : 0;
-    const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
     // any AoS alignment: unaligned 16-byte vector accesses are exact and cheap on gfx950 (launch_transform)
-    (void)aos;
+    const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
     const uint64_t tiles = e.blocks / T;
-    const uint64_t tail_wgs = (e.blocks - tiles * T + 255) / 256;
+    // The same three tile forms as launch_transform: aligned tiles when every stream base is on a 128-byte line; forward,
+    // otherwise, halo tiles (windows moved back to a 64-byte boundary; needs naturally aligned shifts, which an 8-byte
+    // aligned pointer gives); the first shifted form for the rest.
+    bool on_lines = true;
+    int d64[6] = {0, 0, 0, 0, 0, 0}, halo_blocks = 0;
+    for (int i = 0; i < S.n; ++i) {
+        const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * e.blocks;
+        d64[i] = (int)(base & 63);
+        on_lines = on_lines && (base & 127) == 0;
+        halo_blocks = std::max(halo_blocks, (d64[i] + S.width[i] - 1) / S.width[i]);
+    }
+    const bool halo = !on_lines && !inverse && tiles > 0 && shifts_are_natural(S, d64);
+    e.form = on_lines ? 1 : halo ? 2 : 0;
+    for (int i = 0; i < 6; ++i)
+        e.shift[i] = (uint8_t)(halo ? d64[i] : d64[i] & 15);
+    const int per_vec = 16 / fmt_block(fmt);
+    e.halo_vecs = halo ? (uint8_t)((halo_blocks + per_vec - 1) / per_vec) : 0;
     e.tile_wgs = (uint32_t)tiles;
-    return (uint32_t)(tiles + tail_wgs);
+    if (halo)   // one workgroup for the first 64 blocks, then the element path from 64 blocks before the end of the tiles
+        return (uint32_t)(tiles + 1 + (e.blocks - tiles * T + kHaloBlocks + 255) / 256);
+    return (uint32_t)(tiles + (e.blocks - tiles * T + 255) / 256);
 }
 
 hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
@@ -1535,6 +1612,29 @@ hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, c
     default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries);
+    return hipGetLastError();
+}
+
+// Table upload by a kernel: the lanes read the pinned host table over PCIe and write the device twin.  A copy engine
+// transfer in front of the batch kernel costs the stream two queue hand-overs (20-90 us measured per call, more than a
+// quarter of a 1 GiB batch's kernel time); kernel after kernel on one queue is a barrier bit.
+__global__ void __launch_bounds__(256)
+table_upload_kernel(const u32x4* __restrict__ host, u32x4* __restrict__ dev, uint32_t vectors)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < vectors; i += gridDim.x * 256)
+        dev[i] = host[i];
+}
+
+hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0)
+        return hipSuccess;
+    if ((bytes & 15) != 0 || bytes > (size_t(1) << 31))
+        return hipErrorInvalidValue;
+    const uint32_t vectors = (uint32_t)(bytes / 16);
+    const uint32_t grid = std::min<uint32_t>((vectors + 255) / 256, 64);
+    hipLaunchKernelGGL(table_upload_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const u32x4*>(host_mapped),
+                       static_cast<u32x4*>(dev), vectors);
     return hipGetLastError();
 }
 

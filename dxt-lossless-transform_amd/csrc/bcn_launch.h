@@ -87,9 +87,11 @@ struct BatchEntry {
     uint64_t blocks;
     uint32_t first_wg;
     uint32_t tile_wgs;
-    uint8_t variant, split_alpha, split_colour, reserved;
-    uint8_t shift[6];       // misalignment (mod 16) of every stream base
-    uint8_t reserved2[2];
+    uint8_t variant, split_alpha, split_colour;
+    uint8_t form;           // 0: shifted tiles, 1: aligned tiles, 2: forward halo tiles; filled by plan_batch_entry
+    uint8_t shift[6];       // misalignment of every stream base: mod 16, halo tiles mod 64
+    uint8_t halo_vecs;      // halo tiles: 16-byte vectors of blocks in front of a tile that have bytes in its windows
+    uint8_t reserved2;
 };
 static_assert(sizeof(BatchEntry) == 48, "BatchEntry layout is shared between host and device");
 
@@ -99,6 +101,10 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e);
 
 // d_entries / d_coarse: device copies of the entry table and of the coarse index (coarse[k] = index of the entry that
 // owns workgroup 64 * k), total_wgs = first_wg + workgroups of the last entry.
+// Copies a table of `bytes` (a multiple of 16) from mapped pinned host memory (its device-side address) to device memory
+// with a small kernel on `stream` -- no copy-engine hand-over in front of the batch kernel.
+hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes, hipStream_t stream);
+
 hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
                         uint32_t total_wgs, hipStream_t stream);
 

@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--batch-only", action="store_true", help="batch cases only")
     args = ap.parse_args()
     pkg.load()
     dev = torch.device("cuda:0")
@@ -194,7 +195,7 @@ def main():
             case += 1
             continue
         pick = int(rng.integers(0, 16))
-        is7, is_batch = pick < 4, pick == 15
+        is7, is_batch = pick < 4 and not args.batch_only, pick == 15 or args.batch_only
         ok, tag = (batch_case if is_batch else bc7_case if is7 else bcn_case)(case, rng, dev)
         counts["batch" if is_batch else ("bc7" if is7 else "bcn") + ("_ranged" if tag["ranged"] else "")] += 1
         if not ok:
