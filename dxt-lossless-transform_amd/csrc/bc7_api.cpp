@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstring>
+
 #include "bc7_launch.h"
 #include "host_common.h"
 
@@ -27,9 +29,25 @@ int32_t host_call(bool inverse, const uint8_t* in, uint8_t* out, size_t len)
             return prc;
         return host_call(inverse, in + main_blocks * 16, out + main_blocks * 16, (size_t)((blocks - main_blocks) * 16));
     }
+    // small buffers: the kernel reads and writes mapped pinned staging itself (no copy-engine hand-overs)
+    MappedStaging m;
+    int32_t rc = acquire_mapped_staging(len, &m);
+    if (rc != kOk)
+        return rc;
+    if (m.usable) {
+        std::memcpy(m.h_in, in, len);
+        hipError_t e = dxtlt::bc7::launch(inverse, m.d_in, m.d_out, len / 16, m.stream);
+        const hipError_t drained = hipStreamSynchronize(m.stream);
+        if (e == hipSuccess)
+            e = drained;
+        if (e != hipSuccess)
+            return fail(kDevice, "BC7 transform", e);
+        std::memcpy(out, m.h_out, len);
+        return kOk;
+    }
     void *d_in = nullptr, *d_out = nullptr;
     hipStream_t st = nullptr;
-    int32_t rc = acquire_staging(len, &d_in, &d_out, &st);
+    rc = acquire_staging(len, &d_in, &d_out, &st);
     if (rc != kOk)
         return rc;
     hipError_t e = hipMemcpyAsync(d_in, in, len, hipMemcpyHostToDevice, st);

@@ -162,6 +162,48 @@ struct HostCtx {
 
 thread_local HostCtx g_host_ctx;
 
+// Small host buffers: a pair of MAPPED pinned staging buffers per thread.  The caller's bytes are copied in by the CPU,
+// the kernel reads them over PCIe and writes its result straight into the second buffer, the CPU copies that out: one
+// launch and one wait, no copy-engine transfers (each of which is a queue hand-over of its own; a 64 KiB call through
+// two hipMemcpyAsync is 37-39 us).  Used up to kMappedMaxBytes (DXTLT_MAPPED_MAX_BYTES; 0 turns it off).
+struct MappedPair {
+    int device = -1;
+    void* h_in = nullptr;
+    void* h_out = nullptr;
+    void* d_in = nullptr;   // device-side addresses of the two host buffers
+    void* d_out = nullptr;
+    size_t cap = 0;
+
+    ~MappedPair() { release(); }
+    void release()
+    {
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        h_in = h_out = d_in = d_out = nullptr;
+        cap = 0;
+        device = -1;
+    }
+    hipError_t reserve(int dev, size_t bytes)
+    {
+        if (dev == device && bytes <= cap)
+            return hipSuccess;
+        release();
+        const size_t want = std::max<size_t>(bytes, 64u << 10);
+        hipError_t e = hipHostMalloc(&h_in, want, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(&h_out, want, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d_in, h_in, 0);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d_out, h_out, 0);
+        if (e != hipSuccess) {
+            release();
+            return e;
+        }
+        device = dev;
+        cap = want;
+        return hipSuccess;
+    }
+};
+thread_local MappedPair g_mapped;
+
 // ---------------------------------------------------------------------------------------------------
 // Chunked host path: H2D of chunk k+1, the kernel of chunk k and D2H of chunk k-1 overlap.
 // Copies from/to pageable host memory block the calling thread while the runtime stages them, so the two
@@ -184,6 +226,10 @@ size_t env_bytes(const char* name, size_t fallback)
 // ~150 us per chunk and only wins from ~100 MiB up (16 MiB chunks: 32 / 36 / 38 GiB/s at 128 / 256 / 512 MiB; 32 MiB
 // chunks: 40-42 GiB/s from 512 MiB up).
 const size_t kPipelineMinBytes = env_bytes("DXTLT_PIPELINE_MIN_BYTES", 96u << 20);
+// Up to 1 MiB the mapped staging pair wins (tools/host_path_latency.py: 4 KiB 30 -> 17 us per call, 64 KiB 37 -> 20,
+// 256 KiB 52 -> 34, 1 MiB 120 -> 101; at 4 MiB it loses, 347 against 194: lanes reading host memory reach ~12 GiB/s
+// where the copy engines reach 25).
+const size_t kMappedMaxBytes = env_bytes("DXTLT_MAPPED_MAX_BYTES", 1u << 20);
 const uint64_t kPipelineChunkOverride = env_bytes("DXTLT_PIPELINE_CHUNK_BYTES", 0) & ~(uint64_t)0xFFFF;
 // Chunk size.  BC3's six streams include two of a sixteenth of the data each: with 16 MiB chunks their downloads are
 // 1 MiB copies and the pipeline falls to 22-30 GiB/s between 256 MiB and 1 GiB; 32 MiB chunks give 35-40 there
@@ -397,6 +443,21 @@ int32_t dxtlt_host::acquire_staging(size_t bytes, void** d_in, void** d_out, hip
     return DXTLT_OK;
 }
 
+int32_t dxtlt_host::acquire_mapped_staging(size_t bytes, MappedStaging* out)
+{
+    out->usable = false;
+    if (bytes > kMappedMaxBytes)
+        return DXTLT_OK;
+    HostCtx& c = g_host_ctx;
+    int32_t rc = c.prepare(0);   // device and stream only
+    if (rc != DXTLT_OK)
+        return rc;
+    MappedPair& m = g_mapped;
+    HIP_TRY(m.reserve(c.device, bytes), "hipHostMalloc(mapped staging)");
+    *out = MappedStaging{true, m.h_in, m.h_out, m.d_in, m.d_out, c.stream};
+    return DXTLT_OK;
+}
+
 int32_t dxtlt_host::enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
                             bool sa, bool sc, hipStream_t stream, uint8_t normalize)
 {
@@ -412,10 +473,24 @@ int32_t dxtlt_host::transform(int32_t format, bool inverse, const uint8_t* in, u
     if (len == 0)
         return DXTLT_OK;  // zero blocks: nothing to do, no device needed
     HostCtx& c = g_host_ctx;
+    const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
+    MappedStaging m;
+    rc = acquire_mapped_staging(len, &m);
+    if (rc != DXTLT_OK)
+        return rc;
+    if (m.usable) {
+        std::memcpy(m.h_in, in, len);
+        rc = device_range(format, inverse, m.d_in, m.d_out, blocks, 0, blocks, mode, sa, sc, m.stream, normalize);
+        const hipError_t drained = hipStreamSynchronize(m.stream);
+        if (rc != DXTLT_OK)
+            return rc;
+        HIP_TRY(drained, "stream synchronize");
+        std::memcpy(out, m.h_out, len);
+        return DXTLT_OK;
+    }
     rc = c.prepare(len);
     if (rc != DXTLT_OK)
         return rc;
-    const uint64_t blocks = len / (size_t)dxtlt::block_bytes((Format)format);
     if (len >= kPipelineMinBytes && g_host_pipeline.load(std::memory_order_relaxed) != 0)
         return pipelined_transform(c, format, inverse, in, out, blocks, mode, sa, sc, normalize);
     // Every failure exit drains the stream first: the staging buffers belong to this thread's next call, which may
@@ -799,6 +874,7 @@ const char* dxtlt_version(void) { return "dxtlt-gfx950 0.2.0"; }
 void dxtlt_release_thread_resources(void)
 {
     g_host_ctx.release();
+    g_mapped.release();
     shard_pool_clear();   // process-wide: the idle per-device contexts of dxtlt_transform_sharded
     dxtlt_host::release_bc7_thread_scratch();
     dxtlt_host::release_normalize_thread_flag();

@@ -31,6 +31,19 @@ int32_t transform(int32_t format, bool inverse, const uint8_t* in, uint8_t* out,
 // This thread's staging context on the current device: two device buffers of at least `bytes` and a stream.
 int32_t acquire_staging(size_t bytes, void** d_in, void** d_out, hipStream_t* stream);
 
+// Small host buffers (up to 1 MiB, DXTLT_MAPPED_MAX_BYTES): the calling thread's pair of MAPPED pinned staging buffers
+// (h_*: host addresses, d_*: the same memory as the device sees it) and its stream; usable == false above the limit.
+// The caller copies its input to h_in, launches on d_in -> d_out, waits for the stream and copies h_out out.
+struct MappedStaging {
+    bool usable;
+    void* h_in;
+    void* h_out;
+    void* d_in;
+    void* d_out;
+    hipStream_t stream;
+};
+int32_t acquire_mapped_staging(size_t bytes, MappedStaging* out);
+
 // Large BC7 host buffers: the main part (whole 1024-block granules) through the chunked upload | kernel | download
 // pipeline of the BC1-3 host path.  Returns false when the buffer is below the pipeline's threshold (nothing done).
 bool pipelined_bc7_main(bool inverse, const uint8_t* in, uint8_t* out, uint64_t main_blocks, int32_t* rc);

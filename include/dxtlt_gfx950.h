@@ -195,7 +195,8 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path);
 /* "dxtlt-gfx950 <version>" */
 const char *dxtlt_version(void);
 /* The host-pointer entry points keep, per calling thread and device, one stream and a grow-only pair of staging
- * buffers (so that file-after-file callers pay allocation once).  This frees the calling thread's set -- and, process-
+ * buffers (so that file-after-file callers pay allocation once), and for buffers of up to 1 MiB a pair of mapped pinned
+ * host buffers that the kernel reads and writes directly.  This frees the calling thread's set -- and, process-
  * wide, the idle per-device stream + buffer sets that dxtlt_transform_sharded and the BC7 sharded entry points keep
  * across calls (sets in use by a call in flight are left alone). */
 void dxtlt_release_thread_resources(void);

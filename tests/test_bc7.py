@@ -221,7 +221,8 @@ def test_gpu_real_bc7_texture(bc7, oracle):
 
 @pytest.mark.gpu
 def test_host_pointer_entry_points(pkg, bc7, oracle):
-    for n in (0, 1, 1500, 70_001):
+    # up to 1 MiB (65 536 blocks) through the mapped staging pair, above it by two copies
+    for n in (0, 1, 1500, 65_535, 65_536, 65_537, 70_001):
         x = make_blocks(oracle, n, "skewed", n)
         y = np.zeros_like(x)
         bc7.transform_bc7(x, y)

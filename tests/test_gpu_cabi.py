@@ -53,6 +53,28 @@ def test_core_transform_untransform(lib, oracle, n):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3])
+def test_host_buffers_either_side_of_the_mapped_staging_limit(lib, oracle, n):
+    """host pointers: up to 1 MiB the kernel reads and writes mapped pinned staging buffers itself, above that the buffer
+    travels by two copies (and from 96 MiB by the chunked pipeline, tests/test_gpu_parity.py); same bytes either way, odd
+    block counts and a misaligned caller buffer included"""
+    fmt = FMT[n]
+    B = BLOCK[fmt]
+    s = list(all_settings(fmt))[-1]
+    st = core_settings(n, s)
+    for nbytes in (B, (1 << 20) - B, 1 << 20, (1 << 20) + B, (3 << 20) + 5 * B):
+        buf = np.zeros(nbytes + 1, dtype=np.uint8)
+        x = buf[1:]                                # the caller's input at an odd address
+        x[:] = oracle.fill_splitmix64(nbytes, 0x51 + n)
+        y = np.full(nbytes + 16, 0xEE, dtype=np.uint8)
+        r = getattr(lib, f"dltbc{n}core_transform")(x.ctypes.data, x.size, y.ctypes.data, nbytes, st)
+        assert r.ErrorCode == 0
+        assert np.array_equal(y[:nbytes], oracle.transform(fmt, x, s[0], s[2], s[1])) and (y[nbytes:] == 0xEE).all()
+        z = np.full(nbytes + 16, 0xDD, dtype=np.uint8)
+        r = getattr(lib, f"dltbc{n}core_untransform")(y.ctypes.data, nbytes, z.ctypes.data, nbytes, st)
+        assert r.ErrorCode == 0 and np.array_equal(z[:nbytes], x) and (z[nbytes:] == 0xDD).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
 def test_stable_manual_builder(lib, oracle, n):
     fmt = FMT[n]
     p = f"dltbc{n}_"

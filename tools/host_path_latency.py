@@ -17,7 +17,7 @@ from oracle import oracle_c  # noqa: E402
 pkg.load()
 st = pkg.Bc1TransformSettings()
 rows = []
-for kib in (64, 256, 1024, 4096, 16384, 65536):
+for kib in [int(k) for k in os.environ.get("LAT_KIB", "64,256,1024,4096,16384,65536").split(",")]:
     n = kib << 10
     x = np.random.default_rng(1).integers(0, 256, n, dtype=np.uint8)
     y = np.empty_like(x)
