@@ -1,7 +1,7 @@
 """Shifted-tile kernels by alignment class of the stream bases (4 GiB, fractions of 8 TB/s on 2*len): which part of the
 odd-block-count cost is the kernel's own structure and which is misalignment.  force bits: 2 = shifted tiles even when
 aligned, 0x20 = generic (switch per access) LDS scatter/gather, 0x40 = no write-through on whole lines, 0x10 = partial segments left out (timing only), 0x100 / 0x200 = XCD-contiguous
-tile order off / on."""
+tile order off / on.  PROBE_ONLY=<substring> selects cases."""
 import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,6 +26,8 @@ for fmt, B in (("bc3", 16), ("bc1", 8)):
                             ("plus24", base + 24, 0), ("plus40", base + 40, 0), ("plus63", base + 63, 0),
                             ("plus24_xcd_contiguous", base + 24, 0x200), ("plus40_identity_order", base + 40, 0x100), ("plus63_identity_order", base + 63, 0x100), ("plus8_identity_order", base + 8, 0x100),
                             ("odd3_xcd_contiguous", base + 3, 0x200), ("plus63_xcd_contiguous", base + 63, 0x200), ("odd_identity_order", base + 1, 0x100)):
+        if os.environ.get("PROBE_ONLY") and os.environ["PROBE_ONLY"] not in label:
+            continue
         x = torch.empty(n * B, dtype=torch.uint8, device=dev); pkg.fill_splitmix64(x, 1)
         y = torch.empty_like(x); z = torch.empty_like(x)
         pkg.set_tuning(0, force)
