@@ -885,14 +885,86 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint6
     fwd_halo_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
 
-// one shifted tile, inverse
-template <int FMT, int VARIANT, bool SA, bool SC, int R = 1>
+// Loads of wave W of an inverse shifted tile: lane t fetches the aligned 16-byte segment that holds image byte 16 t.
+// Which streams a wave's 1 KiB of the image can meet is known at compile time (BC3 with both splits: wave 0 meets the two
+// alpha endpoint streams and the start of the alpha indices, wave 1 the indices only, wave 2 the two colour streams, wave 3
+// the colour indices), so the per-lane select over the streams shrinks to those, and the extra partial last segment of
+// every stream -- lanes 0 .. n-1 -- is wave 0's business alone.  The kernel is bound by its instruction stream (a wave
+// instruction takes the SIMD four cycles: 146 VALU + 114 SALU per wave against 67 + 36 in the aligned tile, PMC,
+// profiles/r02_a_shift_pmc.txt), which is why this matters.
+// A load may fetch the whole aligned segment even when only part of it belongs to this tile's slice: the other bytes land
+// in the stream's LDS padding.  Only a segment that pokes outside the transformed buffer itself (first tile of the first
+// stream, last tile of the last stream) is fetched piecewise.  All loads of the wave are issued before the first wait.
+template <int FMT, bool SA, bool SC, int W>
+__device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ soa, uint8_t* lds, int t,
+                                                    const uint64_t (&gb)[6], const Shifts& sh, uint64_t total_bytes)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
+    const int o = t * 16;
+    int la = 0, k = 0, shift = 0;
+    uint64_t g = 0;
+    static_for<0, S.n>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int lo = S.off[s] * T;
+        constexpr int hi = lo + S.width[s] * T;
+        if constexpr (lo < wave_hi && hi > wave_lo) {
+            constexpr bool only = lo <= wave_lo && hi >= wave_hi;   // the whole wave sits in this stream
+            if (only || (o >= lo && o < hi)) {
+                la = lo + 16 * s + (o - lo);
+                g = gb[s] + (uint64_t)(o - lo);
+                k = (o - lo) >> 4;
+                shift = sh.d[s];
+            }
+        }
+    });
+    // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
+    const bool main_inside = g + 16 <= total_bytes;
+    u32x4 v_main = {0, 0, 0, 0};
+    if (main_inside)
+        v_main = gload16(soa + g);
+    if constexpr (W == 0) {
+        // the extra, partial last segment of stream t (lanes 0..n-1), selected by data, not by control flow
+        int la_t = 0, shift_t = 0;
+        uint64_t g_t = 0;
+#pragma unroll
+        for (int ss = 0; ss < S.n; ++ss) {
+            if (ss == t) {
+                const int bytes = S.width[ss] * T;
+                la_t = S.off[ss] * T + 16 * ss + bytes;
+                shift_t = sh.d[ss];
+                g_t = gb[ss] + bytes;
+            }
+        }
+        const bool has_tail = t < S.n && shift_t > 0;
+        const bool tail_inside = g_t + 16 <= total_bytes;
+        // (Making these two loads branch-free -- every lane also loading a "tail", lanes without one re-reading their main
+        // segment -- cost 0.08 of peak: the second load instruction is not free even when it hits L1.)
+        u32x4 v_tail = {0, 0, 0, 0};
+        if (has_tail && tail_inside)
+            v_tail = gload16(soa + g_t);
+        if (has_tail) {
+            if (tail_inside)
+                lds_at<u32x4>(lds, la_t) = v_tail;
+            else
+                copy_partial_segment<false>(lds + la_t, soa + g_t, 0, shift_t);
+        }
+    }
+    if (main_inside)
+        lds_at<u32x4>(lds, la) = v_main;
+    else
+        copy_partial_segment<false>(lds + la, soa + g, (k == 0) ? shift : 0, (k == 0) ? 16 : shift);
+}
+
+// one shifted tile, inverse; `lds`: kShiftLdsBytes
+template <int FMT, int VARIANT, bool SA, bool SC>
 __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
                                                uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
                                                uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256) * R;
+    constexpr int T = tile_blocks(FMT, 256);
     const int t = threadIdx.x;
     const uint64_t blk0 = first_block + tile * T;
     int base[6];
@@ -900,76 +972,29 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
     for (int s = 0; s < 6; ++s)
         base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
 
-    // Loads may fetch the whole aligned 16-byte segment even when only part of it belongs to this tile's slice: the
-    // other bytes land in the stream's LDS padding.  Only a segment that pokes outside the transformed buffer
-    // itself (first tile of the first stream, last tile of the last stream) is fetched piecewise.  All loads of the
-    // tile are issued before the first wait.
     const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
     uint64_t gb[6];
     slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
-    int k[R], la[R], shift[R];
-    uint64_t g[R];
-    bool main_inside[R];
-    u32x4 v_main[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        int s, nseg;
-        shifted_segment<FMT, SA, SC, T>((t + 256 * j) * 16, gb, sh, s, k[j], la[j], g[j], shift[j], nseg);
-        // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
-        main_inside[j] = g[j] + 16 <= total_bytes;
-        v_main[j] = u32x4{0, 0, 0, 0};
-        if (main_inside[j])
-            v_main[j] = gload16(soa + g[j]);
-    }
-    // the extra, partial last segment of stream t (lanes 0..n-1), selected by data, not by control flow
-    int la_t = 0, shift_t = 0;
-    uint64_t g_t = 0;
-#pragma unroll
-    for (int ss = 0; ss < S.n; ++ss) {
-        if (ss == t) {
-            const int bytes = S.width[ss] * T;
-            la_t = S.off[ss] * T + 16 * ss + bytes;
-            shift_t = sh.d[ss];
-            g_t = gb[ss] + bytes;
-        }
-    }
-    const bool has_tail = t < S.n && shift_t > 0;
-    const bool tail_inside = g_t + 16 <= total_bytes;
-    // (Making these two loads branch-free -- every lane also loading a "tail", lanes without one re-reading their main
-    // segment -- cost 0.08 of peak: the second load instruction is not free even when it hits L1.)
-    u32x4 v_tail = {0, 0, 0, 0};
-    if (has_tail && tail_inside)
-        v_tail = gload16(soa + g_t);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        if (main_inside[j])
-            lds_at<u32x4>(lds, la[j]) = v_main[j];
-        else
-            copy_partial_segment<false>(lds + la[j], soa + g[j], (k[j] == 0) ? shift[j] : 0, (k[j] == 0) ? 16 : shift[j]);
-    }
-    if (has_tail) {
-        if (tail_inside)
-            lds_at<u32x4>(lds, la_t) = v_tail;
-        else
-            copy_partial_segment<false>(lds + la_t, soa + g_t, 0, shift_t);
+    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+    case 0: inv_shift_load_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, total_bytes); break;
+    case 1: inv_shift_load_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, total_bytes); break;
+    case 2: inv_shift_load_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, total_bytes); break;
+    default: inv_shift_load_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, total_bytes); break;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t + 256 * j, base)
-                                   : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t + 256 * j, base);
-        gstore16_aos(aos, aos + tile * (4096 * R) + (t + 256 * j) * 16, q);
-    }
+    const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t, base)
+                               : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t, base);
+    gstore16_aos(aos, aos + tile * 4096 + t * 16, q);
 }
 
-template <int FMT, int VARIANT, bool SA, bool SC, int R = 1>
+template <int FMT, int VARIANT, bool SA, bool SC>
 __global__ void __launch_bounds__(256)
 inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
                 Shifts sh)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[shift_lds_bytes(R)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
     const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    inv_shift_tile<FMT, VARIANT, SA, SC, R>(soa, aos, total_blocks, first_block, sh, tile, lds);
+    inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
