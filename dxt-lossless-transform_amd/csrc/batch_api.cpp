@@ -5,9 +5,11 @@
 // a launch costs the host ~5 us, longer than the kernel runs: measured 186 GiB/s for 1024 x 1 MiB through one call per
 // buffer, even when spread over eight streams (profiles/r01_x).  So a batch becomes ONE launch per (format, direction)
 // present in it: the host lays the buffers' workgroups end to end in a table (48 bytes per buffer plus a coarse
-// workgroup -> buffer index), copies the table to the device on the caller's stream, and launches batch_kernel
-// (bcn_kernels.hip), in which every workgroup looks its buffer up and runs one shifted tile or 256 blocks of the
-// element path with that buffer's settings.  Asynchronous and ordered like a single call on the caller's stream.
+// workgroup -> buffer index), sends the table to the device on the caller's stream (a small kernel reads the mapped
+// pinned slot: no copy-engine hand-over in front of the batch kernel) and launches batch_kernel (bcn_kernels.hip), in
+// which every workgroup looks its buffer up and runs one tile -- aligned, halo or shifted, as the single-buffer call would
+// choose for that buffer -- or 256 blocks of the element path with that buffer's settings.  Asynchronous and ordered like
+// a single call on the caller's stream.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>

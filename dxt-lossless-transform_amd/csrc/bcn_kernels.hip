@@ -1180,8 +1180,9 @@ generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint6
 // ------------------------------------------------------------------------------------------------
 // Batch kernel: many buffers of one format and direction in ONE launch (dxtlt_transform_batch_device).  A texture of
 // a few MiB cannot fill 256 CUs and launching them one by one is bound by the ~5 us a launch costs the host; here
-// every workgroup looks up which buffer it belongs to and runs one shifted tile of it (the shifted-tile body also
-// covers aligned stream bases: shift 0) or, past the buffer's last full tile, 256 blocks of the element path.
+// every workgroup looks up which buffer it belongs to and runs one tile of it -- the aligned tile, a forward halo tile or
+// a shifted tile, whichever launch_transform would choose for that buffer (BatchEntry::form, plan_batch_entry) -- or, past
+// the buffer's last full tile, 256 blocks of the element path.
 // Settings are per buffer, so the variant / split combination is a run-time switch over the instantiated bodies;
 // workgroups of one buffer all take the same case.
 // ------------------------------------------------------------------------------------------------

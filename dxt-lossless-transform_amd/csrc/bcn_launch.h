@@ -79,8 +79,10 @@ hipError_t launch_normalize_bc3_split(void* alpha_endpoints, void* alpha_indices
 
 // ---- batch launch: many buffers of one format and direction in one kernel (bcn_kernels.hip, batch_kernel) --------
 // One entry per buffer, sorted by first_wg (a multiple of 8).  Workgroups [first_wg, first_wg + tile_wgs) run one
-// 256-lane shifted tile each; the workgroups after them (up to the next entry's first_wg) run 256 blocks of the element
-// path each, or nothing once the buffer's blocks are exhausted (padding up to the next multiple of 8).
+// 256-lane tile each, in the form `form` names (the one launch_transform would pick for the buffer); the workgroups after
+// them (up to the next entry's first_wg) run 256 blocks of the element path each -- for halo tiles the first of them takes
+// the buffer's first 64 blocks and the others start 64 blocks before the end of the tiles -- or nothing once the buffer's
+// blocks are exhausted (padding up to the next multiple of 8).
 struct BatchEntry {
     const uint8_t* src;
     uint8_t* dst;
