@@ -111,7 +111,11 @@ class Ranks:
             index = self.local_rank if self.backend == "nccl" else self.local_rank % n
             torch.cuda.set_device(index)
             self.dev = torch.device("cuda", index)
-        if self.world > 1:
+        # Rehearsal knob (never set by the driver): DXTLT_BENCH_FORCE_DIST=1 makes a one-rank job under a launcher go
+        # through the process-group path too, so that the RCCL calls of the N > 1 path (init with device_id, the gloo
+        # side group, barrier, MAX all-reduce of a double on the device) run on a 1-GPU box.
+        force_dist = os.environ.get("DXTLT_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+        if self.world > 1 or force_dist:
             import torch.distributed as dist
 
             self.dist = dist
