@@ -210,7 +210,9 @@ hipError_t launch_normalize_bc1_all_modes(const void* in, void* const out[3], ui
     dim3 grid;
     if (hipError_t e = grid_for(pairs + singles, grid); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(normalize_all_modes_kernel, grid, dim3(kNormThreads), 0, stream,
+    // 16 bytes read and 48 written per lane: six workgroups per CU instead of eight (1 GiB of blocks: 782 -> 696 us;
+    // five 731, four 688, three 1011; profiles/r02_o_wgs_per_cu.txt)
+    hipLaunchKernelGGL(normalize_all_modes_kernel, grid, dim3(kNormThreads), lds_pad_for_wgs_per_cu(wgs_per_cu_or(6), kNormThreads, 0), stream,
                        static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out[0]), static_cast<uint8_t*>(out[1]),
                        static_cast<uint8_t*>(out[2]), pairs, singles, d_any);
     return hipGetLastError();

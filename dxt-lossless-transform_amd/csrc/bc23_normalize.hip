@@ -204,7 +204,10 @@ hipError_t launch_normalize_bc23_all_modes(int fmt, const void* in, void* const*
     if (hipError_t e = grid23(num_blocks, g); e != hipSuccess)
         return e;
     auto k = fmt == 2 ? normalize23_all_modes_kernel<2> : normalize23_all_modes_kernel<3>;
-    hipLaunchKernelGGL(k, g, dim3(kThreads23), 0, stream, static_cast<const uint8_t*>(in), o, num_blocks, vec);
+    // one read, 3 (BC2) or 12 (BC3) copies written per lane: fewer resident workgroups per CU move more (launch_grid.h).
+    // BC2, 1 GiB of blocks: 764 us at eight, 658 at six, 681 / 672 at five / four, 908 at three; BC3, 256 MiB: 700 at eight,
+    // 664 / 680 / 616 at six / five / four, 584 at three (profiles/r02_o_wgs_per_cu.txt)
+    hipLaunchKernelGGL(k, g, dim3(kThreads23), lds_pad_for_wgs_per_cu(wgs_per_cu_or(fmt == 2 ? 6 : 3), kThreads23, 0), stream, static_cast<const uint8_t*>(in), o, num_blocks, vec);
     return hipGetLastError();
 }
 

@@ -101,13 +101,12 @@ decode_blocks_unaligned_kernel(const uint8_t* __restrict__ in, uint8_t* __restri
 // number of blocks whose decoded pixels differ; byte-identical blocks need no decoding.  A fixed grid walks the
 // blocks and every wave adds its total once: one atomic per 64 blocks on one address costs ~12 ns each (measured:
 // 25 ms for 2^27 blocks that all differ), which is slower than the whole read.
-template <int FMT, bool ALIGNED>
+template <int FMT, bool ALIGNED, int U>
 __global__ void __launch_bounds__(kDecThreads)
 pixel_difference_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t num_blocks,
                         unsigned long long* __restrict__ count)
 {
-    // four blocks per lane and step, the eight loads issued before the first compare
-    constexpr int U = 4;
+    // U blocks per lane and step, the 2 U loads issued before the first compare
     unsigned long long mine = 0;   // wave-uniform
     const uint64_t stride = (uint64_t)gridDim.x * (kDecThreads * U);
     for (uint64_t base = (uint64_t)blockIdx.x * (kDecThreads * U); base < num_blocks; base += stride) {
@@ -158,8 +157,14 @@ hipError_t decode_fmt(const void* in, void* out, uint64_t n, hipStream_t stream)
     if (hipError_t e = grid_rows(n, kDecThreads, grid); e != hipSuccess)
         return e;
     const bool fast = aligned_to(in, FMT == 1 ? 8 : 16) && aligned_to(out, 16);
+    // Workgroups per CU, capped with dynamic LDS nobody touches.  A decoder workgroup writes 16 KiB for 2-4 KiB read, and
+    // on this memory system more bytes in flight per CU than it can take LOWER the rate (tools/shape_lab.hip; DESIGN.md
+    // section 9): with the eight workgroups per CU the wave slots allow BC2 / BC3 decode at 0.745 of the HBM peak, with six
+    // at 0.86-0.87 -- the speed of a plain fill -- (five and four: 0.845; seven: 0.82; three: 0.62).  BC1, which reads half
+    // as much per block, is best left at eight (0.80; seven 0.80, six 0.76).  DXTLT_EXPERIMENT_WGS_PER_CU overrides (experiments).
+    const unsigned pad_lds = lds_pad_for_wgs_per_cu(wgs_per_cu_or(FMT == 1 ? 8 : 6), kDecThreads, (unsigned)((kDecThreads / 64) * kWaveStage * 16));
     if (fast)
-        hipLaunchKernelGGL(decode_blocks_kernel<FMT>, grid, dim3(kDecThreads), 0, stream,
+        hipLaunchKernelGGL(decode_blocks_kernel<FMT>, grid, dim3(kDecThreads), pad_lds, stream,
                            static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), n);
     else
         hipLaunchKernelGGL(decode_blocks_unaligned_kernel<FMT>, grid, dim3(kDecThreads), 0, stream,
@@ -170,16 +175,20 @@ hipError_t decode_fmt(const void* in, void* out, uint64_t n, hipStream_t stream)
 template <int FMT>
 hipError_t difference_fmt(const void* a, const void* b, uint64_t n, unsigned long long* count, hipStream_t stream)
 {
-    uint64_t wgs = (n + kDecThreads * 4 - 1) / (kDecThreads * 4);   // four blocks per lane and step
+    // two blocks per lane and step: four loads in flight per lane.  Four blocks (eight loads) were slower on the sparse
+    // case -- BC2 0.673 against 0.697 of peak, BC3 0.626 against 0.666 -- and one block no better (0.667 / 0.652): more bytes
+    // in flight per CU than the memory system likes lower the rate (launch_grid.h)
+    constexpr int kBlocksPerLane = 2;
+    uint64_t wgs = (n + kDecThreads * kBlocksPerLane - 1) / (kDecThreads * kBlocksPerLane);
     if (wgs > kDifferenceGrid)
         wgs = kDifferenceGrid;
     const uintptr_t al = FMT == 1 ? 8 : 16;
     const auto* pa = static_cast<const uint8_t*>(a);
     const auto* pb = static_cast<const uint8_t*>(b);
     if (aligned_to(a, al) && aligned_to(b, al))
-        hipLaunchKernelGGL((pixel_difference_kernel<FMT, true>), dim3((unsigned)wgs), dim3(kDecThreads), 0, stream, pa, pb, n, count);
+        hipLaunchKernelGGL((pixel_difference_kernel<FMT, true, kBlocksPerLane>), dim3((unsigned)wgs), dim3(kDecThreads), 0, stream, pa, pb, n, count);
     else
-        hipLaunchKernelGGL((pixel_difference_kernel<FMT, false>), dim3((unsigned)wgs), dim3(kDecThreads), 0, stream, pa, pb, n, count);
+        hipLaunchKernelGGL((pixel_difference_kernel<FMT, false, kBlocksPerLane>), dim3((unsigned)wgs), dim3(kDecThreads), 0, stream, pa, pb, n, count);
     return hipGetLastError();
 }
 
