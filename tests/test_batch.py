@@ -45,6 +45,41 @@ def test_batch_equals_oracle_item_by_item(pkg, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_batch_runs_every_tile_form(pkg, oracle, fmt):
+    """The batch kernel picks a tile form per buffer (plan_batch_entry): aligned tiles when every stream base sits on a
+    128-byte line, forward halo tiles when not and the output pointer is 8-byte aligned, the first shifted form for the
+    inverse and for outputs at other addresses.  One batch holds all of them, in both directions, with block counts that
+    put the element workgroups of the halo form (the first 64 blocks, the last 64 of the tiles, the rest) to work."""
+    from dxt_lossless_transform_amd import batch
+
+    dev = torch.device("cuda:0")
+    B = pkg.BLOCK_BYTES[fmt]
+    tile = 4096 // B
+    st = settings_for(pkg, fmt, 1, 1, 1)
+    items, expect = [], []
+    cases = [(64 * tile, 0, 0), (64 * tile + 1, 0, 0), (64 * tile - 1, 0, 0), (3 * tile + 65, 0, 8), (3 * tile + 65, 0, 4),
+             (3 * tile + 65, 0, 1), (tile + 63, 16, 0), (tile, 0, 24), (2 * tile - 1, 8, 8), (tile - 1, 0, 0), (65, 0, 8)]
+    for k, (blocks, in_off, out_off) in enumerate(cases):
+        for inverse in (False, True):
+            x = oracle.fill_splitmix64(blocks * B, 0xF0 + k)
+            if inverse:
+                x = oracle.transform(fmt, x, 1, True, True)
+            want = oracle.transform(fmt, x, 1, True, True, inverse=inverse)
+            xd = torch.zeros(x.size + 64, dtype=torch.uint8, device=dev)
+            xd[in_off:in_off + x.size] = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+            yd = torch.full((x.size + 96,), 0x5A, dtype=torch.uint8, device=dev)
+            items.append((fmt, inverse, xd[in_off:in_off + x.size], yd[out_off:out_off + x.size], st))
+            expect.append((want, yd, out_off, x.size))
+    batch.transform_batch(items)
+    torch.cuda.synchronize()
+    for k, (want, yd, off, n) in enumerate(expect):
+        got = yd.cpu().numpy()
+        assert np.array_equal(got[off:off + n], want), (fmt, cases[k // 2], k % 2)
+        assert (got[:off] == 0x5A).all() and (got[off + n:] == 0x5A).all(), (fmt, cases[k // 2], k % 2)
+
+
+@pytest.mark.gpu
 def test_batch_is_ordered_with_the_callers_stream(pkg, oracle):
     """The batch reads what earlier work on the stream produced and later work on the stream sees its output, without
     any synchronisation by the caller."""
