@@ -890,8 +890,9 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint6
 // alpha endpoint streams and the start of the alpha indices, wave 1 the indices only, wave 2 the two colour streams, wave 3
 // the colour indices), so the per-lane select over the streams shrinks to those, and the extra partial last segment of
 // every stream -- lanes 0 .. n-1 -- is wave 0's business alone.  The kernel is bound by its instruction stream (a wave
-// instruction takes the SIMD four cycles: 146 VALU + 114 SALU per wave against 67 + 36 in the aligned tile, PMC,
-// profiles/r02_a_shift_pmc.txt), which is why this matters.
+// instruction takes the SIMD four cycles: the first form ran 146 VALU + 114 SALU per wave against 67 + 36 in the aligned
+// tile, PMC, profiles/r02_a_shift_pmc.txt; with the per-wave loads 69 + 107, r02_b_shift_probe.txt), which is why this
+// matters -- and why what is left of the distance to the aligned tiles is not instructions any more.
 // A load may fetch the whole aligned segment even when only part of it belongs to this tile's slice: the other bytes land
 // in the stream's LDS padding.  Only a segment that pokes outside the transformed buffer itself (first tile of the first
 // stream, last tile of the last stream) is fetched piecewise.  All loads of the wave are issued before the first wait.
