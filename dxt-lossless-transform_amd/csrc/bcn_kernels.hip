@@ -346,7 +346,20 @@ struct Shifts {
     int skip_partial; // timing experiment only (wrong output): 1 = leave out the partial head / tail segments
     int natural;      // 1: every d[s] is a multiple of stream s's element width (always so when the SoA pointer is 8-byte aligned)
     int halo_vecs;    // halo tiles: 16-byte vectors in front of a tile whose blocks have bytes in the tile's windows
+    // offset from the SoA pointer of the aligned segment that holds the first byte of stream s of the RANGE:
+    // off_s * total_blocks + w_s * first_block - d[s] (may be "negative": wraps).  Filled by the host (launch_transform)
+    // or by the batch kernel from its table entry: the tiles then add one multiple of a constant per stream instead of
+    // redoing two 64-bit products and a difference per stream and workgroup on the scalar unit (PMC: 107 scalar
+    // instructions per wave in the inverse shifted tile, 95 in the halo tile, against 36-40 in the aligned tiles).
+    uint64_t gbase[6];
 };
+
+template <typename STREAMS>
+__host__ __device__ inline void fill_gbase(Shifts& sh, const STREAMS& S, uint64_t total_blocks, uint64_t first_block)
+{
+    for (int i = 0; i < 6; ++i)
+        sh.gbase[i] = i < S.n ? (uint64_t)S.off[i] * total_blocks + (uint64_t)S.width[i] * first_block - (uint64_t)sh.d[i] : 0;
+}
 
 // element width of a stream: its bytes per block, except the 6-byte alpha index records, which move as three halfwords
 __host__ __device__ constexpr int stream_element_width(int bytes_per_block) { return bytes_per_block == 6 ? 2 : bytes_per_block; }
@@ -625,14 +638,15 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
-// global offset (from the SoA pointer) of segment 0 of every stream's slice of this tile: aligned, d[s] bytes before the slice
-template <int FMT, bool SA, bool SC>
-__device__ __forceinline__ void slice_bases(uint64_t total_blocks, uint64_t blk0, const Shifts& sh, uint64_t (&gb)[6])
+// global offset (from the SoA pointer) of segment 0 of every stream's slice of tile `tile` of the range (T blocks per
+// tile): aligned, d[s] bytes before the slice
+template <int FMT, bool SA, bool SC, int T>
+__device__ __forceinline__ void slice_bases(uint64_t tile, const Shifts& sh, uint64_t (&gb)[6])
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
 #pragma unroll
     for (int s = 0; s < 6; ++s)
-        gb[s] = s < S.n ? uniform64((uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 - (uint64_t)sh.d[s]) : 0;
+        gb[s] = s < S.n ? uniform64(sh.gbase[s] + tile * (uint64_t)(S.width[s] * T)) : 0;
 }
 
 // For image byte o (a multiple of 16): stream index, segment number within the slice, LDS address of the segment, global
@@ -670,13 +684,12 @@ constexpr int kShiftLdsBytes = shift_lds_bytes(1);
 // one shifted tile, forward; `lds` is the workgroup's shift_lds_bytes(R) scratch (R = 1: shared with the batch kernel)
 template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone, int R = 1>
 __device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
-                                               uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
+                                               uint64_t /*total_blocks: in sh.gbase*/, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
                                                uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256) * R;
     const int t = threadIdx.x;
-    const uint64_t blk0 = first_block + tile * T;
     int base[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s)
@@ -697,7 +710,7 @@ __device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, 
     __syncthreads();
 
     uint64_t gb[6];
-    slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
+    slice_bases<FMT, SA, SC, T>(tile, sh, gb);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         int s, k, la, shift, nseg;
@@ -827,7 +840,7 @@ __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, co
 // one halo tile; `lds`: halo_lds_bytes<FMT>() bytes
 template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
 __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
-                                              uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
+                                              uint64_t /*total_blocks: in sh.gbase*/, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
                                               uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
@@ -835,7 +848,6 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     constexpr int H = kHaloBlocks;
     constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors at most: 64 (BC2 / BC3) or 32 (BC1)
     const int t = threadIdx.x;
-    const uint64_t blk0 = first_block + tile * T;
     // region of stream s: starts at off_s * (T + H) + 64 * s (16-byte aligned), holds the records of blocks
     // [blk0 - H, blk0 + T) from byte d_s on (d_s = 0..63); base[s] = address of the record of the tile's block 0
     int base[6];
@@ -865,7 +877,7 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     __syncthreads();
 
     uint64_t gb[6];
-    slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
+    slice_bases<FMT, SA, SC, T>(tile, sh, gb);
     const bool first_tile = tile == 0;
     switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
     case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, first_tile, gb, sh); break;
@@ -961,13 +973,12 @@ __device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ 
 // one shifted tile, inverse; `lds`: kShiftLdsBytes
 template <int FMT, int VARIANT, bool SA, bool SC>
 __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
-                                               uint64_t total_blocks, uint64_t first_block, const Shifts& sh, uint64_t tile,
+                                               uint64_t total_blocks, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
                                                uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256);
     const int t = threadIdx.x;
-    const uint64_t blk0 = first_block + tile * T;
     int base[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s)
@@ -975,7 +986,7 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
 
     const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
     uint64_t gb[6];
-    slice_bases<FMT, SA, SC>(total_blocks, blk0, sh, gb);
+    slice_bases<FMT, SA, SC, T>(tile, sh, gb);
     switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
     case 0: inv_shift_load_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, total_bytes); break;
     case 1: inv_shift_load_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, total_bytes); break;
@@ -1242,6 +1253,7 @@ __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, 
                 sh.skip_partial = 0;
                 sh.natural = 1;
                 sh.halo_vecs = (int)(en.shifts[1] >> 16) & 0xFF;
+                fill_gbase(sh, make_streams(FMT, SA, SC), en.blocks, 0);
                 fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, en.blocks, 0, sh, local, lds);
             } else if (local == en.tile_wgs) {
                 generic_block<FMT, VARIANT, SA, SC, false>(en.src, en.dst, en.blocks, 0, 0, kHaloBlocks, threadIdx.x);
@@ -1269,6 +1281,7 @@ __device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, 
         sh.skip_partial = 0;
         sh.halo_vecs = 0;
         sh.natural = shifts_are_natural(make_streams(FMT, SA, SC), sh.d);
+        fill_gbase(sh, make_streams(FMT, SA, SC), en.blocks, 0);
         // every buffer's first workgroup is a multiple of 8 (the host pads), so local % 8 is the XCD this workgroup
         // runs on and the XCD-contiguous tile order of the single-buffer shifted kernels applies per buffer
         const uint64_t tile = xcd_contiguous_tile(local, en.tile_wgs);
@@ -1517,6 +1530,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         // ones do not -- BC3 forward 0.65 against 0.77 of peak (tools/shift_probe.py, profiles/r01_z/shift_probe.txt).
         any_shift = any_shift || (base & 127) != 0;
     }
+    fill_gbase(sh, S, r.total_blocks, r.first_block);
     sh.natural = (force_bits_early(tuning) & 0x20) ? 0 : shifts_are_natural(S, sh.d);   // experiment switch 0x20: generic LDS accesses
     // XCD-contiguous tile order: measured +2..+9 % on shifted tiles (neighbouring tiles share 128-byte lines), -1..-3 %
     // on aligned tiles (profiles/r01_i_*) -- so on for the former, off for the latter unless an experiment says so
@@ -1551,6 +1565,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             shh.d[i] = (int)(base & 63);
             halo_blocks = std::max(halo_blocks, (shh.d[i] + S.width[i] - 1) / S.width[i]);
         }
+        fill_gbase(shh, S, r.total_blocks, r.first_block);
         shh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, shh.d);
         // every window starts on a 64-byte sector: no line needs to meet its other half in one L2 -- identity tile order
         // and, unless experiment switch 0x800 asks for plain nt, the write-through streaming stores of the aligned tiles
