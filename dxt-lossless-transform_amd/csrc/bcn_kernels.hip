@@ -246,8 +246,9 @@ __device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
 // as one full line instead of two partial ones.
 __device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t nwg)
 {
+    // every product below is smaller than nwg: 32-bit arithmetic is exact (and half the scalar instructions)
     const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const uint64_t start = xcd < r ? (uint64_t)xcd * (q + 1) : (uint64_t)r * (q + 1) + (uint64_t)(xcd - r) * q;
+    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + (orig >> 3);
 }
 
