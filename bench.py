@@ -184,6 +184,9 @@ def parse_args():
                         "textures); 'range' = every texture's block range is cut over the ranks (range calls)")
     p.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--leg-steps", type=int, default=10,
+                   help="timed steps of each extra leg (BC3 8 GiB, BC7 4 GiB uniform + skewed, archive slice) that the "
+                        "default single-GPU BC1 run reports under `legs`; 0 = no legs")
     p.add_argument("--cpu-sample-mib", type=int, default=1024)
     p.add_argument("--settings", default="", help="variant,split_alpha,split_colour (e.g. 0,0,1) instead of the "
                    "format's default settings; a sweep knob, the headline run uses the defaults")
@@ -194,8 +197,31 @@ def parse_args():
     return p.parse_args()
 
 
+def physical_cores() -> int:
+    """Physical cores of this host (distinct (package, core) pairs in /proc/cpuinfo); SMT threads are not cores.
+    Falls back to os.cpu_count() where the file does not say."""
+    pairs, phys, core = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    return len(pairs) or (os.cpu_count() or 1)
+
+
 def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
-    """Oracle timed on the host: single thread (comparable to the reference's per-core figures) and all cores."""
+    """Oracle timed on the host: single thread (comparable to the reference's per-core figures) and one thread per
+    physical core."""
     import numpy as np
 
     from oracle import oracle_c
@@ -205,7 +231,7 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
     y = np.zeros_like(x)
     z = np.zeros_like(x)
     v, sa, sc = settings
-    cores = os.cpu_count() or 1
+    cores = physical_cores()
 
     def run(threads, reps):
         best = None
@@ -225,8 +251,8 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
         "value": round(one, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
         "sample": f"{sample_mib} MiB of the same {fmt.upper()} splitmix64 workload, forward+inverse, best of 3, "
                   f"scalar C oracle (gcc -O3)",
-        "all_cores_value": round(allc, 3), "all_cores": cores,
-        "note": "scalar port of the reference's loops" + (
+        "all_cores_value": round(allc, 3), "all_cores": cores, "host_threads": os.cpu_count() or 1,
+        "note": "`value` = scalar port of the reference's loops" + (
             "; for BC3 with split alphas + split colours + decorrelation (the default settings) the reference itself "
             "dispatches to its scalar loop (bc3 with_split_alphas_colour_and_recorr/transform/mod.rs:31), so this leg matches "
             "upstream's own path" if fmt == "bc3" and (v, bool(sa), bool(sc)) == (1, True, True) else
@@ -253,7 +279,7 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
             "value": round(one23, 3), "all_cores_value": round(all23, 3), "isa": "AVX2",
             "sample": f"{sample_mib} MiB of the same {fmt.upper()} splitmix64 workload, forward+inverse, best of 3, AVX2 port of "
                       "the reference's SIMD strategy (oracle/dxtlt_oracle_avx2.c, gcc -O3); scalar_* = scalar C oracle",
-            "note": "AVX2 port of the reference's vectorised path for these settings, pinned to the scalar oracle",
+            "note": "`value` = AVX2 port of the reference's vectorised path for these settings, pinned to the scalar oracle",
         })
     # Vectorised ports of the reference's AVX2 / AVX-512BW strategy exist for the headline settings (BC1, Variant1 +
     # split): when the host has AVX2 the widest one becomes the quoted figure (closest analogue of "the reference's SIMD path on one core").
@@ -279,6 +305,9 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
             "sample": f"{sample_mib} MiB of the same BC1 splitmix64 workload, forward+inverse, best of 3, "
                       f"{oracle_c.SIMD_NAMES[oracle_c.simd_level()]} port of the reference's SIMD strategy "
                       f"(oracle/dxtlt_oracle_avx2.c, gcc -O3; the widest level this host has); scalar_* = scalar C oracle",
+            "note": f"`value` = {oracle_c.SIMD_NAMES[oracle_c.simd_level()]} port of the reference's vectorised path for these "
+                    "settings (with_split_colour_and_recorr), pinned to the scalar oracle byte for byte; all_cores = one "
+                    "thread per physical core",
         })
         if oracle_c.simd_level() == 5:   # also quote the AVX2 port on the same host
             oracle_c.simd_set_cap(2)
@@ -287,6 +316,166 @@ def cpu_baseline(fmt: str, settings, sample_mib: int) -> dict:
             finally:
                 oracle_c.simd_set_cap(5)
     return out
+
+
+def bc7_force_modes_device(torch, x, mix: str) -> list:
+    """Mode-mixed BC7 data in place: for mode m the low m + 1 bits of byte 0 become 1 << m.
+    `uniform`: m uniform in 0..7; `skewed`: a texture-like histogram, mode 6 > 1 > 3 > the rest.  Returns the mode counts."""
+    b = x.view(-1, 16)
+    counts = torch.zeros(9, dtype=torch.int64, device=x.device)
+    for lo in range(0, b.shape[0], 1 << 26):
+        v = b[lo:lo + (1 << 26)]
+        r = v[:, 15].to(torch.int32)
+        if mix == "uniform":
+            m = r & 7
+        else:
+            m = torch.where(r < 140, 6, torch.where(r < 200, 1, torch.where(r < 230, 3, r & 7))).to(torch.int32)
+        low = ((2 << m) - 1).to(torch.uint8)
+        v[:, 0] = (v[:, 0] & ~low) | (1 << m).to(torch.uint8)
+        counts += torch.bincount(m, minlength=9)
+        del r, m, low
+    return counts.tolist()
+
+
+def timed_pair(torch, fwd, inv, steps: int, warmup: int):
+    """`steps` x (fwd, inv) on torch's current stream -- the stream the C ABI is handed -- with HIP events around each
+    half.  Returns (fwd_ms, inv_ms, wall_s)."""
+    for _ in range(warmup):
+        fwd()
+        inv()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        fwd()
+        ev[k][1].record()
+        inv()
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return (sum(e[0].elapsed_time(e[1]) for e in ev) / steps, sum(e[1].elapsed_time(e[2]) for e in ev) / steps, wall)
+
+
+def leg_record(workload: str, nbytes: int, fwd_ms: float, inv_ms: float, wall_s: float, steps: int, fwd_kernel: str,
+               inv_kernel: str, checks: dict, launches_per_direction: int = 1) -> dict:
+    """One entry of `legs`: the same quantities as the headline, for one more BASELINE.json configuration."""
+    fa = 2 * nbytes / (fwd_ms * 1e-3) / 1e9
+    ia = 2 * nbytes / (inv_ms * 1e-3) / 1e9
+    return {
+        "workload": workload, "bytes": nbytes, "steps": steps,
+        "value": round(2 * nbytes * steps / wall_s / 2**30, 2), "unit": "GiB/s (fwd+inv, wall clock of the timed steps)",
+        "fwd_ms": round(fwd_ms, 4), "inv_ms": round(inv_ms, 4),
+        "fwd_GiBps": round(nbytes / (fwd_ms * 1e-3) / 2**30, 1), "inv_GiBps": round(nbytes / (inv_ms * 1e-3) / 2**30, 1),
+        "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernel": fwd_kernel,
+                     "achieved": round(fa, 1), "frac": round(fa / HBM_PEAK_GBPS, 4),
+                     "algorithmic_bytes_per_direction": 2 * nbytes, "launches_per_direction": launches_per_direction,
+                     "inverse_kernel": {"kernel": inv_kernel, "achieved": round(ia, 1), "frac": round(ia / HBM_PEAK_GBPS, 4)}},
+        **checks,
+    }
+
+
+def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int) -> dict:
+    """The other single-GPU configurations of BASELINE.json in the same run, on the headline's three device buffers:
+    configs[2] BC3 default fwd+inv over 8 GiB, configs[3] BC7 fwd+inv over 4 GiB (uniform mode mix and a texture-like
+    skewed one), and one GPU's share of configs[4] (8 GiB of alternating 256 MiB BC1 / BC3 textures).  Every leg: HIP
+    events per direction, exact round trip, a window of the forward output against the CPU oracle.  Legs never enter
+    `value`."""
+    import numpy as np
+
+    from dxt_lossless_transform_amd import bc7
+    from oracle import oracle_c
+
+    legs = {}
+    cap = int(x.numel())
+
+    # configs[2]: BC3, default settings
+    n3 = min(cap, 8 << 30)
+    n3 -= n3 % (16 * 2048)
+    st3 = pkg.Bc3TransformSettings()
+    x3, y3, z3 = x[:n3], y[:n3], z[:n3]
+    pkg.fill_splitmix64(x3, 0x0BC30003, 0)
+    z3.zero_()
+    f_ms, i_ms, wall = timed_pair(torch, lambda: pkg.transform_bc3_with_settings(x3, y3, st3),
+                                  lambda: pkg.untransform_bc3_with_settings(y3, z3, st3), steps, warmup)
+    blocks = n3 // 16
+    win = 1 << 16
+    lf = min(blocks // 2 + 4097, blocks - win)
+    want = oracle_c.transform("bc3", x3[lf * 16:(lf + win) * 16].cpu().numpy(), 1, True, True)
+    got = np.empty_like(want)
+    for off, w in pkg.stream_table("bc3", st3):
+        lo = off * blocks + w * lf
+        got[off * win: off * win + w * win] = y3[lo: lo + w * win].cpu().numpy()
+    legs["bc3"] = leg_record(
+        f"BC3 forward+inverse, default settings (YCoCg Variant1, split alpha + colour endpoints), {n3 / 2**30:g} GiB random "
+        "block buffer (BASELINE.json configs[2])", n3, f_ms, i_ms, wall, steps, "fwd_tiled<bc3>", "inv_tiled<bc3>",
+        {"bit_exact_roundtrip": bool(torch.equal(z3, x3)), "oracle_window_exact": bool(np.array_equal(got, want))})
+
+    # configs[3]: BC7, this build's own format; two mode mixes
+    n7 = min(cap, 4 << 30)
+    n7 -= n7 % (16 * 2048)
+    x7, y7, z7 = x[:n7], y[:n7], z[:n7]
+    for mix in ("uniform", "skewed"):
+        pkg.fill_splitmix64(x7, 0x0BC70004, 0)
+        counts = bc7_force_modes_device(torch, x7, mix)
+        z7.zero_()
+        f_ms, i_ms, wall = timed_pair(torch, lambda: bc7.transform_bc7(x7, y7), lambda: bc7.untransform_bc7(y7, z7),
+                                      steps, warmup)
+        sample = 16 << 20                       # whole granules: the prefix's streams are a transform of their own
+        small = torch.empty(sample, dtype=torch.uint8, device=dev)
+        bc7.transform_bc7(x7[:sample], small)
+        xin = x7[:sample].cpu().numpy()
+        want = oracle_c.transform_bc7(xin)
+        legs[f"bc7_{mix}"] = leg_record(
+            f"BC7 granule-sorted field split v2 (this build's own format, parity unpinned), forward+inverse, {n7 / 2**30:g} GiB "
+            f"synthetic mode-mixed buffer, modes {'0-7 uniform' if mix == 'uniform' else 'skewed like a texture: 6 > 1 > 3 > rest'} "
+            "(BASELINE.json configs[3])", n7, f_ms, i_ms, wall, steps, "bc7_forward", "bc7_inverse",
+            {"bit_exact_roundtrip": bool(torch.equal(z7, x7)),
+             "oracle_prefix_exact": bool(np.array_equal(small.cpu().numpy(), want)), "mode_counts": counts})
+        del small
+
+    # configs[4], one GPU's share: alternating 256 MiB BC1 / BC3 textures, each with its format's default settings
+    tex = 256 << 20
+    k = max(2, min(cap, 8 << 30) // tex // 2 * 2)
+    fmts = ["bc1" if i % 2 == 0 else "bc3" for i in range(k)]
+    st = {"bc1": pkg.Bc1TransformSettings(), "bc3": st3}
+    fwd = {f: getattr(pkg, f"transform_{f}_with_settings") for f in st}
+    inv = {f: getattr(pkg, f"untransform_{f}_with_settings") for f in st}
+    xa, ya, za = x[:k * tex], y[:k * tex], z[:k * tex]
+    pkg.fill_splitmix64(xa, 0x0A5C0005, 0)
+    za.zero_()
+    xs, ys, zs = (list(t.view(k, tex).unbind(0)) for t in (xa, ya, za))
+
+    def a_fwd():
+        for i in range(k):
+            fwd[fmts[i]](xs[i], ys[i], st[fmts[i]])
+
+    def a_inv():
+        for i in range(k):
+            inv[fmts[i]](ys[i], zs[i], st[fmts[i]])
+
+    f_ms, i_ms, wall = timed_pair(torch, a_fwd, a_inv, steps, warmup)
+    ok = True
+    win = 1 << 15
+    for i in (0, 1, k - 1):
+        f = fmts[i]
+        B = pkg.BLOCK_BYTES[f]
+        blocks = tex // B
+        lf = blocks // 3 + 17
+        want = oracle_c.transform(f, xs[i][lf * B:(lf + win) * B].cpu().numpy(), 1, True, True)
+        got = np.empty_like(want)
+        for off, w in pkg.stream_table(f, st[f]):
+            got[off * win: off * win + w * win] = ys[i][off * blocks + w * lf: off * blocks + w * (lf + win)].cpu().numpy()
+        ok = ok and bool(np.array_equal(got, want))
+    legs["archive"] = leg_record(
+        f"BC1+BC3 mixed archive, one GPU's share of BASELINE.json configs[4]: {k * tex / 2**30:g} GiB = {k} alternating 256 MiB "
+        "textures, default settings per format, one call per texture and direction", k * tex, f_ms, i_ms, wall, steps,
+        "fwd_tiled<bc1> + fwd_tiled<bc3>", "inv_tiled<bc1> + inv_tiled<bc3>",
+        {"bit_exact_roundtrip": bool(torch.equal(za, xa)), "oracle_windows_exact": ok}, launches_per_direction=k)
+    for name, leg in legs.items():
+        bad = [c for c, v in leg.items() if c.endswith("exact") or c.startswith("bit_exact") if v is not True]
+        assert not bad, f"leg {name}: {bad} failed"
+    return legs
 
 
 def bc7_main(args) -> None:
@@ -791,6 +980,11 @@ def main() -> None:
                                "frac": round(achieved_inv / HBM_PEAK_GBPS, 4)},
         },
     }
+    default_run = (world == 1 and fmt == "bc1" and not args.settings and not args.drop_blocks and not args.force_path
+                   and not args.tile_threads and not strong and nbytes >= (4 << 30))
+    if default_run and args.leg_steps > 0:
+        # the other single-GPU configurations of BASELINE.json, on the same three device buffers (x is overwritten)
+        out["legs"] = run_legs(pkg, torch, dev, x, y, z, args.leg_steps, 2)
     host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
     if host_gib > 0 and not args.drop_blocks:
         del y, z

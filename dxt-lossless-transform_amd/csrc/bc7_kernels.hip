@@ -106,6 +106,47 @@ __device__ __forceinline__ void rank_in_segment(int cls, int& rank, int& count)
     count = __popc(lo) + __popc(hi);
 }
 
+// The same for a segment whose 64 blocks are all of classes 0..7 (the caller checks), with a quarter fewer vector
+// instructions: a lane's class as a one-hot byte counter -- classes 0..3 in one dword, 4..7 in a second; at most 64 per
+// byte, no carry -- and one inclusive wave scan per dword (four row shifts and two row broadcasts, each fused into its
+// add).  The rank is the lane's own byte of its scan value minus one; lane 63's scan value holds every class's count, which
+// lanes 0..7 write to the counts table (so no class's "last lane" has to be found).
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+__device__ __forceinline__ void rank_by_scan(uint8_t* lds, int cls, int lane, int segment, int& rank)
+{
+    const uint64_t one = 1ull << (8 * cls);
+    const uint32_t a = wave_scan_add((uint32_t)one), b = wave_scan_add((uint32_t)(one >> 32));
+    rank = (int)__builtin_amdgcn_ubfe(cls < 4 ? a : b, 8 * cls, 8) - 1;   // the offset operand is taken modulo 32
+    const uint32_t ta = __builtin_amdgcn_readlane(a, 63), tb = __builtin_amdgcn_readlane(b, 63);
+    if (lane < 8)
+        lds_at<uint16_t>(lds, kLdsCounts + lane * (kSegments * 2) + segment * 2) =
+            (uint16_t)__builtin_amdgcn_ubfe(lane < 4 ? ta : tb, 8 * lane, 8);
+}
+
+// Rank of the lane's block inside its class in this segment, and the segment's class counts into the table.
+template <bool TAIL>
+__device__ __forceinline__ void rank_and_count(uint8_t* lds, int cls, int lane, int segment, int& rank)
+{
+    if (!TAIL && __ballot(cls >= 8) == 0) {
+        rank_by_scan(lds, cls, lane, segment, rank);
+    } else {
+        int count;
+        rank_in_segment(cls, rank, count);
+        if (rank == count - 1 && cls < kClasses)   // the class's last lane in the segment reports its count
+            lds_at<uint16_t>(lds, kLdsCounts + cls * (kSegments * 2) + segment * 2) = (uint16_t)count;
+    }
+}
+
 // Every wave turns the counts table into the class bases of ITS segments: 16-lane row r of the wave works on the wave's
 // r-th segment (segment number r * WAVES + wave), lane c of the row on class c: blocks of class c in earlier segments
 // and in all segments; exclusive scan of the totals over the classes (DPP row shifts stay inside a row).
@@ -183,6 +224,7 @@ __device__ __forceinline__ void bc7_forward_granule(const uint8_t* __restrict__ 
     const int image_f = TAIL ? kLdsTailImage + 15 * n : kLdsF;   // F stream, block order
 
     u32x4 q[V];
+    int cls[V], rank[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         q[v] = u32x4{0, 0, 0, 0};
@@ -192,16 +234,11 @@ __device__ __forceinline__ void bc7_forward_granule(const uint8_t* __restrict__ 
     if (t < kClasses * kSegments)
         lds_at<uint16_t>(lds, kLdsCounts + 2 * t) = 0;
     __syncthreads();
-
-    int cls[V], rank[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const bool live = !TAIL || v * LANES + t < n;
         cls[v] = live ? block_class(q[v].x) : kClasses;
-        int count;
-        rank_in_segment(cls[v], rank[v], count);
-        if (rank[v] == count - 1 && cls[v] < kClasses)   // the class's last lane in the segment reports its count
-            lds_at<uint16_t>(lds, kLdsCounts + cls[v] * (kSegments * 2) + (v * WAVES + wave) * 2) = (uint16_t)count;
+        rank_and_count<TAIL>(lds, cls[v], lane, v * WAVES + wave, rank[v]);
     }
     __syncthreads();
 
@@ -310,10 +347,7 @@ __device__ __forceinline__ void bc7_inverse_granule(const uint8_t* __restrict__ 
         const bool live = !TAIL || v * LANES + t < n;
         f[v] = live ? lds_at<uint8_t>(lds, image_f + v * LANES + t) : 0u;
         cls[v] = live ? block_class(f[v]) : kClasses;
-        int count;
-        rank_in_segment(cls[v], rank[v], count);
-        if (rank[v] == count - 1 && cls[v] < kClasses)
-            lds_at<uint16_t>(lds, kLdsCounts + cls[v] * (kSegments * 2) + (v * WAVES + wave) * 2) = (uint16_t)count;
+        rank_and_count<TAIL>(lds, cls[v], lane, v * WAVES + wave, rank[v]);
     }
     __syncthreads();
 
