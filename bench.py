@@ -184,6 +184,7 @@ def parse_args():
                         "textures); 'range' = every texture's block range is cut over the ranks (range calls)")
     p.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--small-legs", action="store_true", help=argparse.SUPPRESS)   # CLI test: legs on a sub-4-GiB buffer
     p.add_argument("--leg-steps", type=int, default=10,
                    help="timed steps of each extra leg (BC3 8 GiB, BC7 4 GiB uniform + skewed, archive slice) that the "
                         "default single-GPU BC1 run reports under `legs`; 0 = no legs")
@@ -435,7 +436,7 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int) -> dict:
         del small
 
     # configs[4], one GPU's share: alternating 256 MiB BC1 / BC3 textures, each with its format's default settings
-    tex = 256 << 20
+    tex = min(256 << 20, cap // 2 // (16 * 2048) * (16 * 2048))   # 256 MiB; smaller only in the small-buffer CLI test
     k = max(2, min(cap, 8 << 30) // tex // 2 * 2)
     fmts = ["bc1" if i % 2 == 0 else "bc3" for i in range(k)]
     st = {"bc1": pkg.Bc1TransformSettings(), "bc3": st3}
@@ -468,8 +469,8 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int) -> dict:
             got[off * win: off * win + w * win] = ys[i][off * blocks + w * lf: off * blocks + w * (lf + win)].cpu().numpy()
         ok = ok and bool(np.array_equal(got, want))
     legs["archive"] = leg_record(
-        f"BC1+BC3 mixed archive, one GPU's share of BASELINE.json configs[4]: {k * tex / 2**30:g} GiB = {k} alternating 256 MiB "
-        "textures, default settings per format, one call per texture and direction", k * tex, f_ms, i_ms, wall, steps,
+        f"BC1+BC3 mixed archive, one GPU's share of BASELINE.json configs[4]: {k * tex / 2**30:g} GiB = {k} alternating {tex >> 20} MiB "
+        f"textures, default settings per format, one call per texture and direction", k * tex, f_ms, i_ms, wall, steps,
         "fwd_tiled<bc1> + fwd_tiled<bc3>", "inv_tiled<bc1> + inv_tiled<bc3>",
         {"bit_exact_roundtrip": bool(torch.equal(za, xa)), "oracle_windows_exact": ok}, launches_per_direction=k)
     for name, leg in legs.items():
@@ -981,7 +982,7 @@ def main() -> None:
         },
     }
     default_run = (world == 1 and fmt == "bc1" and not args.settings and not args.drop_blocks and not args.force_path
-                   and not args.tile_threads and not strong and nbytes >= (4 << 30))
+                   and not args.tile_threads and not strong and (nbytes >= (4 << 30) or args.small_legs))
     if default_run and args.leg_steps > 0:
         # the other single-GPU configurations of BASELINE.json, on the same three device buffers (x is overwritten)
         out["legs"] = run_legs(pkg, torch, dev, x, y, z, args.leg_steps, 2)

@@ -198,6 +198,8 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
     struct Group {
         std::vector<BatchEntry> entries;
         uint32_t wgs = 0;
+        uint32_t uniform_wgs = 0;   // workgroups per buffer (padded to a multiple of 8) while all buffers own the same number
+        bool uniform = true;
     };
     Group groups[6];
     for (size_t i = 0; i < count; ++i) {
@@ -222,7 +224,15 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             return fail(kInvalidArgument, "batch too large for one launch (64 GiB or more of one format and direction)");
         g.wgs += wgs;
         g.entries.push_back(e);
+        // buffers of one size: every entry owns the same (padded) number of workgroups -- the kernel then divides instead
+        // of looking the entry up; the last buffer's padding is launched too (those workgroups find nothing to do)
+        const uint32_t padded = (wgs + 7u) & ~7u;
+        if (g.entries.size() == 1)
+            g.uniform_wgs = padded;
+        else if (padded != g.uniform_wgs)
+            g.uniform = false;
     }
+    static const bool no_uniform = std::getenv("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switch (tools/batch_kernel_probe.py)
 
     for (int gi = 0; gi < 6; ++gi) {
         Group& g = groups[gi];
@@ -246,10 +256,11 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             coarse[k] = (uint32_t)cur;
         }
         e = upload_table(slot, bytes, user);
+        const bool uniform = g.uniform && !no_uniform && (uint64_t)g.uniform_wgs * n <= 0xFFFFFFull;
         if (e == hipSuccess)
             e = dxtlt::launch_batch((dxtlt::Format)(gi / 2 + 1), (gi & 1) != 0, static_cast<const BatchEntry*>(slot->dev),
                                     reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(slot->dev) + entry_bytes),
-                                    (uint32_t)n, g.wgs, user);
+                                    (uint32_t)n, uniform ? g.uniform_wgs * (uint32_t)n : g.wgs, uniform ? g.uniform_wgs : 0, user);
         // the event marks both the copy and the kernel that reads the device table
         hipError_t ev = hipEventRecord(slot->done, user);
         slot->pending = ev == hipSuccess;

@@ -1312,21 +1312,36 @@ __device__ __forceinline__ void batch_splits(const BatchView& en, uint32_t local
     else batch_unit<FMT, VARIANT, false, false, INVERSE>(en, local, lds);
 }
 
+// uniform_wgs != 0: every buffer of the launch owns exactly that many workgroups (buffers of one size -- the texture
+// sets a batch is made for), so the owning entry is wg / uniform_wgs and ONE scalar load -- the entry, a line every
+// workgroup of the buffer shares -- stands between the start of the workgroup and its tile's load instead of two
+// dependent ones (coarse index, then entry).  The quotient comes from a multiply-high with magic = floor(2^32 /
+// uniform_wgs): exact or one short for wg < 2^24, put right by one compare.
 template <int FMT, bool INVERSE>
 __global__ void __launch_bounds__(256)
-batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries)
+batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries,
+             uint32_t uniform_wgs, uint32_t magic)
 {
     constexpr int kLds = (!INVERSE && halo_lds_bytes<FMT>() > kShiftLdsBytes) ? halo_lds_bytes<FMT>() : kShiftLdsBytes;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
     const uint32_t wg = blockIdx.x;
-    // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each
-    // The entry and its successor's first workgroup are fetched together: two dependent scalar loads stand between the
-    // start of the workgroup and its tile's load, not three (a buffer of 64 workgroups or more never takes the loop twice).
-    uint32_t e = coarse[wg >> 6];
-    BatchView en = load_batch_entry(entries + e);
-    while (e + 1 < n_entries && entries[e + 1].first_wg <= wg) {
-        ++e;
+    uint32_t e;
+    BatchView en;
+    if (uniform_wgs != 0) {
+        e = __umulhi(wg, magic);
+        if ((e + 1) * uniform_wgs <= wg)
+            ++e;
         en = load_batch_entry(entries + e);
+    } else {
+        // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each
+        // The entry and its successor's first workgroup are fetched together: two dependent scalar loads stand between the
+        // start of the workgroup and its tile's load, not three (a buffer of 64 workgroups or more never takes the loop twice).
+        e = coarse[wg >> 6];
+        en = load_batch_entry(entries + e);
+        while (e + 1 < n_entries && entries[e + 1].first_wg <= wg) {
+            ++e;
+            en = load_batch_entry(entries + e);
+        }
     }
     const uint32_t local = wg - en.first_wg;
     switch (en.flags & 0xFF) {
@@ -1643,18 +1658,23 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)
 }
 
 hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
-                        uint32_t total_wgs, hipStream_t stream)
+                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream)
 {
     if (n_entries == 0 || total_wgs == 0)
         return hipSuccess;
-    void (*k)(const BatchEntry*, const uint32_t*, uint32_t) = nullptr;
+    if (uniform_wgs != 0 && ((uint64_t)uniform_wgs * n_entries != total_wgs || total_wgs > 0xFFFFFFu))
+        return hipErrorInvalidValue;
+    const uint32_t magic = uniform_wgs > 1 ? (uint32_t)((1ull << 32) / uniform_wgs) : 0;
+    if (uniform_wgs == 1)
+        uniform_wgs = 0;   // 2^32 does not fit the magic word; one workgroup per buffer takes the general lookup
+    void (*k)(const BatchEntry*, const uint32_t*, uint32_t, uint32_t, uint32_t) = nullptr;
     switch (fmt) {
     case kBc1: k = inverse ? batch_kernel<kBc1, true> : batch_kernel<kBc1, false>; break;
     case kBc2: k = inverse ? batch_kernel<kBc2, true> : batch_kernel<kBc2, false>; break;
     case kBc3: k = inverse ? batch_kernel<kBc3, true> : batch_kernel<kBc3, false>; break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries);
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries, uniform_wgs, magic);
     return hipGetLastError();
 }
 

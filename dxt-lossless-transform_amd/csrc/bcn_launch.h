@@ -107,8 +107,10 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e);
 // with a small kernel on `stream` -- no copy-engine hand-over in front of the batch kernel.
 hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes, hipStream_t stream);
 
+// uniform_wgs: 0, or the number of workgroups EVERY entry owns (first_wg == index * uniform_wgs, total_wgs == n_entries *
+// uniform_wgs): the kernel then finds a workgroup's entry by division instead of through the coarse index.
 hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
-                        uint32_t total_wgs, hipStream_t stream);
+                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream);
 
 inline int block_bytes(Format f) { return f == kBc1 ? 8 : 16; }
 

@@ -130,6 +130,24 @@ def test_bench_line_has_the_contract_fields_and_the_host_array_leg():
 
 
 @pytest.mark.gpu
+def test_default_line_carries_the_other_single_gpu_configs_as_legs():
+    """BC3, BC7 (uniform and skewed mode mix) and the archive slice ride in the default BC1 line as `legs`; here on a
+    small buffer.  Each leg has both directions' times, a roofline fraction and its own exactness flags."""
+    d = _run_bench(["--host-array-gib", "0", "--small-legs", "--leg-steps", "2"])
+    legs = d["legs"]
+    assert set(legs) == {"bc3", "bc7_uniform", "bc7_skewed", "archive"}
+    for name, leg in legs.items():
+        assert leg["bit_exact_roundtrip"] is True, name
+        assert leg["fwd_ms"] > 0 and leg["inv_ms"] > 0 and 0 < leg["roofline"]["frac"] < 1, name
+        assert 0 < leg["roofline"]["inverse_kernel"]["frac"] < 1, name
+    assert legs["bc3"]["oracle_window_exact"] and legs["archive"]["oracle_windows_exact"]
+    assert legs["bc7_uniform"]["oracle_prefix_exact"] and legs["bc7_skewed"]["oracle_prefix_exact"]
+    assert legs["bc7_skewed"]["mode_counts"][6] > 2 * legs["bc7_uniform"]["mode_counts"][6]
+    # without the switch a small buffer has no legs (they are defined on the BASELINE sizes)
+    assert "legs" not in _run_bench(["--host-array-gib", "0"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_self_launched_on_one_gpu(scaling):
     """`python bench.py --gpus 2` from a bare shell: the parent starts the ranks; here they share the one GPU over gloo.
@@ -149,3 +167,12 @@ def test_bench_bc7_and_archive_lines():
     a = _run_bench(["--workload", "archive", "--size-gib", "1", "--gpus", "2", "--archive-split", "range"],
                    env={"DXTLT_BENCH_BACKEND": "gloo"})
     assert a["config"]["archive_split"] == "range" and a["config"]["bit_exact_roundtrip_and_oracle_windows"] is True
+
+
+def test_physical_cores_counts_cores_not_threads():
+    """cpu_baseline quotes physical cores (north_star: "core count stated"), not SMT threads."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    n = bench.physical_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)

@@ -3,7 +3,8 @@
 
     python3 tools/pmc_passes.py OUT_DIR SETS_FILE -- python3 tools/odd_pmc.py 1
 
-SETS_FILE: one counter set per line (space separated counter names; '#' comments).  Every pass is its own run with
+SETS_FILE: one counter set per line -- at most 8 SQ and 4 TCC slots per set (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2:
+MI355X_MICROARCH.md "rocprofv3 PMC slots"; an over-subscribed set does not fail, it hangs until the pass timeout) (space separated counter names; '#' comments).  Every pass is its own run with
 --kernel-trace only (never combined with a trace domain gpurun refuses).  A pass whose counters this rocprofv3 does not
 know fails on its own and is reported; a pass that times out stops the whole script (no further GPU work after a hang).
 """
@@ -28,7 +29,7 @@ def main():
         d = os.path.join(out_dir, f"pass{i}")
         full = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd
         try:
-            r = subprocess.run(full, env=env, capture_output=True, text=True, timeout=400)
+            r = subprocess.run(full, env=env, capture_output=True, text=True, timeout=int(os.environ.get("PMC_PASS_TIMEOUT", "240")))
         except subprocess.TimeoutExpired:
             print(f"pass {i} {counters}: TIMEOUT, stopping", flush=True)
             break
