@@ -775,7 +775,15 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
         return best
 
     fwd_s = timed(False, a_in, a_soa)
+    fwd_shards = pkg.sharded_last_stats()
     inv_s = timed(True, a_soa, a_back)
+    inv_shards = pkg.sharded_last_stats()
+    # per device: block bytes of its shard / the shard's own wall time (upload + kernels + downloads), last of the timed calls
+    per_device = [{"device": f["device"], "bytes": f["blocks"] * block, "cpus_bound": f["cpus_bound"],
+                   "local_cpulist": pkg.device_local_cpulist(f["device"]),
+                   "fwd_GiBps": round(f["blocks"] * block / f["seconds"] / 2**30, 2),
+                   "inv_GiBps": round(i["blocks"] * block / i["seconds"] / 2**30, 2)}
+                  for f, i in zip(fwd_shards, inv_shards)]
     ok = bool(torch.equal(h_back, h_in))
     win = 1 << 14
     table = pkg.stream_table(fmt, settings)
@@ -793,6 +801,9 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
         "array_bytes": nbytes, "devices": n_dev, "host_memory": "pinned" if pinned else "pageable",
         "fwd_GiBps": round(nbytes / fwd_s / 2**30, 2), "inv_GiBps": round(nbytes / inv_s / 2**30, 2),
         "fwd_plus_inv_GiBps": round(2 * nbytes / (fwd_s + inv_s) / 2**30, 2),
+        "per_device": per_device,
+        "numa": "each shard's worker thread (and the downloader thread it starts) is bound to the CPUs local to its device "
+                "(cpus_bound; 0 = the kernel names no node or none of its CPUs is available to this process)",
         "bit_exact_roundtrip_and_oracle_windows_across_shard_boundaries": ok,
         "setup_s": round(setup_s, 2),
         "note": "host -> device -> host with placement, PCIe-bound; reported beside `value`, never as `value`",

@@ -278,6 +278,34 @@ def transform_sharded(fmt: str, inverse: bool, input, output, settings, num_devi
                                           int(num_devices)))
 
 
+def sharded_last_stats() -> list[dict]:
+    """What this thread's last transform_sharded call did, shard by shard (dxtlt_sharded_last_stats): device, the number
+    of CPUs the shard's worker thread was bound to (0 = not bound), block range, seconds."""
+    import ctypes as C
+
+    class _Stat(C.Structure):
+        _fields_ = [("device", C.c_int32), ("cpus_bound", C.c_int32), ("first_block", C.c_uint64), ("blocks", C.c_uint64),
+                    ("seconds", C.c_double)]
+
+    l = load()
+    l.dxtlt_sharded_last_stats.argtypes, l.dxtlt_sharded_last_stats.restype = [C.POINTER(_Stat), C.c_int32], C.c_int32
+    buf = (_Stat * 64)()
+    n = min(64, int(l.dxtlt_sharded_last_stats(buf, 64)))
+    return [{"device": s.device, "cpus_bound": s.cpus_bound, "first_block": s.first_block, "blocks": s.blocks,
+             "seconds": s.seconds} for s in buf[:n]]
+
+
+def device_local_cpulist(device: int) -> str:
+    """CPUs local to a HIP device's PCI function ("" when the kernel does not say): dxtlt_device_local_cpulist."""
+    import ctypes as C
+
+    l = load()
+    l.dxtlt_device_local_cpulist.argtypes, l.dxtlt_device_local_cpulist.restype = [C.c_int32, C.c_char_p, C.c_size_t], C.c_int32
+    out = C.create_string_buffer(4096)
+    l.dxtlt_device_local_cpulist(int(device), out, 4096)
+    return out.value.decode()
+
+
 def fill_splitmix64(tensor, seed: int, first_qword: int = 0) -> None:
     """Fill a CUDA uint8 tensor with the synthetic block stream (same bytes as oracle_fill_splitmix64)."""
     import torch

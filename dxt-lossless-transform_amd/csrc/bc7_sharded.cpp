@@ -8,6 +8,7 @@
 
 #include <string>
 #include <algorithm>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -159,15 +160,24 @@ int32_t sharded(bool inverse, const uint8_t* in, uint8_t* out, size_t len, int32
     std::vector<int32_t> codes((size_t)shards, kOk);
     std::vector<std::string> msgs((size_t)shards);
     std::vector<std::thread> threads;
-    for (int s = 0; s < shards; ++s)
-        threads.emplace_back([&, s] {
-            codes[(size_t)s] = shard_worker(s % count, inverse, in, out, total, pl[(size_t)s]);
-            if (codes[(size_t)s] != kOk)
-                msgs[(size_t)s] = dxtlt_last_error();
-        });
+    bool spawn_failed = false;
+    for (int s = 0; s < shards && !spawn_failed; ++s) {
+        try {
+            threads.emplace_back([&, s] {
+                (void)dxtlt_host::bind_this_thread_near_device(s % count);   // the library's own thread: next to its device
+                codes[(size_t)s] = shard_worker(s % count, inverse, in, out, total, pl[(size_t)s]);
+                if (codes[(size_t)s] != kOk)
+                    msgs[(size_t)s] = dxtlt_last_error();
+            });
+        } catch (const std::exception&) {
+            spawn_failed = true;   // EAGAIN under a process limit: join what was started, then report
+        }
+    }
     for (auto& t : threads)
         t.join();
     (void)hipSetDevice(prev);
+    if (spawn_failed)
+        return fail(kDevice, "could not start a shard worker thread");
     for (int s = 0; s < shards; ++s)
         if (codes[(size_t)s] != kOk)
             return fail(codes[(size_t)s], msgs[(size_t)s].c_str());

@@ -7,11 +7,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +29,7 @@ using dxtlt::Range;
 using dxtlt::Settings;
 
 thread_local std::string g_last_error;
+thread_local std::vector<DxtltShardStat> g_shard_stats;   // of this thread's last dxtlt_transform_sharded call
 std::atomic<int> g_tile_threads{0};
 std::atomic<int> g_force_generic{0};
 std::atomic<int> g_xcd_remap{-1};
@@ -822,16 +825,34 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in,
     std::vector<ShardPlan> plan = plan_shards(total, shards, 2048);
     std::vector<int32_t> codes((size_t)shards, DXTLT_OK);
     std::vector<std::string> msgs((size_t)shards);
+    std::vector<DxtltShardStat> stats((size_t)shards);
     std::vector<std::thread> threads;
-    for (int d = 0; d < shards; ++d) {
-        threads.emplace_back([&, d] {
-            codes[(size_t)d] = shard_worker(d % count, format, inverse, in, out, total, plan[(size_t)d], mode, sa, sc);
-            if (codes[(size_t)d] != DXTLT_OK)
-                msgs[(size_t)d] = g_last_error;
-        });
+    // thread creation can fail (EAGAIN under a process limit): whatever was started is joined before the error leaves
+    int32_t spawn_rc = DXTLT_OK;
+    for (int d = 0; d < shards && spawn_rc == DXTLT_OK; ++d) {
+        try {
+            threads.emplace_back([&, d] {
+                // this thread is the library's own: put it next to its device before it submits anything (the pipeline's
+                // downloader thread is created from it and inherits the mask)
+                const int bound = dxtlt_host::bind_this_thread_near_device(d % count);
+                const auto t0 = std::chrono::steady_clock::now();
+                codes[(size_t)d] = shard_worker(d % count, format, inverse, in, out, total, plan[(size_t)d], mode, sa, sc);
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                stats[(size_t)d] = DxtltShardStat{d % count, bound, plan[(size_t)d].first, plan[(size_t)d].count, dt};
+                if (codes[(size_t)d] != DXTLT_OK)
+                    msgs[(size_t)d] = g_last_error;
+            });
+        } catch (const std::exception&) {
+            spawn_rc = fail(DXTLT_E_DEVICE, "could not start a shard worker thread");
+        }
     }
     for (auto& t : threads)
         t.join();
+    g_shard_stats = stats;
+    if (spawn_rc != DXTLT_OK) {
+        (void)hipSetDevice(prev);
+        return spawn_rc;
+    }
     (void)hipSetDevice(prev);
     for (int d = 0; d < shards; ++d) {
         if (codes[(size_t)d] != DXTLT_OK) {
@@ -840,6 +861,14 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in,
         }
     }
     return DXTLT_OK;
+}
+
+int32_t dxtlt_sharded_last_stats(DxtltShardStat* out, int32_t cap)
+{
+    const int32_t n = (int32_t)g_shard_stats.size();
+    for (int32_t i = 0; out != nullptr && i < n && i < cap; ++i)
+        out[i] = g_shard_stats[(size_t)i];
+    return n;
 }
 
 // ---- plumbing -------------------------------------------------------------------------------------------

@@ -64,6 +64,10 @@ void release_shard_buffers(const ShardBuffers& sb);
 bool pipelined_bc7_shard(const ShardBuffers& sb, int dev, bool inverse, const uint8_t* in, uint8_t* out, uint64_t total_main,
                          uint64_t first, uint64_t count, int32_t* rc);
 
+// Binds the calling thread -- one this library created for `device` -- to the CPUs local to the device (numa_affinity.cpp).
+// Returns the number of CPUs bound to, 0 when nothing was changed.
+int bind_this_thread_near_device(int device);
+
 // Enqueue one whole-buffer transform on device pointers.
 int32_t enqueue(int32_t format, bool inverse, const void* d_src, void* d_dst, uint64_t blocks, uint8_t mode,
                 bool split_alpha, bool split_colour, hipStream_t stream, uint8_t normalize = 0);

@@ -180,6 +180,31 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t *inp
                                 size_t len, uint8_t decorrelation_mode, bool split_alpha_endpoints,
                                 bool split_colour_endpoints, int32_t num_devices);
 
+/* What the last dxtlt_transform_sharded call on this thread did, shard by shard (a reporting aid: bench.py prints the
+ * per-device rates from it).  Returns the number of shards of that call and fills at most `cap` records. */
+typedef struct DxtltShardStat {
+    int32_t device;        /* HIP device ordinal the shard ran on */
+    int32_t cpus_bound;    /* CPUs the shard's worker thread was bound to (0: not bound -- unknown node, or DXTLT_NUMA_BIND=0) */
+    uint64_t first_block;  /* the shard's block range */
+    uint64_t blocks;
+    double seconds;        /* wall time of the shard: upload + kernels + downloads to their final host offsets */
+} DxtltShardStat;
+int32_t dxtlt_sharded_last_stats(DxtltShardStat *out, int32_t cap);
+
+/* ---- NUMA placement of the library's own host threads -------------------------------------------
+ * Every worker thread dxtlt_transform_sharded (and the BC7 sharded calls) starts for a device binds itself to the CPUs
+ * the kernel lists as local to that device's PCI function, intersected with the CPUs the process may use; the threads of
+ * the caller are never touched.  DXTLT_NUMA_BIND=0 switches it off.  The three helpers are exported so that a host
+ * program can place its own feeder threads -- and its first touch of the arrays -- the same way.
+ * dxtlt_pci_local_cpulist: pure host code; reads <sysfs>/bus/pci/devices/<bdf>/local_cpulist (or numa_node -> node
+ * cpulist), <sysfs> = $DXTLT_SYSFS_ROOT or /sys; writes e.g. "0-63,128-191" and returns its length, 0 when unknown.
+ * dxtlt_device_local_cpulist: the same for a HIP device ordinal (hipDeviceGetPCIBusId).
+ * dxtlt_bind_thread_to_cpulist: sched_setaffinity of the CALLING thread; returns the number of CPUs bound to, 0 when
+ * the list is malformed or none of its CPUs is available to this process (the thread then stays where it is). */
+int32_t dxtlt_pci_local_cpulist(const char *pci_bdf, char *out, size_t cap);
+int32_t dxtlt_device_local_cpulist(int32_t device, char *out, size_t cap);
+int32_t dxtlt_bind_thread_to_cpulist(const char *cpulist);
+
 /* ---- plumbing ---------------------------------------------------------------------------------- */
 /* Deterministic synthetic blocks on the device: qword i = splitmix64(seed, first_qword + i). */
 int32_t dxtlt_fill_splitmix64_device(void *d_dst, size_t len_bytes, uint64_t seed, uint64_t first_qword,

@@ -176,3 +176,23 @@ def test_physical_cores_counts_cores_not_threads():
 
     n = bench.physical_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_eight_rank_rendezvous_the_driver_shape():
+    """The driver's N = 8 launch, without a GPU: `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
+    --rendezvous-only` -- eight ranks rendezvous over gloo on 127.0.0.1, barrier, MAX-reduce, rank 0 prints the one line."""
+    import json
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8",
+                        "--rendezvous-only"], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 8, "max_over_ranks": 8.0, "backend": "gloo"}
