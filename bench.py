@@ -750,9 +750,36 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
     h_in = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
     h_soa = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
     h_back = torch.empty(nbytes, dtype=torch.uint8, pin_memory=pinned)
+    first_touch = os.environ.get("DXTLT_BENCH_FIRST_TOUCH", "near")
     if not pinned:
-        h_soa.zero_()      # first touch outside the timed calls
-        h_back.zero_()
+        # First touch outside the timed calls -- and, as a NUMA-aware caller would, by a thread that runs next to the device
+        # that will read / write those pages: every shard's block range of the AoS arrays and its slice of every stream of
+        # the transformed array is zeroed by a thread bound to its device's local CPUs (DXTLT_BENCH_FIRST_TOUCH=main: by
+        # this thread, wherever it runs).
+        import threading
+
+        def touch(dev_index, ranges):
+            cpus = set()
+            for part in (pkg.device_local_cpulist(dev_index) or "").split(","):
+                a, _, b = part.partition("-")
+                if a:
+                    cpus |= set(range(int(a), int(b or a) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus and first_touch == "near":
+                os.sched_setaffinity(threading.get_native_id(), cpus)
+            for arr, lo, n in ranges:
+                arr[lo:lo + n].zero_()
+
+        table = pkg.stream_table(fmt, settings)
+        workers = []
+        for d, (first, count) in enumerate(pkg.plan_shards(blocks, n_dev)):
+            ranges = [(h_in, first * block, count * block), (h_back, first * block, count * block)]
+            ranges += [(h_soa, off * blocks + w * first, w * count) for off, w in table]
+            workers.append(threading.Thread(target=touch, args=(d, ranges)))
+        for w in workers:
+            w.start()
+        for w in workers:
+            w.join()
     # the same logical array as the kernel legs, generated on the device in pieces and copied out
     piece = min(nbytes, 1 << 30)
     scratch = torch.empty(piece, dtype=torch.uint8, device=dev)
@@ -801,7 +828,7 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
         "array_bytes": nbytes, "devices": n_dev, "host_memory": "pinned" if pinned else "pageable",
         "fwd_GiBps": round(nbytes / fwd_s / 2**30, 2), "inv_GiBps": round(nbytes / inv_s / 2**30, 2),
         "fwd_plus_inv_GiBps": round(2 * nbytes / (fwd_s + inv_s) / 2**30, 2),
-        "per_device": per_device,
+        "per_device": per_device, "first_touch": first_touch if not pinned else "pinned",
         "numa": "each shard's worker thread (and the downloader thread it starts) is bound to the CPUs local to its device "
                 "(cpus_bound; 0 = the kernel names no node or none of its CPUs is available to this process)",
         "bit_exact_roundtrip_and_oracle_windows_across_shard_boundaries": ok,

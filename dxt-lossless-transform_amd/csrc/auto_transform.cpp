@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -208,9 +209,16 @@ bool estimate_sections_parallel(std::vector<Section>& sections, const DltSizeEst
                 s.rc = est->EstimateCompressedSize(est->Context, stage + s.slot, s.len, scratch[(size_t)tid], max_comp, &s.size);
             }
         };
+        // a thread that cannot be started (EAGAIN under a process limit) is simply not part of the pool: the sections are
+        // handed out through `next`, so the threads that did start -- this one at least -- take all of them
         std::vector<std::thread> pool;
-        for (int t = 1; t < threads; ++t)
-            pool.emplace_back(worker, t);
+        for (int t = 1; t < threads; ++t) {
+            try {
+                pool.emplace_back(worker, t);
+            } catch (const std::exception&) {
+                break;
+            }
+        }
         worker(0);
         for (auto& t : pool)
             t.join();

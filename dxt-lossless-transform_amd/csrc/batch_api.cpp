@@ -16,10 +16,12 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
 
+#include "../../include/dxtlt_bc7.h"
 #include "../../include/dxtlt_gfx950.h"
 #include "bc7_launch.h"
 #include "bcn_launch.h"
@@ -138,63 +140,20 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         if (it.len > 0 && (it.d_input == nullptr || it.d_output == nullptr))
             return fail(kInvalidArgument, "batch item: NULL device buffer with len > 0");
     }
+    // one launch holds fewer than 2^32 threads = 2^24 workgroups of 256 lanes: for BC7 that is 256 GiB of granules per
+    // direction.  Checked here, before anything is enqueued (a batch goes out whole or not at all).
+    {
+        uint64_t granules[2] = {0, 0};
+        for (size_t i = 0; i < count; ++i)
+            if (items[i].format == 7)
+                granules[items[i].inverse ? 1 : 0] += items[i].len / 16 / 1024;
+        if (granules[0] > 0xFFFFFFull || granules[1] > 0xFFFFFFull)
+            return fail(kInvalidArgument, "batch too large for one launch (256 GiB or more of BC7 in one direction)");
+    }
     hipStream_t user = static_cast<hipStream_t>(hip_stream);
 
-    // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one
-    for (int inverse = 0; inverse < 2; ++inverse) {
-        std::vector<dxtlt::bc7::BatchEntry> entries, tails;
-        uint64_t wgs = 0;
-        for (size_t i = 0; i < count; ++i) {
-            const DxtltBatchItem& it = items[i];
-            if (it.format != 7 || it.len == 0 || (it.inverse != 0) != (inverse != 0))
-                continue;
-            const uint64_t blocks = it.len / 16, tail = blocks % 1024, main = blocks - tail;
-            const uint8_t* src = static_cast<const uint8_t*>(it.d_input);
-            uint8_t* dst = static_cast<uint8_t*>(it.d_output);
-            if (main != 0) {
-                entries.push_back({src, dst, main, (uint32_t)wgs, 0});
-                wgs += main / 1024;
-            }
-            if (tail != 0)
-                tails.push_back({src + main * 16, dst + main * 16, 0, 0, (uint32_t)tail});
-            if (wgs > 0x7FFFFFFFull)
-                return fail(kInvalidArgument, "batch too large for one launch (32 TiB or more of BC7 in one direction)");
-        }
-        if (entries.empty() && tails.empty())
-            continue;
-        const size_t coarse_n = ((size_t)wgs + 63) / 64;
-        const size_t entry_bytes = entries.size() * sizeof(dxtlt::bc7::BatchEntry), tail_bytes = tails.size() * sizeof(dxtlt::bc7::BatchEntry);
-        const size_t bytes = (entry_bytes + tail_bytes + coarse_n * sizeof(uint32_t) + 15) & ~(size_t)15;
-        TableSlot* slot = nullptr;
-        hipError_t e = g_ring.acquire(bytes, &slot);
-        if (e != hipSuccess)
-            return fail(kDevice, "batch table staging", e);
-        uint8_t* h = static_cast<uint8_t*>(slot->host);
-        if (entry_bytes) std::memcpy(h, entries.data(), entry_bytes);
-        if (tail_bytes) std::memcpy(h + entry_bytes, tails.data(), tail_bytes);
-        uint32_t* coarse = reinterpret_cast<uint32_t*>(h + entry_bytes + tail_bytes);
-        size_t cur = 0;
-        for (size_t k = 0; k < coarse_n; ++k) {
-            while (cur + 1 < entries.size() && entries[cur + 1].first_wg <= (uint32_t)(k * 64))
-                ++cur;
-            coarse[k] = (uint32_t)cur;
-        }
-        const uint8_t* d = static_cast<const uint8_t*>(slot->dev);
-        e = upload_table(slot, bytes, user);
-        if (e == hipSuccess)
-            e = dxtlt::bc7::launch_batch(inverse != 0, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d),
-                                         reinterpret_cast<const uint32_t*>(d + entry_bytes + tail_bytes), (uint32_t)entries.size(),
-                                         (uint32_t)wgs, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d + entry_bytes),
-                                         (uint32_t)tails.size(), user);
-        hipError_t ev = hipEventRecord(slot->done, user);
-        slot->pending = ev == hipSuccess;
-        if (e != hipSuccess)
-            return fail(kDevice, "BC7 batch table copy / launch", e);
-        if (ev != hipSuccess)
-            return fail(kDevice, "batch event", ev);
-    }
-
-    // one table per (format, direction) group; groups are launched one after the other on the caller's stream
+    // one table per (format, direction) group, planned (and checked against the launch limit) before anything is enqueued;
+    // the groups are launched one after the other on the caller's stream, behind the BC7 launches
     struct Group {
         std::vector<BatchEntry> entries;
         uint32_t wgs = 0;
@@ -233,6 +192,58 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             g.uniform = false;
     }
     static const bool no_uniform = std::getenv("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switch (tools/batch_kernel_probe.py)
+
+    // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one
+    for (int inverse = 0; inverse < 2; ++inverse) {
+        std::vector<dxtlt::bc7::BatchEntry> entries, tails;
+        uint64_t wgs = 0;
+        for (size_t i = 0; i < count; ++i) {
+            const DxtltBatchItem& it = items[i];
+            if (it.format != 7 || it.len == 0 || (it.inverse != 0) != (inverse != 0))
+                continue;
+            const uint64_t blocks = it.len / 16, tail = blocks % 1024, main = blocks - tail;
+            const uint8_t* src = static_cast<const uint8_t*>(it.d_input);
+            uint8_t* dst = static_cast<uint8_t*>(it.d_output);
+            if (main != 0) {
+                entries.push_back({src, dst, main, (uint32_t)wgs, 0});
+                wgs += main / 1024;
+            }
+            if (tail != 0)
+                tails.push_back({src + main * 16, dst + main * 16, 0, 0, (uint32_t)tail});
+        }
+        if (entries.empty() && tails.empty())
+            continue;
+        const size_t coarse_n = ((size_t)wgs + 63) / 64;
+        const size_t entry_bytes = entries.size() * sizeof(dxtlt::bc7::BatchEntry), tail_bytes = tails.size() * sizeof(dxtlt::bc7::BatchEntry);
+        const size_t bytes = (entry_bytes + tail_bytes + coarse_n * sizeof(uint32_t) + 15) & ~(size_t)15;
+        TableSlot* slot = nullptr;
+        hipError_t e = g_ring.acquire(bytes, &slot);
+        if (e != hipSuccess)
+            return fail(kDevice, "batch table staging", e);
+        uint8_t* h = static_cast<uint8_t*>(slot->host);
+        if (entry_bytes) std::memcpy(h, entries.data(), entry_bytes);
+        if (tail_bytes) std::memcpy(h + entry_bytes, tails.data(), tail_bytes);
+        uint32_t* coarse = reinterpret_cast<uint32_t*>(h + entry_bytes + tail_bytes);
+        size_t cur = 0;
+        for (size_t k = 0; k < coarse_n; ++k) {
+            while (cur + 1 < entries.size() && entries[cur + 1].first_wg <= (uint32_t)(k * 64))
+                ++cur;
+            coarse[k] = (uint32_t)cur;
+        }
+        const uint8_t* d = static_cast<const uint8_t*>(slot->dev);
+        e = upload_table(slot, bytes, user);
+        if (e == hipSuccess)
+            e = dxtlt::bc7::launch_batch(inverse != 0, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d),
+                                         reinterpret_cast<const uint32_t*>(d + entry_bytes + tail_bytes), (uint32_t)entries.size(),
+                                         (uint32_t)wgs, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d + entry_bytes),
+                                         (uint32_t)tails.size(), user);
+        hipError_t ev = hipEventRecord(slot->done, user);
+        slot->pending = ev == hipSuccess;
+        if (e != hipSuccess)
+            return fail(kDevice, "BC7 batch table copy / launch", e);
+        if (ev != hipSuccess)
+            return fail(kDevice, "batch event", ev);
+    }
 
     for (int gi = 0; gi < 6; ++gi) {
         Group& g = groups[gi];
@@ -381,6 +392,35 @@ extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_
     if (total == 0)
         return kOk;
 
+    // Items of two chunks or more do not belong in a chunk: the arenas (four pinned ones and two device slots per
+    // direction, all of the largest chunk's size) would grow to the item's size and the item would move as one unpipelined
+    // upload, kernel, download.  They go through the single-buffer host entry points instead, which run their own chunked
+    // pipeline from 96 MiB up; what is left keeps every arena below 3 x the chunk size.
+    const uint64_t big_item = 2 * (uint64_t)kHostBatchChunkBytes;
+    std::vector<DxtltBatchItem> small;
+    small.reserve(count);
+    for (size_t i = 0; i < count; ++i) {
+        const DxtltBatchItem& it = items[i];
+        if (it.len < big_item) {
+            small.push_back(it);
+            continue;
+        }
+        int32_t rc;
+        if (it.format == 7)
+            rc = it.inverse ? dxtlt_untransform_bc7(static_cast<const uint8_t*>(it.d_input), static_cast<uint8_t*>(it.d_output), it.len)
+                            : dxtlt_transform_bc7(static_cast<const uint8_t*>(it.d_input), static_cast<uint8_t*>(it.d_output), it.len);
+        else
+            rc = dxtlt_host::transform(it.format, it.inverse != 0, static_cast<const uint8_t*>(it.d_input),
+                                       static_cast<uint8_t*>(it.d_output), it.len, it.decorrelation_mode,
+                                       it.format == 3 && it.split_alpha_endpoints, it.split_colour_endpoints != 0);
+        if (rc != kOk)
+            return rc;
+    }
+    if (small.empty())
+        return kOk;
+    items = small.data();
+    count = small.size();
+
     // chunks, and every item's 256-byte aligned slot inside its chunk (the same offset in all four arenas and on the device)
     std::vector<uint64_t> slot(count);
     std::vector<size_t> chunk_first;   // first item of every chunk, plus the end
@@ -389,13 +429,16 @@ extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_
         uint64_t in_chunk = 0;
         chunk_first.push_back(0);
         for (size_t i = 0; i < count; ++i) {
-            if (in_chunk >= kHostBatchChunkBytes) {
+            const uint64_t padded = (items[i].len + 255) & ~uint64_t(255);
+            // a chunk is closed BEFORE the item that would push it past the cap (so a chunk holds at most the cap, or one
+            // item of less than two chunks): arena_bytes stays bounded whatever the item sizes
+            if (in_chunk > 0 && in_chunk + padded > kHostBatchChunkBytes) {
                 chunk_first.push_back(i);
                 chunk_bytes.push_back(in_chunk);
                 in_chunk = 0;
             }
             slot[i] = in_chunk;
-            in_chunk += (items[i].len + 255) & ~uint64_t(255);
+            in_chunk += padded;
         }
         chunk_first.push_back(count);
         chunk_bytes.push_back(in_chunk);
@@ -497,9 +540,21 @@ extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_
             set_failed(e);
     };
 
+    // Thread creation can fail (EAGAIN under a process limit).  Every stage below waits on counts that only the full set
+    // of threads reaches, so a partial set is told to leave (failed), joined, the streams drained, and the call reports it.
     std::vector<std::thread> threads;
-    for (int t = 0; t < kCopyThreads; ++t) threads.emplace_back(packer, t);
-    for (int t = 0; t < kCopyThreads; ++t) threads.emplace_back(unpacker, t);
+    bool spawn_failed = false;
+    auto spawn = [&](auto&& fn, auto... args) {
+        if (spawn_failed)
+            return;
+        try {
+            threads.emplace_back(fn, args...);
+        } catch (const std::exception&) {
+            spawn_failed = true;
+        }
+    };
+    for (int t = 0; t < kCopyThreads; ++t) spawn(packer, t);
+    for (int t = 0; t < kCopyThreads; ++t) spawn(unpacker, t);
 
     // The downloads are issued by a thread of their own.  A chunk's download may only be enqueued once the unpackers have
     // emptied its pinned output arena (chunk c - 2) -- a HOST-side condition -- and when this thread waited for that before
@@ -531,7 +586,15 @@ extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_
         if (e != hipSuccess)
             set_failed(e);
     };
-    threads.emplace_back(downloader);
+    spawn(downloader);
+    if (spawn_failed) {
+        set_failed(hipErrorOutOfMemory);
+        for (auto& t : threads)
+            t.join();
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(down);
+        return fail(kAllocation, "could not start the batch copy threads");
+    }
 
     // this thread: upload and kernels of every chunk, as soon as it is packed and its device slots are free
     int32_t rc = kOk;

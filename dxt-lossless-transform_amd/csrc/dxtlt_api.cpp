@@ -609,10 +609,35 @@ ShardCtx* shard_ctx_acquire(int dev, size_t bytes, hipError_t* err)
     return c;
 }
 
+// At most kIdleShardCtxPerDevice idle contexts stay per device (the largest ones): a call with 64 round-robin shards on
+// one device would otherwise leave 64 streams and 2 x the array size of HBM behind until someone calls
+// dxtlt_release_thread_resources().  Retained memory per device is thus bounded by 2 buffers x the largest shard x 2.
+constexpr int kIdleShardCtxPerDevice = 2;
+
 void shard_ctx_release(ShardCtx* c)
 {
-    std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
-    c->busy = false;
+    std::vector<ShardCtx*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
+        c->busy = false;
+        std::vector<ShardCtx*> idle;
+        for (ShardCtx* x : g_shard_pool)
+            if (!x->busy && x->dev == c->dev)
+                idle.push_back(x);
+        if ((int)idle.size() > kIdleShardCtxPerDevice) {
+            std::sort(idle.begin(), idle.end(), [](const ShardCtx* l, const ShardCtx* r) { return l->cap > r->cap; });
+            drop.assign(idle.begin() + kIdleShardCtxPerDevice, idle.end());
+            for (ShardCtx* x : drop)
+                g_shard_pool.erase(std::find(g_shard_pool.begin(), g_shard_pool.end(), x));
+        }
+    }
+    // the calling shard thread has c->dev current and has drained its stream; the dropped contexts are idle ones of that device
+    for (ShardCtx* x : drop) {
+        if (x->a) (void)hipFree(x->a);
+        if (x->b) (void)hipFree(x->b);
+        if (x->st) (void)hipStreamDestroy(x->st);
+        delete x;
+    }
 }
 
 void shard_pool_clear()

@@ -223,7 +223,8 @@ const char *dxtlt_version(void);
  * buffers (so that file-after-file callers pay allocation once), and for buffers of up to 1 MiB a pair of mapped pinned
  * host buffers that the kernel reads and writes directly.  This frees the calling thread's set -- and, process-
  * wide, the idle per-device stream + buffer sets that dxtlt_transform_sharded and the BC7 sharded entry points keep
- * across calls (sets in use by a call in flight are left alone). */
+ * across calls (sets in use by a call in flight are left alone).  Those sets are bounded without this call too: at most
+ * two idle ones stay per device, i.e. at most 4 x the largest shard's bytes of HBM per device. */
 void dxtlt_release_thread_resources(void);
 
 #ifdef __cplusplus

@@ -20,8 +20,8 @@ pub unsafe fn transform_bc1_auto<T>(
 where
     T: SizeEstimationOperations,
 {
-    let mut bridge = EstimatorBridge { estimator: &transform_options.size_estimator, error: None };
-    let table = vtable(&mut bridge);
+    let bridge = EstimatorBridge::new(&transform_options.size_estimator);
+    let table = vtable(&bridge);
     let (mut mode, mut split_colour, mut estimator_error) = (0u8, false, 0u32);
     let rc = dxtlt_transform_bc1_auto(
         input_ptr, output_ptr, len, &table, transform_options.use_all_decorrelation_modes,
@@ -34,7 +34,7 @@ where
             split_colour_endpoints: split_colour,
         }),
         DXTLT_E_ESTIMATOR => Err(DetermineBestTransformError::SizeEstimationError(
-            bridge.error.take().expect("the estimator callback failed, so it parked its error"))),
+            bridge.take_error().expect("the estimator callback failed, so it parked its error"))),
         DXTLT_E_ALLOCATION => Err(DetermineBestTransformError::AllocateError(AllocateError::default())),
         other => abort_on_device_failure("transform_bc1_auto", other),
     }

@@ -160,6 +160,36 @@ def test_host_batch_equals_oracle_item_by_item(pkg, oracle):
 
 
 @pytest.mark.gpu
+def test_host_batch_with_items_larger_than_a_chunk(pkg, oracle):
+    """Arena sizes stay bounded whatever the item sizes: an item of two chunks or more (here 136 MiB of BC1
+    and 130 MiB of BC7) goes through the single-buffer pipeline, a chunk is closed BEFORE the item that would overfill it
+    (40 MiB items: one per chunk once a 30 MiB item sits in it), and the small items around them still batch."""
+    from dxt_lossless_transform_amd import batch
+    from tests.test_bc7 import make_blocks
+
+    plan = [("bc1", 1 << 20), ("bc3", 30 << 20), ("bc1", 40 << 20), ("bc2", 40 << 20), ("bc1", 136 << 20), ("bc3", 4096 * 16 + 16),
+            ("bc7", 130 << 20), ("bc7", 5 * 1024 * 16 + 48), ("bc1", 8), ("bc3", 20 << 20)]
+    items, expect = [], []
+    for k, (fmt, nbytes) in enumerate(plan):
+        inverse = k % 3 == 2
+        if fmt == "bc7":
+            x = make_blocks(oracle, nbytes // 16, "uniform", k)
+            want = oracle.transform_bc7(x, inverse=inverse)
+            st = None
+        else:
+            x = oracle.fill_splitmix64(nbytes, 0xB16 + k)
+            want = oracle.transform(fmt, x, 1, True, True, inverse=inverse)
+            st = settings_for(pkg, fmt, 1, 1, 1)
+        y = np.full(x.size + 32, 0x5A, dtype=np.uint8)
+        items.append((fmt, inverse, x, y[: x.size], st))
+        expect.append((want, y, x.size))
+    batch.transform_batch_host(items)
+    for k, (want, y, n) in enumerate(expect):
+        assert np.array_equal(y[:n], want), (k, plan[k])
+        assert (y[n:] == 0x5A).all(), k
+
+
+@pytest.mark.gpu
 def test_concurrent_host_batches_and_parallel_auto_transforms(pkg, oracle):
     """Four threads at once: two host batches (each with its own pinned arenas, copy threads and streams), one auto
     transform with the estimator on four threads, one plain host call -- every result equal to the oracle's."""
