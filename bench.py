@@ -376,7 +376,49 @@ def leg_record(workload: str, nbytes: int, fwd_ms: float, inv_ms: float, wall_s:
     }
 
 
-def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int) -> dict:
+def leg_cpu_baseline(fmt: str, sample, mode_mix=None) -> dict:
+    """The CPU side of a leg on a bounded sample (about a second of work): the oracle's scalar C loops on one core and,
+    for BC3, on every physical core.  For BC3 with the default settings the reference itself dispatches to its scalar loop
+    (bc3 with_split_alphas_colour_and_recorr/transform/mod.rs:31); BC7 has no reference implementation at all -- what is
+    timed is the CPU statement of this build's own format."""
+    import numpy as np
+
+    from oracle import oracle_c
+
+    if fmt == "bc7":
+        t0 = time.perf_counter()
+        fwd = oracle_c.transform_bc7(sample)
+        t1 = time.perf_counter()
+        back = oracle_c.transform_bc7(fwd, inverse=True)
+        t2 = time.perf_counter()
+        assert np.array_equal(back, sample)
+        return {"value": round(2 * sample.size / (t2 - t0) / 2**30, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+                "sample": f"{sample.size >> 20} MiB of the leg's {mode_mix} mode mix, forward+inverse, scalar C statement of this "
+                          "build's own BC7 format (oracle/dxtlt_oracle_bc7.c; the reference has no BC7 transform to time)",
+                "fwd_value": round(sample.size / (t1 - t0) / 2**30, 3)}
+    y, z = np.zeros_like(sample), np.zeros_like(sample)
+    cores = physical_cores()
+
+    def run(threads):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle_c.run_mt(fmt, sample, y, 1, True, True, False, threads)
+            oracle_c.run_mt(fmt, y, z, 1, True, True, True, threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return round(2 * sample.size / best / 2**30, 3)
+
+    run(cores)
+    one, allc = run(1), run(cores)
+    assert np.array_equal(z, sample)
+    return {"value": one, "unit": "GiB/s", "cores": 1, "kind": "port", "all_cores_value": allc, "all_cores": cores,
+            "sample": f"{sample.size >> 20} MiB of the leg's blocks, forward+inverse, best of 3, scalar C oracle (gcc -O3)",
+            "note": "the reference dispatches BC3 with split alphas + split colours + decorrelation to its scalar loop "
+                    "(bc3 with_split_alphas_colour_and_recorr/transform/mod.rs:31): this leg is upstream's own path"}
+
+
+def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int, cpu: bool = True) -> dict:
     """The other single-GPU configurations of BASELINE.json in the same run, on the headline's three device buffers:
     configs[2] BC3 default fwd+inv over 8 GiB, configs[3] BC7 fwd+inv over 4 GiB (uniform mode mix and a texture-like
     skewed one), and one GPU's share of configs[4] (8 GiB of alternating 256 MiB BC1 / BC3 textures).  Every leg: HIP
@@ -411,6 +453,8 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int) -> dict:
         f"BC3 forward+inverse, default settings (YCoCg Variant1, split alpha + colour endpoints), {n3 / 2**30:g} GiB random "
         "block buffer (BASELINE.json configs[2])", n3, f_ms, i_ms, wall, steps, "fwd_tiled<bc3>", "inv_tiled<bc3>",
         {"bit_exact_roundtrip": bool(torch.equal(z3, x3)), "oracle_window_exact": bool(np.array_equal(got, want))})
+    if cpu:
+        legs["bc3"]["cpu_baseline"] = leg_cpu_baseline("bc3", x3[: min(n3, 256 << 20)].cpu().numpy())
 
     # configs[3]: BC7, this build's own format; two mode mixes
     n7 = min(cap, 4 << 30)
@@ -433,6 +477,8 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int) -> dict:
             "(BASELINE.json configs[3])", n7, f_ms, i_ms, wall, steps, "bc7_forward", "bc7_inverse",
             {"bit_exact_roundtrip": bool(torch.equal(z7, x7)),
              "oracle_prefix_exact": bool(np.array_equal(small.cpu().numpy(), want)), "mode_counts": counts})
+        if cpu:
+            legs[f"bc7_{mix}"]["cpu_baseline"] = leg_cpu_baseline("bc7", xin, mix)
         del small
 
     # configs[4], one GPU's share: alternating 256 MiB BC1 / BC3 textures, each with its format's default settings
@@ -1023,7 +1069,7 @@ def main() -> None:
                    and not args.tile_threads and not strong and (nbytes >= (4 << 30) or args.small_legs))
     if default_run and args.leg_steps > 0:
         # the other single-GPU configurations of BASELINE.json, on the same three device buffers (x is overwritten)
-        out["legs"] = run_legs(pkg, torch, dev, x, y, z, args.leg_steps, 2)
+        out["legs"] = run_legs(pkg, torch, dev, x, y, z, args.leg_steps, 2, cpu=not args.no_cpu_baseline)
     host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
     if host_gib > 0 and not args.drop_blocks:
         del y, z
