@@ -100,7 +100,26 @@ extern "C" {
     pub fn dxtlt_transform_sharded(format: i32, inverse: bool, input_ptr: *const u8, output_ptr: *mut u8, len: usize,
         decorrelation_mode: u8, split_alpha_endpoints: bool, split_colour_endpoints: bool, num_devices: i32) -> i32;
 
+    /// What the last `dxtlt_transform_sharded` call on this thread did, shard by shard; returns the number of shards.
+    pub fn dxtlt_sharded_last_stats(out: *mut DxtltShardStat, cap: i32) -> i32;
+
+    // ---- NUMA placement of host threads that feed a device (the library's own shard workers use these themselves) ------
+    pub fn dxtlt_pci_local_cpulist(pci_bdf: *const c_char, out: *mut c_char, cap: usize) -> i32;
+    pub fn dxtlt_device_local_cpulist(device: i32, out: *mut c_char, cap: usize) -> i32;
+    pub fn dxtlt_bind_thread_to_cpulist(cpulist: *const c_char) -> i32;
+
     pub fn dxtlt_last_error() -> *const c_char;
     pub fn dxtlt_device_count() -> i32;
     pub fn dxtlt_release_thread_resources();
+}
+
+/// `DxtltShardStat` of include/dxtlt_gfx950.h
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct DxtltShardStat {
+    pub device: i32,
+    pub cpus_bound: i32,
+    pub first_block: u64,
+    pub blocks: u64,
+    pub seconds: f64,
 }
