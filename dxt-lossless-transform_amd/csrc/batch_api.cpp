@@ -191,7 +191,8 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         else if (padded != g.uniform_wgs)
             g.uniform = false;
     }
-    static const bool no_uniform = std::getenv("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switch (tools/batch_kernel_probe.py)
+    static const bool no_uniform = std::getenv("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switches (tools/batch_kernel_probe.py)
+    static const bool no_strided = std::getenv("DXTLT_BATCH_NO_STRIDED") != nullptr;
 
     // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one
     for (int inverse = 0; inverse < 2; ++inverse) {
@@ -266,12 +267,24 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
                 ++cur;
             coarse[k] = (uint32_t)cur;
         }
-        e = upload_table(slot, bytes, user);
         const bool uniform = g.uniform && !no_uniform && (uint64_t)g.uniform_wgs * n <= 0xFFFFFFull;
+        // a regular array of buffers: one size, one set of settings and tile form, pointers a constant stride apart
+        bool strided = uniform && !no_strided;   // (one buffer is a regular array too)
+        const int64_t src_stride = n >= 2 ? (int64_t)(g.entries[1].src - g.entries[0].src) : 0;
+        const int64_t dst_stride = n >= 2 ? (int64_t)(g.entries[1].dst - g.entries[0].dst) : 0;
+        for (size_t i = 1; i < n && strided; ++i) {
+            const BatchEntry &a = g.entries[0], &b = g.entries[i];
+            strided = b.blocks == a.blocks && b.tile_wgs == a.tile_wgs && b.variant == a.variant && b.split_alpha == a.split_alpha &&
+                      b.split_colour == a.split_colour && b.form == a.form && b.halo_vecs == a.halo_vecs &&
+                      std::memcmp(b.shift, a.shift, sizeof a.shift) == 0 &&
+                      b.src == a.src + (int64_t)i * src_stride && b.dst == a.dst + (int64_t)i * dst_stride;
+        }
+        e = upload_table(slot, bytes, user);
         if (e == hipSuccess)
             e = dxtlt::launch_batch((dxtlt::Format)(gi / 2 + 1), (gi & 1) != 0, static_cast<const BatchEntry*>(slot->dev),
                                     reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(slot->dev) + entry_bytes),
-                                    (uint32_t)n, uniform ? g.uniform_wgs * (uint32_t)n : g.wgs, uniform ? g.uniform_wgs : 0, user);
+                                    (uint32_t)n, uniform ? g.uniform_wgs * (uint32_t)n : g.wgs, uniform ? g.uniform_wgs : 0, user,
+                                    strided ? &g.entries[0] : nullptr, src_stride, dst_stride);
         // the event marks both the copy and the kernel that reads the device table
         hipError_t ev = hipEventRecord(slot->done, user);
         slot->pending = ev == hipSuccess;

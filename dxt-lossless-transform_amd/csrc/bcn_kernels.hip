@@ -279,6 +279,10 @@ __device__ __forceinline__ u32x4 normalize_vector(u32x4 q)
     return q;
 }
 
+// bit 1 of the tiled kernels' `xcd_remap` argument: the launch is two-dimensional, blockIdx.y numbers the buffers of a regular
+// array whose sources / destinations lie `*_stride` bytes apart (first pointer argument, second pointer argument)
+constexpr int kTiledArray = 2;
+
 // One aligned tile (the body of fwd_tiled / inv_tiled; the batch kernel runs it for buffers whose stream bases are aligned).
 // `lds`: THREADS * 16 bytes.
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
@@ -311,20 +315,28 @@ __device__ __forceinline__ void inv_aligned_tile(const uint8_t* __restrict__ soa
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
 __global__ void __launch_bounds__(THREADS)
 fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-          int xcd_remap)
+          int xcd_remap, int64_t aos_stride, int64_t soa_stride)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
-    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    if (xcd_remap & kTiledArray) {   // a regular array of buffers: blockIdx.y is the buffer (launch_batch)
+        aos += (int64_t)blockIdx.y * aos_stride;
+        soa += (int64_t)blockIdx.y * soa_stride;
+    }
+    const uint64_t tile = (xcd_remap & 1) ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     fwd_aligned_tile<FMT, VARIANT, SA, SC, THREADS, NORM>(aos, soa, total_blocks, first_block, tile, lds);
 }
 
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
-          int xcd_remap)
+          int xcd_remap, int64_t soa_stride, int64_t aos_stride)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
-    const uint64_t tile = xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+    if (xcd_remap & kTiledArray) {
+        soa += (int64_t)blockIdx.y * soa_stride;
+        aos += (int64_t)blockIdx.y * aos_stride;
+    }
+    const uint64_t tile = (xcd_remap & 1) ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     inv_aligned_tile<FMT, VARIANT, SA, SC, THREADS>(soa, aos, total_blocks, first_block, tile, lds);
 }
 
@@ -1317,10 +1329,21 @@ __device__ __forceinline__ void batch_splits(const BatchView& en, uint32_t local
 // workgroup of the buffer shares -- stands between the start of the workgroup and its tile's load instead of two
 // dependent ones (coarse index, then entry).  The quotient comes from a multiply-high with magic = floor(2^32 /
 // uniform_wgs): exact or one short for wg < 2^24, put right by one compare.
+//
+// strided.on: the batch is a regular array of buffers -- one size, one set of settings, sources and destinations each a
+// constant stride apart (an array texture, the mip level of a texture set that a decompressor wrote into one
+// allocation).  Its first entry then travels in the kernel arguments with the two strides, and a workgroup reaches its
+// tile without any table load at all: entry = first entry with both pointers advanced by (wg / uniform_wgs) strides.
+struct StridedBatch {
+    BatchEntry first;
+    int64_t src_stride, dst_stride;
+    uint32_t on;
+};
+
 template <int FMT, bool INVERSE>
 __global__ void __launch_bounds__(256)
 batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries,
-             uint32_t uniform_wgs, uint32_t magic)
+             uint32_t uniform_wgs, uint32_t magic, StridedBatch strided)
 {
     constexpr int kLds = (!INVERSE && halo_lds_bytes<FMT>() > kShiftLdsBytes) ? halo_lds_bytes<FMT>() : kShiftLdsBytes;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
@@ -1331,7 +1354,22 @@ batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict_
         e = __umulhi(wg, magic);
         if ((e + 1) * uniform_wgs <= wg)
             ++e;
-        en = load_batch_entry(entries + e);
+        if (strided.on != 0) {
+            // kernel arguments: scalar loads off the kernarg pointer, nothing depends on a table
+            typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
+            typedef __attribute__((address_space(1))) uint8_t* global_ptr;
+            const BatchEntry& f = strided.first;
+            en.src = (const uint8_t*)(global_cptr)(reinterpret_cast<uintptr_t>(f.src) + (uint64_t)((int64_t)e * strided.src_stride));
+            en.dst = (uint8_t*)(global_ptr)(reinterpret_cast<uintptr_t>(f.dst) + (uint64_t)((int64_t)e * strided.dst_stride));
+            en.blocks = f.blocks;
+            en.first_wg = e * uniform_wgs;
+            en.tile_wgs = f.tile_wgs;
+            en.flags = (uint32_t)f.variant | ((uint32_t)f.split_alpha << 8) | ((uint32_t)f.split_colour << 16) | ((uint32_t)f.form << 24);
+            en.shifts[0] = (uint32_t)f.shift[0] | ((uint32_t)f.shift[1] << 8) | ((uint32_t)f.shift[2] << 16) | ((uint32_t)f.shift[3] << 24);
+            en.shifts[1] = (uint32_t)f.shift[4] | ((uint32_t)f.shift[5] << 8) | ((uint32_t)f.halo_vecs << 16);
+        } else {
+            en = load_batch_entry(entries + e);
+        }
     } else {
         // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each
         // The entry and its successor's first workgroup are fetched together: two dependent scalar loads stand between the
@@ -1384,7 +1422,7 @@ fill_splitmix64_kernel(uint8_t* __restrict__ dst, uint64_t len_bytes, uint64_t s
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int);
+using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int, int64_t, int64_t);
 using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
 using ShiftFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, Shifts);
 
@@ -1602,7 +1640,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
                                r.first_block, sh);
         else
             hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream,
-                               src8, dst8, r.total_blocks, r.first_block, aligned_remap);
+                               src8, dst8, r.total_blocks, r.first_block, aligned_remap, (int64_t)0, (int64_t)0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
@@ -1658,7 +1696,8 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)
 }
 
 hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
-                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream)
+                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream, const BatchEntry* strided_first,
+                        int64_t src_stride, int64_t dst_stride)
 {
     if (n_entries == 0 || total_wgs == 0)
         return hipSuccess;
@@ -1667,14 +1706,43 @@ hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, c
     const uint32_t magic = uniform_wgs > 1 ? (uint32_t)((1ull << 32) / uniform_wgs) : 0;
     if (uniform_wgs == 1)
         uniform_wgs = 0;   // 2^32 does not fit the magic word; one workgroup per buffer takes the general lookup
-    void (*k)(const BatchEntry*, const uint32_t*, uint32_t, uint32_t, uint32_t) = nullptr;
+    // A regular array of buffers whose stream bases all sit on 128-byte lines and whose block count is a whole number of
+    // tiles IS the single-buffer aligned kernel with one more grid dimension: no table, no per-workgroup settings switch
+    // (the batch kernel runs 92 scalar instructions per wave where the tiled kernel runs 34 -- one scalar unit serves a
+    // CU's four SIMDs: 0.80 against 0.835 of peak on one 1 GiB BC3 buffer, profiles/r03_batch_spacing.txt).
+    static const bool no_array = std::getenv("DXTLT_BATCH_NO_ARRAY") != nullptr;   // A/B switch
+    if (strided_first != nullptr && uniform_wgs != 0 && !no_array && strided_first->form == 1 && n_entries <= 65535) {
+        const BatchEntry& f = *strided_first;
+        const int threads = default_tile_threads(fmt, inverse);
+        const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
+        if (f.blocks % T == 0 && f.blocks / T <= 0x7FFFFFFFull) {
+            const bool sa = fmt == kBc3 && f.split_alpha != 0, sc = f.split_colour != 0;
+            KernelSet ks;
+            switch (fmt) {
+            case kBc1: ks = pick_variant<kBc1>(f.variant, false, sc, inverse); break;
+            case kBc2: ks = pick_variant<kBc2>(f.variant, false, sc, inverse); break;
+            default: ks = pick_variant<kBc3>(f.variant, sa, sc, inverse); break;
+            }
+            hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)(f.blocks / T), n_entries), dim3(threads), 0, stream,
+                               f.src, f.dst, f.blocks, (uint64_t)0, kTiledArray, src_stride, dst_stride);
+            return hipGetLastError();
+        }
+    }
+    StridedBatch strided{};
+    if (strided_first != nullptr && uniform_wgs != 0) {
+        strided.first = *strided_first;
+        strided.src_stride = src_stride;
+        strided.dst_stride = dst_stride;
+        strided.on = 1;
+    }
+    void (*k)(const BatchEntry*, const uint32_t*, uint32_t, uint32_t, uint32_t, StridedBatch) = nullptr;
     switch (fmt) {
     case kBc1: k = inverse ? batch_kernel<kBc1, true> : batch_kernel<kBc1, false>; break;
     case kBc2: k = inverse ? batch_kernel<kBc2, true> : batch_kernel<kBc2, false>; break;
     case kBc3: k = inverse ? batch_kernel<kBc3, true> : batch_kernel<kBc3, false>; break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries, uniform_wgs, magic);
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries, uniform_wgs, magic, strided);
     return hipGetLastError();
 }
 

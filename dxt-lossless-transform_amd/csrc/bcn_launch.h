@@ -109,8 +109,11 @@ hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes,
 
 // uniform_wgs: 0, or the number of workgroups EVERY entry owns (first_wg == index * uniform_wgs, total_wgs == n_entries *
 // uniform_wgs): the kernel then finds a workgroup's entry by division instead of through the coarse index.
+// strided_first != nullptr (needs uniform_wgs != 0): the batch is a regular array -- every entry equals *strided_first but for
+// its pointers, which advance by src_stride / dst_stride bytes per entry; the kernel then reads no table at all.
 hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
-                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream);
+                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream, const BatchEntry* strided_first = nullptr,
+                        int64_t src_stride = 0, int64_t dst_stride = 0);
 
 inline int block_bytes(Format f) { return f == kBc1 ? 8 : 16; }
 

@@ -80,6 +80,50 @@ def test_batch_runs_every_tile_form(pkg, oracle, fmt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_batch_of_equal_buffers_every_lookup(pkg, oracle, fmt):
+    """Batches of equal-size buffers take shortcuts in the kernel's buffer lookup: a division instead of the table walk, and
+    for a regular array (one stride between the sources, one between the destinations) no table at all.  Every layout --
+    back to back, padded stride, reverse order (negative stride), scattered -- and every tile form (block counts on and off
+    the 128-byte lines), both directions, against the oracle; guard bytes between the outputs stay untouched."""
+    from dxt_lossless_transform_amd import batch
+
+    dev = torch.device("cuda:0")
+    B = pkg.BLOCK_BYTES[fmt]
+    tile = 4096 // B
+    st = settings_for(pkg, fmt, 2, 1, 0)
+    count = 19
+    for blocks in (8 * tile, 8 * tile + 1, 3 * tile + 65, tile - 1):
+        n = blocks * B
+        for layout, pad in (("back_to_back", 0), ("padded", 4352), ("reverse", 128), ("scattered", 640)):
+            for inverse in (False, True):
+                xs = [oracle.fill_splitmix64(n, 0xE9 + 31 * k + blocks) for k in range(count)]
+                if inverse:
+                    xs = [oracle.transform(fmt, x, 2, False, True) for x in xs]
+                want = [oracle.transform(fmt, x, 2, False, True, inverse=inverse) for x in xs]
+                stride = n + pad
+                order = list(range(count))
+                if layout == "reverse":
+                    order = order[::-1]
+                if layout == "scattered":
+                    order = [(7 * k + 3) % count for k in range(count)]
+                xd = torch.zeros(count * stride + 64, dtype=torch.uint8, device=dev)
+                yd = torch.full((count * stride + 64,), 0x5A, dtype=torch.uint8, device=dev)
+                items = []
+                for k in range(count):
+                    lo = order[k] * stride
+                    xd[lo:lo + n] = torch.from_numpy(np.ascontiguousarray(xs[k])).to(dev)
+                    items.append((fmt, inverse, xd[lo:lo + n], yd[lo:lo + n], st))
+                batch.transform_batch(items)
+                torch.cuda.synchronize()
+                got = yd.cpu().numpy()
+                for k in range(count):
+                    lo = order[k] * stride
+                    assert np.array_equal(got[lo:lo + n], want[k]), (fmt, blocks, layout, inverse, k)
+                    assert (got[lo + n:lo + stride] == 0x5A).all(), (fmt, blocks, layout, inverse, k)
+
+
+@pytest.mark.gpu
 def test_batch_is_ordered_with_the_callers_stream(pkg, oracle):
     """The batch reads what earlier work on the stream produced and later work on the stream sees its output, without
     any synchronisation by the caller."""

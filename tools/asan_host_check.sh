@@ -38,4 +38,4 @@ DXTLT_LIB_PATH="$OUT/libdxtlt_gfx950_asan.so" LD_PRELOAD="$RT" \
     ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
     python3 -m pytest -q -m "not gpu" -p no:cacheprovider \
     tests/test_cabi_load.py tests/test_cabi_reference_surface.py tests/test_file_formats.py tests/test_bc7_sharded.py \
-    tests/test_batch.py tests/test_bc7.py tests/test_oracle.py tests/test_compression_gain.py tests/test_color565.py tests/test_decode.py tests/test_normalize.py tests/test_normalize_bc23.py "$@"
+    tests/test_batch.py tests/test_numa_affinity.py tests/test_bc7.py tests/test_oracle.py tests/test_compression_gain.py tests/test_color565.py tests/test_decode.py tests/test_normalize.py tests/test_normalize_bc23.py "$@"
