@@ -1371,14 +1371,20 @@ batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict_
             en = load_batch_entry(entries + e);
         }
     } else {
-        // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each
-        // The entry and its successor's first workgroup are fetched together: two dependent scalar loads stand between the
-        // start of the workgroup and its tile's load, not three (a buffer of 64 workgroups or more never takes the loop twice).
+        // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each.
+        // The entry and its successor's first workgroup are fetched TOGETHER, so that two dependent scalar loads stand between
+        // the start of the workgroup and its tile's load, not three: with buffers of a few hundred workgroups every one of
+        // these loads misses the scalar cache (a CU sees about one workgroup per buffer).  The empty asm pins the entry's loads
+        // in front of the loop -- the compiler otherwise sinks them behind it (round 2's binary did: coarse -> successor's
+        // first workgroup -> entry, three levels).
         e = coarse[wg >> 6];
         en = load_batch_entry(entries + e);
-        while (e + 1 < n_entries && entries[e + 1].first_wg <= wg) {
+        uint32_t next_first = e + 1 < n_entries ? entries[e + 1].first_wg : 0xFFFFFFFFu;
+        asm volatile("" ::"s"(en.src), "s"(en.dst), "s"(en.blocks), "s"(en.flags), "s"(en.tile_wgs), "s"(next_first));
+        while (next_first <= wg) {   // only buffers of fewer than 64 workgroups take this
             ++e;
             en = load_batch_entry(entries + e);
+            next_first = e + 1 < n_entries ? entries[e + 1].first_wg : 0xFFFFFFFFu;
         }
     }
     const uint32_t local = wg - en.first_wg;
@@ -1715,7 +1721,8 @@ hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, c
         const BatchEntry& f = *strided_first;
         const int threads = default_tile_threads(fmt, inverse);
         const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
-        if (f.blocks % T == 0 && f.blocks / T <= 0x7FFFFFFFull) {
+        // (HIP refuses a launch of 2^32 threads or more)
+        if (f.blocks % T == 0 && f.blocks / T <= 0x7FFFFFFFull && (f.blocks / T) * n_entries * (uint64_t)threads < (1ull << 32)) {
             const bool sa = fmt == kBc3 && f.split_alpha != 0, sc = f.split_colour != 0;
             KernelSet ks;
             switch (fmt) {
