@@ -177,6 +177,60 @@ def batch_case(case, rng, dev):
     return True, dict(case=case, kind="batch", ranged=False)
 
 
+def uniform_batch_case(case, rng, dev):
+    """one batch call over 2..24 buffers of ONE format, size, direction and settings (the kernel's equal-size lookups): laid
+    out as a regular array (stride >= size, sometimes in reverse order, sometimes so that every stream base sits on a
+    128-byte line: the tiled-kernel launch) or at scattered offsets of one arena; guard bytes between the outputs"""
+    from dxt_lossless_transform_amd import batch
+
+    fmt = ("bc1", "bc2", "bc3")[int(rng.integers(0, 3))]
+    B, t = BLOCK[fmt], TILE[fmt]
+    k = int(rng.integers(2, 25))
+    kind = int(rng.integers(0, 4))
+    n = int(rng.integers(1, 40)) * (t // 2) if kind == 0 else block_count(fmt, rng) % 40_000   # kind 0: whole tiles, aligned
+    inverse = bool(rng.integers(0, 2))
+    (v, sa, sc), st = settings_of(fmt, rng)
+    pad = (0, 128, 4352, 16 * int(rng.integers(0, 300)))[int(rng.integers(0, 4))] if kind != 3 else 0
+    stride = n * B + pad
+    order = list(range(k))
+    if kind == 2:
+        order.reverse()
+    offs = [o * stride for o in order]
+    if kind == 3:       # scattered: distinct, non-uniform gaps
+        at, offs = 0, []
+        for _ in range(k):
+            at += int(rng.integers(0, 5)) * 16
+            offs.append(at)
+            at += n * B
+        rng.shuffle(offs)
+        offs = [int(o) for o in offs]
+    total = max(offs) + n * B + 256 if offs else 256
+    a, b = (0, 0) if kind == 0 else (int(rng.integers(0, 4)) * 8, int(rng.integers(0, 4)) * 8)
+    xd = torch.full((total,), 0x11, dtype=torch.uint8, device=dev)
+    yd = torch.full((total,), 0x22, dtype=torch.uint8, device=dev)
+    items, wants = [], []
+    for i in range(k):
+        x = oracle_c.fill_splitmix64(n * B, 0xA77 + case * 64 + i)
+        if inverse:
+            x = oracle_c.transform(fmt, x, v, sc, sa)
+        wants.append(oracle_c.transform(fmt, x, v, sc, sa, inverse=inverse))
+        lo = offs[i]
+        xd[a + lo:a + lo + n * B] = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        items.append((fmt, inverse, xd[a + lo:a + lo + n * B], yd[b + lo:b + lo + n * B], st))
+    batch.transform_batch(items)
+    torch.cuda.synchronize()
+    h = yd.cpu().numpy()
+    covered = np.zeros(total, dtype=bool)
+    for i in range(k):
+        lo = b + offs[i]
+        if not np.array_equal(h[lo:lo + n * B], wants[i]):
+            return False, dict(case=case, kind="uniform_batch", item=(fmt, inverse, n, kind, pad, i, (v, sa, sc)), ranged=False)
+        covered[lo:lo + n * B] = True
+    if not (h[~covered] == 0x22).all():
+        return False, dict(case=case, kind="uniform_batch", item=(fmt, inverse, n, kind, pad, "guard", (v, sa, sc)), ranged=False)
+    return True, dict(case=case, kind="uniform_batch", ranged=False)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
@@ -188,7 +242,7 @@ def main():
     dev = torch.device("cuda:0")
     t0 = time.time()
     case = 0
-    counts = {"bcn": 0, "bcn_ranged": 0, "bc7": 0, "bc7_ranged": 0, "batch": 0}
+    counts = {"bcn": 0, "bcn_ranged": 0, "bc7": 0, "bc7_ranged": 0, "batch": 0, "uniform_batch": 0}
     while time.time() - t0 < args.seconds:
         rng = np.random.default_rng([args.seed, case])
         if args.only >= 0 and case != args.only:
@@ -196,8 +250,9 @@ def main():
             continue
         pick = int(rng.integers(0, 16))
         is7, is_batch = pick < 4 and not args.batch_only, pick == 15 or args.batch_only
-        ok, tag = (batch_case if is_batch else bc7_case if is7 else bcn_case)(case, rng, dev)
-        counts["batch" if is_batch else ("bc7" if is7 else "bcn") + ("_ranged" if tag["ranged"] else "")] += 1
+        is_uniform = is_batch and bool(rng.integers(0, 2))
+        ok, tag = (uniform_batch_case if is_uniform else batch_case if is_batch else bc7_case if is7 else bcn_case)(case, rng, dev)
+        counts["uniform_batch" if is_uniform else "batch" if is_batch else ("bc7" if is7 else "bcn") + ("_ranged" if tag["ranged"] else "")] += 1
         if not ok:
             print("FAIL", tag, flush=True)
             sys.exit(1)
