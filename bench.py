@@ -519,6 +519,25 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int, cpu: bool = True
         f"textures, default settings per format, one call per texture and direction", k * tex, f_ms, i_ms, wall, steps,
         "fwd_tiled<bc1> + fwd_tiled<bc3>", "inv_tiled<bc1> + inv_tiled<bc3>",
         {"bit_exact_roundtrip": bool(torch.equal(za, xa)), "oracle_windows_exact": ok}, launches_per_direction=k)
+    # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json), where the leg ran at the profiled size
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)
+        lt, src = rec.get("legs", {}), rec.get("source", "profiles/pmc_traffic.json")
+        note = f"{src}: committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 rule, WRITE_SIZE); NOT measured by this run"
+        if lt.get("bc3", {}).get("bytes") == n3 and lt["bc3"].get("fwd"):
+            legs["bc3"]["roofline"].update({"traffic": lt["bc3"]["fwd"], "inverse_traffic": lt["bc3"]["inv"], "traffic_source": note})
+        for mix in ("uniform", "skewed"):
+            if lt.get("bc7", {}).get("bytes") == n7 and lt["bc7"].get("fwd"):
+                legs[f"bc7_{mix}"]["roofline"].update({"traffic": lt["bc7"]["fwd"], "inverse_traffic": lt["bc7"]["inv"],
+                                                       "traffic_source": note + " (uniform mix)"})
+        at = lt.get("archive_texture", {})
+        if at.get("bytes") == tex and all(at.get(x) for x in ("bc1_fwd", "bc3_fwd", "bc1_inv", "bc3_inv")):
+            legs["archive"]["roofline"].update({"traffic": (at["bc1_fwd"] + at["bc3_fwd"]) * (k // 2),
+                                                "inverse_traffic": (at["bc1_inv"] + at["bc3_inv"]) * (k // 2),
+                                                "traffic_source": note + "; per-texture figures x the textures of one direction"})
+    except (OSError, ValueError, KeyError):
+        pass
     for name, leg in legs.items():
         bad = [c for c, v in leg.items() if c.endswith("exact") or c.startswith("bit_exact") if v is not True]
         assert not bad, f"leg {name}: {bad} failed"

@@ -96,6 +96,19 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
         shutil.copy(f, os.path.join(out, f"{tag}_{os.path.basename(f)}"))
 shutil.copy(os.path.join(src, "prof_kt.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
 
+def find(pattern, alg):
+    hits = [t for t in traffic if pattern in t["kernel"] and t["algorithmic_bytes_per_launch"] == alg]
+    return hits[0]["hbm_bytes_per_launch"] if hits else None
+
+
+# per-launch HBM bytes of the legs' kernels (bench.py attaches them to `legs.*.roofline.traffic`, labelled as a committed pass)
+leg_traffic = {
+    "bc3": {"bytes": 8 << 30, "fwd": find("fwd_tiled<3, 1, true, true", 2 * (8 << 30)), "inv": find("inv_tiled<3, 1, true, true", 2 * (8 << 30))},
+    "bc7": {"bytes": 4 << 30, "fwd": find("bc7_forward<", 2 * (4 << 30)), "inv": find("bc7_inverse<", 2 * (4 << 30))},
+    "archive_texture": {"bytes": 256 << 20,
+                        "bc1_fwd": find("fwd_tiled<1, 1, false, true", 2 * (256 << 20)), "bc1_inv": find("inv_tiled<1, 1, false, true", 2 * (256 << 20)),
+                        "bc3_fwd": find("fwd_tiled<3, 1, true, true", 2 * (256 << 20)), "bc3_inv": find("inv_tiled<3, 1, true, true", 2 * (256 << 20))},
+}
 head = {}
 for t in traffic:
     if "fwd_tiled<1, 1, false, true" in t["kernel"] and t["algorithmic_bytes_per_launch"] == 2 * (8 << 30):
@@ -105,7 +118,7 @@ for t in traffic:
 if len(head) == 2:
     json.dump({"format": "bc1", "workload_bytes": 8 << 30, "source": f"profiles/{tag}_pmc.json",
                "fwd_hbm_bytes_per_launch": head["fwd"]["hbm_bytes_per_launch"],
-               "inv_hbm_bytes_per_launch": head["inv"]["hbm_bytes_per_launch"]},
+               "inv_hbm_bytes_per_launch": head["inv"]["hbm_bytes_per_launch"], "legs": leg_traffic},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 for k in kernels:
     print(f"{k['kernel']:60s} grid {k['grid_threads']:>11d} x{k['launches']:<3d} avg {k['average_ns'] / 1e6:7.3f} ms  frac {k['frac_of_8TBps']:.4f}")
