@@ -13,7 +13,7 @@ from dxt_lossless_transform_amd import bc7  # noqa: E402
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 dist = sys.argv[2] if len(sys.argv) > 2 else "uniform"
-steps = 10
+steps = int(os.environ.get("STEPS", "20"))
 dev = torch.device("cuda:0")
 n = int(gib * (1 << 30)) // 16
 x = torch.empty(n * 16, dtype=torch.uint8, device=dev)
@@ -37,9 +37,17 @@ low = ((2 << m) - 1).to(torch.uint8)
 b[:, 0] = (b[:, 0] & ~low) | ((1 << m) & 0xFF).to(torch.uint8)
 del r, low
 y, z = torch.empty_like(x), torch.empty_like(x)
-for _ in range(2):
-    bc7.transform_bc7(x, y)
-    bc7.untransform_bc7(y, z)
+# warm up for WARM_MS of wall time, not for a number of launches: after an idle phase the chip needs ~40 ms of load to reach its
+# steady clocks, and these kernels -- close to the vector-issue bound -- run at 0.5-0.7 of peak until then (tools/clock_ramp_probe.py,
+# profiles/r03_clock_ramp.txt).  Rounds 1-2 and the first half of round 3 warmed up with two launches: their BC7 figures are ramp figures.
+import time
+warm_ms = float(os.environ.get("WARM_MS", "150"))
+t0 = time.perf_counter()
+while (time.perf_counter() - t0) * 1e3 < warm_ms:
+    for _ in range(8):          # back to back: a wait after every launch would let the clocks sag again
+        bc7.transform_bc7(x, y)
+        bc7.untransform_bc7(y, z)
+    torch.cuda.synchronize()
 ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
 torch.cuda.synchronize()
 for k in range(steps):
