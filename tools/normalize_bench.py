@@ -34,8 +34,12 @@ M = norm.ColorNormalizationMode
 
 
 def timed(fn, steps=10):
-    for _ in range(2):
-        fn()
+    import time as _t
+    _t0 = _t.perf_counter()
+    while (_t.perf_counter() - _t0) < 0.1:   # warm up by wall time: the chip ramps its clocks for ~40 ms after idling (profiles/r03_clock_ramp.txt)
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for _ in range(steps):
