@@ -1,6 +1,14 @@
-import sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
-import bc7_format_lab as L
+"""Format-lab trial of round 3: BC7 records that keep the fields' pitch (every output word = shifted channel words merged under masks --
+about one device instruction per two fields instead of four) against version 2, on the reference's BC7 texture and on synthetic ones
+(tools/bc7_synth.py).  Result: profiles/r03_bc7_experiments.txt section 4 -- the cheap records give back most of version 2's gain.
+    python tools/bc7_synth.py 1024 /tmp/bc7_synth_1024.bin && python tools/bc7_format_lab_v3.py /tmp/bc7_synth_1024.bin"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bc7_format_lab as L  # noqa: E402
 import numpy as np
 
 def decor(f, how):
@@ -75,7 +83,7 @@ def order_v2_xor(m, f):
     return hdr + pb + idx + [L.lo(x, x[1] - 4) for x in ep if x[1] > 4] + [L.hi(x, 4) for x in ep]
 
 def main():
-    corpora = {"ref": "/root/repo/tests/golden/r2-256-bc7.payload.bin"}
+    corpora = {"ref": os.path.join(ROOT, "tests", "golden", "r2-256-bc7.payload.bin")}
     for p in sys.argv[1:]:
         corpora[os.path.basename(p)] = p
     slots = (8, 2, 1, 1, 1, 1, 1)
