@@ -128,9 +128,9 @@ __device__ __forceinline__ void rank_by_scan(uint8_t* lds, int cls, int lane, in
     const uint32_t a = wave_scan_add((uint32_t)one), b = wave_scan_add((uint32_t)(one >> 32));
     rank = (int)__builtin_amdgcn_ubfe(cls < 4 ? a : b, 8 * cls, 8) - 1;   // the offset operand is taken modulo 32
     const uint32_t ta = __builtin_amdgcn_readlane(a, 63), tb = __builtin_amdgcn_readlane(b, 63);
-    if (lane < 8)
+    if (lane < kClasses)   // lanes 0..7: the segment's count of class `lane`; lane 8: class 8 is absent here (the caller checked)
         lds_at<uint16_t>(lds, kLdsCounts + lane * (kSegments * 2) + segment * 2) =
-            (uint16_t)__builtin_amdgcn_ubfe(lane < 4 ? ta : tb, 8 * lane, 8);
+            lane < 8 ? (uint16_t)__builtin_amdgcn_ubfe(lane < 4 ? ta : tb, 8 * lane, 8) : (uint16_t)0;
 }
 
 // Rank of the lane's block inside its class in this segment, and the segment's class counts into the table.
@@ -140,6 +140,10 @@ __device__ __forceinline__ void rank_and_count(uint8_t* lds, int cls, int lane, 
     if (!TAIL && __ballot(cls >= 8) == 0) {
         rank_by_scan(lds, cls, lane, segment, rank);
     } else {
+        // the segment's column of the table is written whole by this wave -- zeros first, then the counts that exist (LDS
+        // operations of one wave complete in order) -- so the table needs no zero fill and no barrier in front of the ranks
+        if (lane < kClasses)
+            lds_at<uint16_t>(lds, kLdsCounts + lane * (kSegments * 2) + segment * 2) = 0;
         int count;
         rank_in_segment(cls, rank, count);
         if (rank == count - 1 && cls < kClasses)   // the class's last lane in the segment reports its count
@@ -231,9 +235,8 @@ __device__ __forceinline__ void bc7_forward_granule(const uint8_t* __restrict__ 
         if (!TAIL || v * LANES + t < n)
             q[v] = gload16(src + (v * LANES + t) * 16);
     }
-    if (t < kClasses * kSegments)
-        lds_at<uint16_t>(lds, kLdsCounts + 2 * t) = 0;
-    __syncthreads();
+    // no barrier between the loads and the ranks: every wave writes the whole table column of each of its segments itself
+    // (rank_and_count), and the rank of the blocks that have arrived is computed under the loads still in flight
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const bool live = !TAIL || v * LANES + t < n;
@@ -326,8 +329,6 @@ __device__ __forceinline__ void bc7_inverse_granule(const uint8_t* __restrict__ 
             in[v] = gload16(soa + slice_offset(j, v * WAVES + wave, part_blocks, granule_first));
         }
     }
-    if (t < kClasses * kSegments)
-        lds_at<uint16_t>(lds, kLdsCounts + 2 * t) = 0;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int j = v * LANES + t;
