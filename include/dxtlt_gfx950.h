@@ -147,7 +147,13 @@ int32_t dxtlt_transform_range_device(int32_t format, bool inverse, const void *d
  * per (format, direction) present in it -- every workgroup looks up the buffer it belongs to (a small table is copied
  * to the device on `hip_stream` first).  Per-buffer settings, any block counts and alignments.  Asynchronous; ordered
  * like a single call with respect to `hip_stream`; validated as a whole before anything is enqueued.  Items must not
- * overlap one another. */
+ * overlap one another.
+ * Regular batches are recognised and served by shorter paths, with identical results: when all items of one format and
+ * direction have ONE size the owning item is found by a division instead of a table walk; when they also share their
+ * settings and their inputs and outputs each lie a constant stride apart (an array texture) no table is read at all; and
+ * when on top of that every stream of a buffer starts on a 128-byte line and holds a whole number of tiles (any
+ * power-of-two texture) the launch is the single-buffer kernel with one more grid dimension.  INTEGRATION.md section 7
+ * has the rates and one more caller-side lever (transformed buffers not a power of two apart). */
 typedef struct DxtltBatchItem {
     const void *d_input;
     void *d_output;
