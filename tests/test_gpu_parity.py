@@ -72,6 +72,25 @@ def test_every_n_up_to_two_tiles_default_settings(pkg, oracle, dev, fmt):
         assert np.array_equal(got, fwd_oracle(oracle, fmt, x, s)), (fmt, n)
 
 
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_every_n_through_four_tiles_round_trip_and_oracle(pkg, oracle, dev, fmt):
+    """The reference's harness runs transform -> untransform for EVERY block count 1..=max_blocks (bc1 test_prelude.rs:154-181);
+    here every n from 1 to four tiles + 70 (so that every alignment class of the stream bases, every tail length of the
+    element path and every head / tail of the halo ranges occurs), default settings and one non-default combination:
+    forward == oracle, inverse(forward) == input."""
+    t = TILE[fmt]
+    combos = [{"bc1": (1, 0, 1), "bc2": (1, 0, 1), "bc3": (1, 1, 1)}[fmt], {"bc1": (3, 0, 0), "bc2": (2, 0, 0), "bc3": (2, 0, 1)}[fmt]]
+    whole = oracle.fill_splitmix64((4 * t + 70) * BLOCK[fmt], 0xE7E12)
+    for n in range(1, 4 * t + 71):
+        x = whole[: n * BLOCK[fmt]]
+        s = combos[n & 1]
+        want = fwd_oracle(oracle, fmt, x, s)
+        got = run_device(pkg, fmt, x, s, dev)
+        assert np.array_equal(got, want), (fmt, n, "forward")
+        back = run_device(pkg, fmt, want, s, dev, inverse=True)
+        assert np.array_equal(back, x), (fmt, n, "inverse")
+
+
 def test_zero_blocks_is_a_noop(pkg, dev):
     x = torch.empty(0, dtype=torch.uint8, device=dev)
     y = torch.empty(0, dtype=torch.uint8, device=dev)
