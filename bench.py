@@ -146,9 +146,38 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_over_ranks(self, values) -> list:
+        """Every rank's list of floats, in rank order (all_gather; one rank: its own list).  The N > 1 line carries them as
+        `per_rank`, so that a straggler shows in the record and not only in the MAX."""
+        if self.dist is None:
+            return [[float(v) for v in values]]
+        on = self.dev if self.backend == "nccl" else "cpu"
+        mine = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=on)
+        out = [self.torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [[float(x) for x in t.tolist()] for t in out]
+
+    def world_size_seen(self) -> int:
+        """The world size the process group itself reports (RCCL's view under the nccl backend), not the environment's."""
+        return int(self.dist.get_world_size()) if self.dist is not None else 1
+
     def finish(self) -> None:
         if self.dist is not None:
             self.dist.destroy_process_group()
+
+
+def per_rank_record(R, fwd_ms, inv_ms, elapsed_s) -> dict:
+    """`world_size_seen` + `per_rank` of the JSON line: every rank's own HIP-event times and wall clock of the timed steps
+    (a collective: every rank calls it).  With them the first record taken on more than one device shows a straggler and
+    proves that the process group -- RCCL under the nccl backend -- saw N ranks."""
+    rows = R.gather_over_ranks([R.rank, -1.0 if fwd_ms is None else fwd_ms, -1.0 if inv_ms is None else inv_ms, elapsed_s])
+    per_rank = []
+    for r, f, i, e in rows:
+        row = {"rank": int(r), "elapsed_s": round(e, 5)}
+        if f >= 0:
+            row.update({"fwd_ms": round(f, 4), "inv_ms": round(i, 4)})
+        per_rank.append(row)
+    return {"world_size_seen": R.world_size_seen(), "backend": R.backend if R.dist is not None else "none", "per_rank": per_rank}
 
 
 def rendezvous_only(args) -> None:
@@ -158,8 +187,11 @@ def rendezvous_only(args) -> None:
     R = Ranks(args, need_gpu=False)
     R.barrier()
     worst = R.max_over_ranks(float(R.rank + 1))
+    per_rank = R.gather_over_ranks([float(R.rank + 1), float(10 * R.rank)])
+    seen = R.world_size_seen()
     if R.rank == 0:
-        print(json.dumps({"rendezvous": "ok", "n_gpus": R.world, "max_over_ranks": worst, "backend": R.backend}), flush=True)
+        print(json.dumps({"rendezvous": "ok", "n_gpus": R.world, "max_over_ranks": worst, "backend": R.backend,
+                          "world_size_seen": seen, "per_rank": per_rank}), flush=True)
     R.finish()
 
 
@@ -433,10 +465,13 @@ def leg_cpu_baseline(fmt: str, sample, mode_mix=None) -> dict:
     run(cores)
     one, allc = run(1), run(cores)
     assert np.array_equal(z, sample)
+    note = ("the reference dispatches BC3 with split alphas + split colours + decorrelation to its scalar loop "
+            "(bc3 with_split_alphas_colour_and_recorr/transform/mod.rs:31): this leg is upstream's own path") if fmt == "bc3" else (
+            "scalar port of the reference's loops; the reference has vectorised paths for these settings that this figure does "
+            "not reproduce (the headline's cpu_baseline carries the AVX-512 / AVX2 ports)")
     return {"value": one, "unit": "GiB/s", "cores": 1, "kind": "port", "all_cores_value": allc, "all_cores": cores,
             "sample": f"{sample.size >> 20} MiB of the leg's blocks, forward+inverse, best of 3, scalar C oracle (gcc -O3)",
-            "note": "the reference dispatches BC3 with split alphas + split colours + decorrelation to its scalar loop "
-                    "(bc3 with_split_alphas_colour_and_recorr/transform/mod.rs:31): this leg is upstream's own path"}
+            "note": note}
 
 
 def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int, cpu: bool = True) -> dict:
@@ -476,6 +511,24 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int, cpu: bool = True
         {"bit_exact_roundtrip": bool(torch.equal(z3, x3)), "oracle_window_exact": bool(np.array_equal(got, want))})
     if cpu:
         legs["bc3"]["cpu_baseline"] = leg_cpu_baseline("bc3", x3[: min(n3, 256 << 20)].cpu().numpy())
+
+    # BC2 (north_star names it beside BC1 / BC3; bc2 transform_with_settings.rs:30,93): default settings, same shape as the BC3 leg
+    st2 = pkg.Bc2TransformSettings()
+    pkg.fill_splitmix64(x3, 0x0BC20002, 0)
+    z3.zero_()
+    f_ms, i_ms, wall = timed_pair(torch, lambda: pkg.transform_bc2_with_settings(x3, y3, st2),
+                                  lambda: pkg.untransform_bc2_with_settings(y3, z3, st2), steps, warmup)
+    want = oracle_c.transform("bc2", x3[lf * 16:(lf + win) * 16].cpu().numpy(), 1, True, False)
+    got = np.empty_like(want)
+    for off, w in pkg.stream_table("bc2", st2):
+        lo = off * blocks + w * lf
+        got[off * win: off * win + w * win] = y3[lo: lo + w * win].cpu().numpy()
+    legs["bc2"] = leg_record(
+        f"BC2 forward+inverse, default settings (YCoCg Variant1, split colour endpoints), {n3 / 2**30:g} GiB random block buffer",
+        n3, f_ms, i_ms, wall, steps, "fwd_tiled<bc2>", "inv_tiled<bc2>",
+        {"bit_exact_roundtrip": bool(torch.equal(z3, x3)), "oracle_window_exact": bool(np.array_equal(got, want))})
+    if cpu:
+        legs["bc2"]["cpu_baseline"] = leg_cpu_baseline("bc2", x3[: min(n3, 256 << 20)].cpu().numpy())
 
     # configs[3]: BC7, this build's own format; two mode mixes
     n7 = min(cap, 4 << 30)
@@ -548,10 +601,14 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int, cpu: bool = True
         note = f"{src}: committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 rule, WRITE_SIZE); NOT measured by this run"
         if lt.get("bc3", {}).get("bytes") == n3 and lt["bc3"].get("fwd"):
             legs["bc3"]["roofline"].update({"traffic": lt["bc3"]["fwd"], "inverse_traffic": lt["bc3"]["inv"], "traffic_source": note})
+        if lt.get("bc2", {}).get("bytes") == n3 and lt["bc2"].get("fwd"):
+            legs["bc2"]["roofline"].update({"traffic": lt["bc2"]["fwd"], "inverse_traffic": lt["bc2"]["inv"], "traffic_source": note})
         for mix in ("uniform", "skewed"):
-            if lt.get("bc7", {}).get("bytes") == n7 and lt["bc7"].get("fwd"):
-                legs[f"bc7_{mix}"]["roofline"].update({"traffic": lt["bc7"]["fwd"], "inverse_traffic": lt["bc7"]["inv"],
-                                                       "traffic_source": note + " (uniform mix)"})
+            # a traffic figure rides only in the leg whose mode mix was profiled ("bc7" = the uniform mix of earlier rounds)
+            rec7 = lt.get(f"bc7_{mix}") or (lt.get("bc7") if mix == "uniform" else None) or {}
+            if rec7.get("bytes") == n7 and rec7.get("fwd"):
+                legs[f"bc7_{mix}"]["roofline"].update({"traffic": rec7["fwd"], "inverse_traffic": rec7["inv"],
+                                                       "traffic_source": note + f" ({mix} mix)"})
         at = lt.get("archive_texture", {})
         if at.get("bytes") == tex and all(at.get(x) for x in ("bc1_fwd", "bc3_fwd", "bc1_inv", "bc3_inv")):
             legs["archive"]["roofline"].update({"traffic": (at["bc1_fwd"] + at["bc3_fwd"]) * (k // 2),
@@ -563,6 +620,138 @@ def run_legs(pkg, torch, dev, x, y, z, steps: int, warmup: int, cpu: bool = True
         bad = [c for c, v in leg.items() if c.endswith("exact") or c.startswith("bit_exact") if v is not True]
         assert not bad, f"leg {name}: {bad} failed"
     return legs
+
+
+# ---- the corpus-shaped leg ---------------------------------------------------------------------------------------------
+# The reference's own published benchmark is not one big buffer: it is "2130 real files (8692.9 MiB)" of BC1 DDS textures
+# (api/dxt-lossless-transform-bc1-api/README.MD:286-311), transformed file after file.  A DDS texture with a full mip chain
+# has an ODD block count (... + 4 + 1 + 1 + 1 blocks for the 8x8, 4x4, 2x2 and 1x1 levels), so every stream base of its
+# transformed buffer is off its 16-byte / 128-byte boundary: the halo / shifted tile forms and ragged tails, not the aligned
+# tiles the 2^k-byte legs run.  This leg rebuilds that shape synthetically: 2130 textures with full mip chains, dimensions
+# 256..4096, 8693 MiB as BC1, resident in HBM side by side (each at the next 256-byte boundary, what an allocator hands out),
+# ONE dxtlt_transform_batch_device call per direction.
+CORPUS_CLASSES = [  # (width, height, count): 2130 textures, 8693 MiB as BC1 with full mip chains
+    (4096, 4096, 540), (4096, 2048, 200), (2048, 2048, 500), (2048, 1024, 200), (1024, 1024, 300), (1024, 512, 100),
+    (512, 512, 150), (512, 256, 50), (256, 256, 90),
+]
+
+
+def mip_chain_blocks(width: int, height: int) -> int:
+    """4x4 blocks of a texture with its full mip chain (every level down to 1x1, each at least one block)."""
+    n = 0
+    while True:
+        n += ((width + 3) // 4) * ((height + 3) // 4)
+        if width == 1 and height == 1:
+            return n
+        width, height = max(1, width // 2), max(1, height // 2)
+
+
+def corpus_textures(count_scale: float = 1.0, seed: int = 0xC0A9005) -> list:
+    """[(width, height, blocks)] of the corpus in a fixed shuffled order (a directory walk does not sort by size)."""
+    import random
+
+    texs = []
+    for w, h, c in CORPUS_CLASSES:
+        texs += [(w, h, mip_chain_blocks(w, h))] * max(1, int(round(c * count_scale)))
+    random.Random(seed).shuffle(texs)
+    return texs
+
+
+def corpus_layout(texs, block_bytes: int, align: int = 256):
+    """Byte offset of every texture in an arena where each starts at the next `align`-byte boundary; (offsets, arena bytes)."""
+    offs, at = [], 0
+    for _, _, blocks in texs:
+        offs.append(at)
+        at = (at + blocks * block_bytes + align - 1) // align * align
+    return offs, at
+
+
+def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_scale: float = 1.0, cpu: bool = True) -> dict:
+    """One corpus-shaped leg (see CORPUS_CLASSES): device-resident textures, one batch call per direction, HIP events per
+    direction, exact round trip over the whole arena, oracle equality on three whole textures (the smallest, a middle one,
+    one of the largest)."""
+    import numpy as np
+
+    from dxt_lossless_transform_amd import batch
+    from oracle import oracle_c
+
+    B = pkg.BLOCK_BYTES[fmt]
+    st = {"bc1": pkg.Bc1TransformSettings, "bc2": pkg.Bc2TransformSettings, "bc3": pkg.Bc3TransformSettings}[fmt]()
+    texs = corpus_textures(count_scale)
+    if fmt != "bc1":
+        texs = texs[::2]                     # 16-byte blocks: every second texture, the same ~8.5 GiB
+    offs, arena = corpus_layout(texs, B)
+    x = torch.empty(arena, dtype=torch.uint8, device=dev)
+    y = torch.zeros(arena, dtype=torch.uint8, device=dev)
+    z = torch.zeros(arena, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, 0xC0A90000 + B, 0)
+    nbytes = 0
+    for (w, h, blocks), o in zip(texs, offs):   # the gaps between textures: zero in all three arenas
+        end = o + blocks * B
+        nbytes += blocks * B
+        x[end:(end + 255) // 256 * 256].zero_()
+    views = [(x[o:o + n * B], y[o:o + n * B], z[o:o + n * B]) for (_, _, n), o in zip(texs, offs)]
+    fwd_items = batch.prepare_batch([(fmt, False, xi, yi, st) for xi, yi, _ in views])
+    inv_items = batch.prepare_batch([(fmt, True, yi, zi, st) for _, yi, zi in views])
+    f_ms, i_ms, wall = timed_pair(torch, lambda: batch.run_prepared_batch(fwd_items),
+                                  lambda: batch.run_prepared_batch(inv_items), steps, warmup)
+    order = sorted(range(len(texs)), key=lambda i: texs[i][2])
+    ok = True
+    mode, sa, sc = int(st.decorrelation_mode), getattr(st, "split_alpha_endpoints", True), st.split_colour_endpoints
+    for i in (order[0], order[len(order) // 2], order[-1]):
+        want = oracle_c.transform(fmt, views[i][0].cpu().numpy(), mode, sc, sa)
+        ok = ok and bool(np.array_equal(views[i][1].cpu().numpy(), want))
+    odd = sum(1 for _, _, n in texs if n % 2)
+    leg = leg_record(
+        f"{fmt.upper()} corpus shape of the reference's published benchmark (bc1-api README.MD:286-311: 2130 files, 8692.9 MiB): "
+        f"{len(texs)} device-resident textures with full mip chains, 256..4096 pixels a side, {nbytes / 2**20:.1f} MiB, "
+        f"{odd} of them with an odd block count, each at the next 256-byte boundary of one arena; default settings; ONE "
+        "dxtlt_transform_batch_device call per direction", nbytes, f_ms, i_ms, wall, steps,
+        f"batch tiles<{fmt}> forward (halo + edge tiles)", f"batch tiles<{fmt}> inverse (shifted + edge tiles)",
+        {"bit_exact_roundtrip": bool(torch.equal(z, x)), "oracle_textures_exact": ok, "textures": len(texs),
+         "smallest_blocks": texs[order[0]][2], "largest_blocks": texs[order[-1]][2]})
+    if cpu:
+        sample = views[order[-1]][0].cpu().numpy()
+        leg["cpu_baseline"] = leg_cpu_baseline(fmt, sample) if fmt != "bc1" else cpu_baseline_corpus_bc1(sample)
+    return leg
+
+
+def cpu_baseline_corpus_bc1(sample) -> dict:
+    """BC1 default settings on one of the corpus' largest textures, one core: the widest SIMD port this host has (the
+    reference's published figures are one thread per file), scalar beside it."""
+    import numpy as np
+
+    from oracle import oracle_c
+
+    y, z = np.zeros_like(sample), np.zeros_like(sample)
+
+    def best(fn):
+        b = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            b = dt if b is None else min(b, dt)
+        return round(2 * sample.size / b / 2**30, 3)
+
+    def scalar():
+        oracle_c.run_mt("bc1", sample, y, 1, True, False, False, 1)
+        oracle_c.run_mt("bc1", y, z, 1, True, False, True, 1)
+
+    out = {"value": best(scalar), "unit": "GiB/s", "cores": 1, "kind": "port",
+           "sample": f"one texture of the corpus ({sample.size / 2**20:.2f} MiB, odd block count), forward+inverse, best of 5, "
+                     "scalar C oracle (gcc -O3)"}
+    assert np.array_equal(z, sample)
+    if oracle_c.simd_available():
+        def simd():
+            oracle_c.run_bc1_default_simd(sample, y, False, 1)
+            oracle_c.run_bc1_default_simd(y, z, True, 1)
+
+        z[:] = 0
+        v = best(simd)
+        assert np.array_equal(z, sample)
+        out.update({"scalar_value": out["value"], "value": v, "isa": oracle_c.SIMD_NAMES[oracle_c.simd_level()]})
+    return out
 
 
 def bc7_main(args) -> None:
@@ -613,10 +802,11 @@ def bc7_main(args) -> None:
         ev[k][2].record()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = R.max_over_ranks(elapsed)
+    elapsed_here = time.perf_counter() - t0
+    elapsed = R.max_over_ranks(elapsed_here)
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    per_rank = per_rank_record(R, fwd_ms, inv_ms, elapsed_here)
     ok = bool(torch.equal(z, x))
     cpu = None
     if rank == 0:
@@ -650,7 +840,7 @@ def bc7_main(args) -> None:
         "value": round(2 * nbytes * args.steps * world / elapsed / 2**30, 2),
         "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic", "clock_warmup_ms": LEG_WARM_MS,
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic", "clock_warmup_ms": LEG_WARM_MS, **per_rank,
         "config": {
             "workload": f"BC7 granule-sorted field split v2, forward+inverse (this build's own format, parity unpinned), {nbytes / 2**30:g} GiB "
                         "synthetic mode-mixed buffer per GPU, modes 0-7 uniform (BASELINE.json configs[3])",
@@ -752,8 +942,9 @@ def archive_main(args) -> None:
         step()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = R.max_over_ranks(elapsed)
+    elapsed_here = time.perf_counter() - t0
+    elapsed = R.max_over_ranks(elapsed_here)
+    per_rank = per_rank_record(R, None, None, elapsed_here)
 
     ok = all(bool(torch.equal(z, x)) for x, z in zip(xs, zs))
     win = 1 << 15
@@ -799,7 +990,7 @@ def archive_main(args) -> None:
     out = {
         "metric": "GiB/s BC blocks transformed (fwd+inv)", "value": round(total / elapsed / 2**30, 2), "unit": "GiB/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", **per_rank,
         "config": {
             "workload": f"BC1+BC3 mixed archive, {archive_gib:g} GiB of alternating 256 MiB textures, default settings per format, "
                         + ("every texture's block range cut over the ranks (dxtlt_transform_range_device), " if by_range else
@@ -1015,11 +1206,12 @@ def main() -> None:
         ev[k][2].record()
     torch.cuda.synchronize()
     R.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = R.max_over_ranks(elapsed)
+    elapsed_here = time.perf_counter() - t0
+    elapsed = R.max_over_ranks(elapsed_here)
 
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    per_rank = per_rank_record(R, fwd_ms, inv_ms, elapsed_here)
 
     # correctness inside the run: exact round trip, and one window against the oracle
     bit_exact = bool(torch.equal(z, x))
@@ -1087,6 +1279,7 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
+        **per_rank,
         "config": {
             "workload": f"{fmt.upper()} forward+inverse, "
                         + (f"settings {args.settings} (variant,split_alpha,split_colour), " if args.settings else f"default settings ({dflt}), ")
@@ -1112,6 +1305,13 @@ def main() -> None:
     if default_run and args.leg_steps > 0:
         # the other single-GPU configurations of BASELINE.json, on the same three device buffers (x is overwritten)
         out["legs"] = run_legs(pkg, torch, dev, x, y, z, args.leg_steps, 2, cpu=not args.no_cpu_baseline)
+        # the reference's own benchmark shape: a corpus of mip-chained textures through one batch call per direction
+        del x, y, z
+        torch.cuda.empty_cache()
+        scale = 1.0 if nbytes >= (4 << 30) else 0.01
+        out["legs"]["corpus"] = run_corpus_leg(pkg, torch, dev, "bc1", args.leg_steps, 2, scale, cpu=not args.no_cpu_baseline)
+        out["legs"]["corpus_bc3"] = run_corpus_leg(pkg, torch, dev, "bc3", args.leg_steps, 2, scale, cpu=not args.no_cpu_baseline)
+        x = y = z = None
     host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
     if host_gib > 0 and not args.drop_blocks:
         del y, z

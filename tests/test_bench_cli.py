@@ -48,7 +48,8 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec == {"rendezvous": "ok", "n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo"}
+    assert rec == {"rendezvous": "ok", "n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo", "world_size_seen": 2,
+                   "per_rank": [[1.0, 0.0], [2.0, 10.0]]}
 
 
 def test_stdout_of_a_launcher_run_is_one_json_line():
@@ -71,7 +72,8 @@ def test_stdout_of_a_launcher_run_is_one_json_line():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
-    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 3, "max_over_ranks": 3.0, "backend": "gloo"}
+    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 3, "max_over_ranks": 3.0, "backend": "gloo",
+                                    "world_size_seen": 3, "per_rank": [[1.0, 0.0], [2.0, 10.0], [3.0, 20.0]]}
 
 
 def test_bench_self_launch_returns_the_childs_exit_code():
@@ -135,12 +137,15 @@ def test_default_line_carries_the_other_single_gpu_configs_as_legs():
     small buffer.  Each leg has both directions' times, a roofline fraction and its own exactness flags."""
     d = _run_bench(["--host-array-gib", "0", "--small-legs", "--leg-steps", "2"])
     legs = d["legs"]
-    assert set(legs) == {"bc3", "bc7_uniform", "bc7_skewed", "archive"}
+    assert set(legs) == {"bc3", "bc2", "bc7_uniform", "bc7_skewed", "archive", "corpus", "corpus_bc3"}
     for name, leg in legs.items():
         assert leg["bit_exact_roundtrip"] is True, name
         assert leg["fwd_ms"] > 0 and leg["inv_ms"] > 0 and 0 < leg["roofline"]["frac"] < 1, name
         assert 0 < leg["roofline"]["inverse_kernel"]["frac"] < 1, name
-    assert legs["bc3"]["oracle_window_exact"] and legs["archive"]["oracle_windows_exact"]
+    assert legs["bc3"]["oracle_window_exact"] and legs["bc2"]["oracle_window_exact"] and legs["archive"]["oracle_windows_exact"]
+    for name in ("corpus", "corpus_bc3"):     # the reference's benchmark shape in miniature: mip-chained, odd block counts, one batch call
+        assert legs[name]["oracle_textures_exact"] is True and legs[name]["textures"] >= 9
+        assert legs[name]["largest_blocks"] == 1398103 and legs[name]["smallest_blocks"] % 2 == 1   # 4096 x 4096 with mips; odd counts
     assert legs["bc7_uniform"]["oracle_prefix_exact"] and legs["bc7_skewed"]["oracle_prefix_exact"]
     assert legs["bc7_skewed"]["mode_counts"][6] > 2 * legs["bc7_uniform"]["mode_counts"][6]
     # without the switch a small buffer has no legs (they are defined on the BASELINE sizes)
@@ -154,6 +159,8 @@ def test_bench_two_ranks_self_launched_on_one_gpu(scaling):
     Strong scaling = one array, each rank its block range through dxtlt_transform_range_device."""
     d = _run_bench(["--gpus", "2", "--scaling", scaling, "--host-array-gib", "0"], env={"DXTLT_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == scaling
+    assert d["world_size_seen"] == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1]
+    assert all(r["fwd_ms"] > 0 and r["inv_ms"] > 0 and r["elapsed_s"] > 0 for r in d["per_rank"])
     assert d["config"]["bit_exact_roundtrip_and_oracle_window"] is True
     total = d["config"]["total_blocks"]
     assert total == (d["config"]["blocks_per_gpu"] * 2)      # strong: the array split in two; weak: two shards of one array
@@ -195,4 +202,7 @@ def test_eight_rank_rendezvous_the_driver_shape():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
-    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 8, "max_over_ranks": 8.0, "backend": "gloo"}
+    # world_size_seen is the process group's own count; per_rank = every rank's figures in rank order (all_gather): the keys a
+    # real N > 1 line carries so that the first SCALE record shows stragglers and proves the group saw N ranks
+    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 8, "max_over_ranks": 8.0, "backend": "gloo",
+                                    "world_size_seen": 8, "per_rank": [[float(r + 1), float(10 * r)] for r in range(8)]}
