@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdxtlt_gfx950.so")
 OBJ_DIR = os.path.join(os.path.dirname(_HERE), "build", "obj")
 
-SOURCES = ["bcn_kernels.hip", "dxtlt_api.cpp", "c_api_core.cpp", "c_api_stable.cpp", "auto_transform.cpp", "file_format.cpp",
+SOURCES = ["bcn_kernels.hip", "batch_kernels.hip", "dxtlt_api.cpp", "c_api_core.cpp", "c_api_stable.cpp", "auto_transform.cpp", "file_format.cpp",
            "bc7_kernels.hip", "bc7_api.cpp", "bc7_sharded.cpp", "bc1_normalize.hip", "normalize_api.cpp", "batch_api.cpp", "bc23_normalize.hip",
            "normalize23_api.cpp", "color565_ops.hip", "color565_api.cpp", "bcn_decode.hip", "decode_api.cpp",
            "auto_kernels.hip", "numa_affinity.cpp"]

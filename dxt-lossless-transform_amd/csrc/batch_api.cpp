@@ -152,43 +152,54 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
     }
     hipStream_t user = static_cast<hipStream_t>(hip_stream);
 
-    // one table per (format, direction) group, planned (and checked against the launch limit) before anything is enqueued;
-    // the groups are launched one after the other on the caller's stream, behind the BC7 launches
+    // one table per (format, direction, settings) group, planned (and checked against the launch limit) before anything is
+    // enqueued; the groups are launched one after the other on the caller's stream, behind the BC7 launches.  The kernel is
+    // instantiated per settings combination (no run-time switch in front of every tile): a corpus usually has one or two.
     struct Group {
         std::vector<BatchEntry> entries;
         uint32_t wgs = 0;
-        uint32_t uniform_wgs = 0;   // workgroups per buffer (padded to a multiple of 8) while all buffers own the same number
+        uint32_t uniform_wgs = 0;   // workgroups per buffer while all buffers own the same number
         bool uniform = true;
     };
-    Group groups[6];
+    constexpr int kGroups = 3 * 2 * 16;   // format, direction, variant x split_alpha x split_colour
+    std::vector<Group> groups(kGroups);
+    auto group_settings = [](int gi) {
+        dxtlt::Settings s{};
+        s.variant = (gi >> 2) & 3;
+        s.split_alpha = ((gi >> 1) & 1) != 0;
+        s.split_colour = (gi & 1) != 0;
+        return s;
+    };
+    std::vector<size_t> singles;   // items the batch kernel does not take (plan_batch_entry): launched alone, behind the batches
     for (size_t i = 0; i < count; ++i) {
         const DxtltBatchItem& it = items[i];
         if (it.len == 0 || it.format == 7)
             continue;
         if (it.len >= (size_t(64) << 30))
             return fail(kInvalidArgument, "batch item of 64 GiB or more: use the single-buffer entry point");
-        Group& g = groups[(it.format - 1) * 2 + (it.inverse ? 1 : 0)];
+        const int sa = it.format == 3 && it.split_alpha_endpoints ? 1 : 0, sc = it.split_colour_endpoints ? 1 : 0;
+        const int gi = (((it.format - 1) * 2 + (it.inverse ? 1 : 0)) << 4) | (it.decorrelation_mode << 2) | (sa << 1) | sc;
+        Group& g = groups[gi];
         BatchEntry e{};
         e.src = static_cast<const uint8_t*>(it.d_input);
         e.dst = static_cast<uint8_t*>(it.d_output);
         e.blocks = it.len / (it.format == 1 ? 8u : 16u);
-        e.variant = it.decorrelation_mode;
-        e.split_alpha = it.format == 3 && it.split_alpha_endpoints ? 1 : 0;
-        e.split_colour = it.split_colour_endpoints ? 1 : 0;
-        g.wgs = (g.wgs + 7u) & ~7u;   // first workgroup on XCD 0: the kernel orders each buffer's tiles per XCD
         e.first_wg = g.wgs;
-        const uint32_t wgs = dxtlt::plan_batch_entry((dxtlt::Format)it.format, it.inverse != 0, e);
-        // one launch holds fewer than 2^32 threads = 2^24 workgroups of 256 (64 GiB of blocks per format and direction)
+        const uint32_t wgs = dxtlt::plan_batch_entry((dxtlt::Format)it.format, it.inverse != 0, group_settings(gi), e);
+        if (wgs == 0xFFFFFFFFu) {
+            singles.push_back(i);
+            continue;
+        }
+        // one launch holds fewer than 2^32 threads = 2^24 workgroups of 256 (64 GiB of blocks per format, direction and settings)
         if ((uint64_t)g.wgs + wgs > 0xFFFFFFull)
-            return fail(kInvalidArgument, "batch too large for one launch (64 GiB or more of one format and direction)");
+            return fail(kInvalidArgument, "batch too large for one launch (64 GiB or more of one format, direction and settings)");
         g.wgs += wgs;
         g.entries.push_back(e);
-        // buffers of one size: every entry owns the same (padded) number of workgroups -- the kernel then divides instead
-        // of looking the entry up; the last buffer's padding is launched too (those workgroups find nothing to do)
-        const uint32_t padded = (wgs + 7u) & ~7u;
+        // buffers of one size: every entry owns the same number of workgroups -- the kernel then divides instead of looking
+        // the entry up
         if (g.entries.size() == 1)
-            g.uniform_wgs = padded;
-        else if (padded != g.uniform_wgs)
+            g.uniform_wgs = wgs;
+        else if (wgs != g.uniform_wgs)
             g.uniform = false;
     }
     static const bool no_uniform = std::getenv("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switches (tools/batch_kernel_probe.py)
@@ -246,7 +257,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             return fail(kDevice, "batch event", ev);
     }
 
-    for (int gi = 0; gi < 6; ++gi) {
+    for (int gi = 0; gi < kGroups; ++gi) {
         Group& g = groups[gi];
         if (g.entries.empty())
             continue;
@@ -263,27 +274,27 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         size_t cur = 0;
         for (size_t k = 0; k < coarse_n; ++k) {
             const uint32_t wg = (uint32_t)(k * 64);
-            while (cur + 1 < n && g.entries[cur + 1].first_wg <= wg)
+            while (cur + 1 < n && g.entries[cur].end_wg <= wg)
                 ++cur;
             coarse[k] = (uint32_t)cur;
         }
-        const bool uniform = g.uniform && !no_uniform && (uint64_t)g.uniform_wgs * n <= 0xFFFFFFull;
-        // a regular array of buffers: one size, one set of settings and tile form, pointers a constant stride apart
+        const bool uniform = g.uniform && !no_uniform;
+        // a regular array of buffers: one size and tile form, pointers a constant stride apart
         bool strided = uniform && !no_strided;   // (one buffer is a regular array too)
         const int64_t src_stride = n >= 2 ? (int64_t)(g.entries[1].src - g.entries[0].src) : 0;
         const int64_t dst_stride = n >= 2 ? (int64_t)(g.entries[1].dst - g.entries[0].dst) : 0;
         for (size_t i = 1; i < n && strided; ++i) {
             const BatchEntry &a = g.entries[0], &b = g.entries[i];
-            strided = b.blocks == a.blocks && b.tile_wgs == a.tile_wgs && b.variant == a.variant && b.split_alpha == a.split_alpha &&
-                      b.split_colour == a.split_colour && b.form == a.form && b.halo_vecs == a.halo_vecs &&
-                      std::memcmp(b.shift, a.shift, sizeof a.shift) == 0 &&
+            strided = b.blocks == a.blocks && b.full_tiles == a.full_tiles && b.form == a.form && b.halo_vecs == a.halo_vecs &&
+                      std::memcmp(b.shift, a.shift, sizeof a.shift) == 0 && std::memcmp(b.gbase, a.gbase, sizeof a.gbase) == 0 &&
                       b.src == a.src + (int64_t)i * src_stride && b.dst == a.dst + (int64_t)i * dst_stride;
         }
         e = upload_table(slot, bytes, user);
         if (e == hipSuccess)
-            e = dxtlt::launch_batch((dxtlt::Format)(gi / 2 + 1), (gi & 1) != 0, static_cast<const BatchEntry*>(slot->dev),
+            e = dxtlt::launch_batch((dxtlt::Format)((gi >> 5) + 1), ((gi >> 4) & 1) != 0, group_settings(gi),
+                                    static_cast<const BatchEntry*>(slot->dev),
                                     reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(slot->dev) + entry_bytes),
-                                    (uint32_t)n, uniform ? g.uniform_wgs * (uint32_t)n : g.wgs, uniform ? g.uniform_wgs : 0, user,
+                                    (uint32_t)n, g.wgs, uniform ? g.uniform_wgs : 0, user,
                                     strided ? &g.entries[0] : nullptr, src_stride, dst_stride);
         // the event marks both the copy and the kernel that reads the device table
         hipError_t ev = hipEventRecord(slot->done, user);
@@ -292,6 +303,19 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             return fail(kDevice, "batch table copy / launch", e);
         if (ev != hipSuccess)
             return fail(kDevice, "batch event", ev);
+    }
+    // buffers whose transformed-side pointer is not 8-byte aligned: the single-buffer call, one launch each
+    for (size_t i : singles) {
+        const DxtltBatchItem& it = items[i];
+        dxtlt::Settings s{};
+        s.variant = it.decorrelation_mode;
+        s.split_alpha = it.format == 3 && it.split_alpha_endpoints;
+        s.split_colour = it.split_colour_endpoints != 0;
+        const uint64_t blocks = it.len / (it.format == 1 ? 8u : 16u);
+        const hipError_t e = dxtlt::launch_transform((dxtlt::Format)it.format, it.inverse != 0, s, it.d_input, it.d_output,
+                                                     dxtlt::Range{blocks, 0, blocks}, user);
+        if (e != hipSuccess)
+            return fail(kDevice, "batch item launch", e);
     }
     return kOk;
 }

@@ -1,0 +1,276 @@
+// batch_kernels.hip -- many buffers of one format, direction and settings in ONE launch (dxtlt_transform_batch_device).
+//
+// A texture of a few MiB cannot fill 256 CUs, and launching textures one by one is bound by the ~5 us a launch costs the
+// host.  Here every workgroup looks up which buffer it belongs to and runs one tile of it: the tile the single-buffer call
+// would pick for that buffer (bcn_device.h) -- aligned, forward halo or inverse shifted -- or the buffer's edge tile.
+//
+// What round 4 changed, and why (profiles/r03_batch_spacing.txt, profiles/r04_batch_*): the reference's own benchmark is
+// a corpus of ~4 MiB DDS textures with mip chains (bc1-api README.MD:286-311), i.e. odd block counts, and on such buffers the
+// round-3 kernel sat at 0.57-0.72 of the HBM peak where the single call does 0.82:
+//   * heads and tails went through 256-block workgroups of the element path (one lane per block, 8-11 narrow stores per
+//     lane) -- now ONE edge tile per buffer moves them as 16-byte vectors like every other tile, and a buffer owns exactly
+//     ceil(blocks / T) (+1 forward when only stream tails are left) workgroups: no element path, no padding to multiples of 8;
+//   * every workgroup decoded its entry and switched over variant / splits / tile form at run time: 58 scalar instructions per
+//     wave on the one scalar unit a CU's four SIMDs share -- now the kernel is instantiated per settings (the host launches
+//     one kernel per settings combination present in the batch; a corpus usually has one) and the entry carries the
+//     per-stream bases (Shifts::gbase) ready-made instead of six 64-bit products per workgroup.
+#include <cstdlib>
+
+#include "bcn_device.h"
+
+namespace dxtlt {
+
+// A table entry as the workgroup sees it: everything arrives through scalar (dword) loads -- byte fields read one by
+// one would go through the vector memory path and add a second round trip before the tile's own load can start --
+// and the buffer pointers are tagged as global memory again (a pointer that was loaded from memory is a generic one
+// to the compiler, which would turn every access of the tile into a flat_* instruction).
+struct BatchView {
+    const uint8_t* src;
+    uint8_t* dst;
+    uint64_t blocks;
+    uint32_t first_wg, end_wg, full_tiles;
+    uint32_t flags;       // form | halo_vecs << 8 | natural << 16
+    uint32_t shifts[2];   // shift[0..3], shift[4..5]
+    uint64_t gbase[6];
+};
+
+typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
+typedef __attribute__((address_space(1))) uint8_t* global_ptr;
+
+__device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
+{
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(entry);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(entry);
+    BatchView v;
+    v.src = (const uint8_t*)(global_cptr)q[0];
+    v.dst = (uint8_t*)(global_ptr)q[1];
+    v.blocks = q[2];
+    v.first_wg = w[6];
+    v.end_wg = w[7];
+    v.full_tiles = w[8];
+    v.flags = w[9];
+    v.shifts[0] = w[10];
+    v.shifts[1] = w[11];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        v.gbase[i] = q[6 + i];
+    return v;
+}
+static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, full_tiles) == 32 && offsetof(BatchEntry, form) == 36 &&
+                  offsetof(BatchEntry, shift) == 40 && offsetof(BatchEntry, gbase) == 48,
+              "load_batch_entry reads BatchEntry by dword offsets");
+
+constexpr uint32_t kBatchAligned = 1;   // BatchEntry::form
+
+// uniform_wgs != 0: every buffer of the launch owns exactly that many workgroups (buffers of one size -- the texture
+// sets a batch is made for), so the owning entry is wg / uniform_wgs and ONE scalar load -- the entry, a line every
+// workgroup of the buffer shares -- stands between the start of the workgroup and its tile's load instead of two
+// dependent ones (coarse index, then entry).  The quotient comes from a multiply-high with magic = floor(2^32 /
+// uniform_wgs): exact or one short for wg < 2^24, put right by one compare.
+//
+// strided.on: the batch is a regular array of buffers -- one size, sources and destinations each a constant stride apart (an
+// array texture, the mip level of a texture set that a decompressor wrote into one allocation).  Its first entry then
+// travels in the kernel arguments with the two strides, and a workgroup reaches its tile without any table load at all:
+// entry = first entry with both pointers advanced by (wg / uniform_wgs) strides.
+struct StridedBatch {
+    BatchEntry first;
+    int64_t src_stride, dst_stride;
+    uint32_t on;
+};
+
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
+__global__ void __launch_bounds__(256)
+batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t uniform_wgs, uint32_t magic,
+             StridedBatch strided)
+{
+    constexpr int kLds = INVERSE ? kShiftLdsBytes : halo_lds_bytes<FMT>();
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
+    const uint32_t wg = blockIdx.x;
+    BatchView en;
+    if (uniform_wgs != 0) {
+        uint32_t e = __umulhi(wg, magic);
+        if ((e + 1) * uniform_wgs <= wg)
+            ++e;
+        if (strided.on != 0) {
+            // kernel arguments: scalar loads off the kernarg pointer, nothing depends on a table
+            const BatchEntry& f = strided.first;
+            en.src = (const uint8_t*)(global_cptr)(reinterpret_cast<uintptr_t>(f.src) + (uint64_t)((int64_t)e * strided.src_stride));
+            en.dst = (uint8_t*)(global_ptr)(reinterpret_cast<uintptr_t>(f.dst) + (uint64_t)((int64_t)e * strided.dst_stride));
+            en.blocks = f.blocks;
+            en.first_wg = e * uniform_wgs;
+            en.end_wg = en.first_wg + uniform_wgs;
+            en.full_tiles = f.full_tiles;
+            en.flags = (uint32_t)f.form | ((uint32_t)f.halo_vecs << 8) | ((uint32_t)f.natural << 16);
+            en.shifts[0] = (uint32_t)f.shift[0] | ((uint32_t)f.shift[1] << 8) | ((uint32_t)f.shift[2] << 16) | ((uint32_t)f.shift[3] << 24);
+            en.shifts[1] = (uint32_t)f.shift[4] | ((uint32_t)f.shift[5] << 8);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                en.gbase[i] = f.gbase[i];
+        } else {
+            en = load_batch_entry(entries + e);
+        }
+    } else {
+        // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each and carry
+        // their own end, so a workgroup of a buffer with 64 workgroups or more is two dependent scalar loads away from its
+        // tile's load (with buffers of a few hundred workgroups every one of these loads misses the scalar cache: a CU sees
+        // about one workgroup per buffer)
+        uint32_t e = coarse[wg >> 6];
+        en = load_batch_entry(entries + e);
+        while (en.end_wg <= wg) {   // only buffers of fewer than 64 workgroups take this
+            ++e;
+            en = load_batch_entry(entries + e);
+        }
+    }
+    const uint32_t local = wg - en.first_wg;
+    const bool aligned = (en.flags & 0xFF) == kBatchAligned;
+    if (aligned && local < en.full_tiles) {
+        // every stream base on a 128-byte line: the aligned tile, tiles in launch order (as the single-buffer call runs it)
+        if constexpr (INVERSE)
+            inv_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+        else
+            fwd_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+        return;
+    }
+    Shifts sh;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 63u);
+        sh.gbase[i] = en.gbase[i];
+    }
+    sh.xcd_remap = 0;
+    sh.line_policy = INVERSE ? 1 : 3;
+    sh.skip_partial = 0;
+    sh.natural = 1;             // plan_batch_entry hands buffers with other shifts back to the host
+    sh.halo_vecs = (int)(en.flags >> 8) & 0xFF;
+    sh.full_tiles = en.full_tiles;
+    sh.range_blocks = en.blocks;
+    if constexpr (INVERSE) {
+        if (local >= en.full_tiles) {
+            inv_shift_edge_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, sh, en.full_tiles, lds);
+        } else {
+            // Neighbouring tiles share 128-byte lines: consecutive tiles stay on one XCD (xcd_contiguous_tile).  Workgroup
+            // residues mod 8 are XCDs whatever the buffer's first workgroup is: equal residues of `local` meet on one XCD.
+            const uint64_t tile = xcd_contiguous_tile(local, en.full_tiles);
+            inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
+        }
+    } else {
+        if (local == 0 || local >= en.full_tiles)
+            fwd_halo_edge_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, sh, local, lds);
+        else
+            fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+    }
+}
+
+uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntry& e)
+{
+    if (e.blocks == 0)
+        return 0;
+    const bool sa = fmt == kBc3 && s.split_alpha;
+    const Streams S = make_streams(fmt, sa, s.split_colour);
+    const void* soa = inverse ? (const void*)e.src : (const void*)e.dst;
+    // any AoS alignment: unaligned 16-byte vector accesses are exact and cheap on gfx950 (launch_transform)
+    const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
+    const uint64_t tiles = e.blocks / T, rest = e.blocks % T;
+    // The tile forms of launch_transform: aligned tiles when every stream base is on a 128-byte line; otherwise forward halo
+    // tiles (windows moved back to a 64-byte boundary) and inverse shifted tiles (slices displaced by the base modulo 16).
+    const uint64_t mask = inverse ? 15 : 63;
+    bool on_lines = true, stream_tails = false;
+    int d[6] = {0, 0, 0, 0, 0, 0}, halo_blocks = 0;
+    for (int i = 0; i < S.n; ++i) {
+        const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * e.blocks;
+        d[i] = (int)(base & mask);
+        on_lines = on_lines && (base & 127) == 0;
+        stream_tails = stream_tails || d[i] != 0;
+        halo_blocks = std::max(halo_blocks, (d[i] + S.width[i] - 1) / S.width[i]);
+    }
+    if (!shifts_are_natural(S, d))
+        return 0xFFFFFFFFu;   // a transformed-side pointer that is not even 8-byte aligned: the single-buffer call handles it
+    e.form = on_lines ? 1 : 0;
+    e.natural = 1;
+    e.reserved = 0;
+    e.reserved2[0] = e.reserved2[1] = 0;
+    const int per_vec = 16 / fmt_block(fmt);
+    e.halo_vecs = inverse ? 0 : (uint8_t)((halo_blocks + per_vec - 1) / per_vec);
+    for (int i = 0; i < 6; ++i) {
+        e.shift[i] = (uint8_t)d[i];
+        e.gbase[i] = i < S.n ? (uint64_t)S.off[i] * e.blocks - (uint64_t)d[i] : 0;
+    }
+    e.full_tiles = (uint32_t)tiles;
+    // the edge tile: the blocks behind the last whole tile and, forward, the last d_s bytes of every stream, which the whole
+    // tiles' moved-back windows leave out
+    const bool edge = rest != 0 || (!inverse && stream_tails);
+    const uint32_t wgs = (uint32_t)tiles + (edge ? 1u : 0u);
+    e.end_wg = e.first_wg + wgs;
+    return wgs;
+}
+
+namespace {
+
+using BatchFn = void (*)(const BatchEntry*, const uint32_t*, uint32_t, uint32_t, StridedBatch);
+
+template <int FMT, int VARIANT, bool SA, bool SC>
+BatchFn batch_fn(bool inverse) { return inverse ? batch_kernel<FMT, VARIANT, SA, SC, true> : batch_kernel<FMT, VARIANT, SA, SC, false>; }
+
+template <int FMT, int VARIANT>
+BatchFn batch_splits(bool sa, bool sc, bool inverse)
+{
+    if constexpr (FMT == kBc3) {
+        if (sa)
+            return sc ? batch_fn<FMT, VARIANT, true, true>(inverse) : batch_fn<FMT, VARIANT, true, false>(inverse);
+    }
+    return sc ? batch_fn<FMT, VARIANT, false, true>(inverse) : batch_fn<FMT, VARIANT, false, false>(inverse);
+}
+
+template <int FMT>
+BatchFn batch_variant(int variant, bool sa, bool sc, bool inverse)
+{
+    switch (variant) {
+    case kNone: return batch_splits<FMT, kNone>(sa, sc, inverse);
+    case kVar1: return batch_splits<FMT, kVar1>(sa, sc, inverse);
+    case kVar2: return batch_splits<FMT, kVar2>(sa, sc, inverse);
+    default: return batch_splits<FMT, kVar3>(sa, sc, inverse);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint32_t* d_coarse,
+                        uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
+                        const BatchEntry* strided_first, int64_t src_stride, int64_t dst_stride)
+{
+    if (n_entries == 0 || total_wgs == 0)
+        return hipSuccess;
+    if (s.variant < 0 || s.variant > 3 || total_wgs > 0xFFFFFFu)
+        return hipErrorInvalidValue;
+    if (uniform_wgs != 0 && (uint64_t)uniform_wgs * n_entries != total_wgs)
+        return hipErrorInvalidValue;
+    const uint32_t magic = uniform_wgs > 1 ? (uint32_t)((1ull << 32) / uniform_wgs) : 0;
+    if (uniform_wgs == 1)
+        uniform_wgs = 0;   // 2^32 does not fit the magic word; one workgroup per buffer takes the general lookup
+    static const bool no_array = std::getenv("DXTLT_BATCH_NO_ARRAY") != nullptr;   // A/B switch
+    if (strided_first != nullptr && uniform_wgs != 0 && !no_array && strided_first->form == 1) {
+        const hipError_t e = launch_tiled_array(fmt, inverse, s, strided_first->src, strided_first->dst, strided_first->blocks, n_entries,
+                                                src_stride, dst_stride, stream);
+        if (e != hipErrorNotSupported)
+            return e;
+    }
+    StridedBatch strided{};
+    if (strided_first != nullptr && uniform_wgs != 0) {
+        strided.first = *strided_first;
+        strided.src_stride = src_stride;
+        strided.dst_stride = dst_stride;
+        strided.on = 1;
+    }
+    const bool sa = fmt == kBc3 && s.split_alpha, sc = s.split_colour;
+    BatchFn k = nullptr;
+    switch (fmt) {
+    case kBc1: k = batch_variant<kBc1>(s.variant, false, sc, inverse); break;
+    case kBc2: k = batch_variant<kBc2>(s.variant, false, sc, inverse); break;
+    case kBc3: k = batch_variant<kBc3>(s.variant, sa, sc, inverse); break;
+    default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, uniform_wgs, magic, strided);
+    return hipGetLastError();
+}
+
+}  // namespace dxtlt

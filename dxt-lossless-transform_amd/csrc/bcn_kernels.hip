@@ -34,1367 +34,9 @@
 //     misalignment so the body still moves as aligned 16-byte vectors (0.72-0.79 of peak).
 //   * What no tile path can take (the < 1 tile tail, an AoS pointer that is itself misaligned) goes to an
 //     element-granular kernel: one lane per block, natural-width or byte accesses.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstddef>
-#include <type_traits>
-
-#include "bc1_normalize.h"
-#include "bcn_launch.h"
-#include "streaming_store.h"
-#include "ycocg_swar.h"
+#include "bcn_device.h"
 
 namespace dxtlt {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kThreads = 256;        // element-granular / fill kernels
-// Default tile workgroup size (tile = threads * 16 bytes) per format and direction, chosen by measurement on the
-// 8 GiB workloads with the final store policy (profiles/r01_q_tile_threads_sweep_sc1_stores.txt): fraction of peak, fwd / inv
-//   BC1  64: .82/.83   128: .85/.84   256: .84/.82   512: .81/.78
-//   BC2  64: .80/.81   128: .83/.82   256: .84/.82   512: .82/.79
-//   BC3  64: .71/.72   128: .80/.78   256: .84/.81   512: .82/.80
-// (with plain `nt` stores the optimum was smaller for the inverse: profiles/r01_g_tile_threads_sweep.txt)
-constexpr int default_tile_threads(int fmt, bool inverse)
-{
-    (void)inverse;
-    return fmt == kBc1 ? 128 : 256;
-}
-
-#ifndef DXTLT_NONTEMPORAL
-#define DXTLT_NONTEMPORAL 1
-#endif
-
-__device__ __forceinline__ u32x4 gload16(const void* p)
-{
-#if DXTLT_NONTEMPORAL
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-#else
-    return *reinterpret_cast<const u32x4*>(p);
-#endif
-}
-
-// Streaming 16-byte store: streaming_store.h (policy measurements and the wait states its inline asm needs)
-__device__ __forceinline__ void gstore16(void* p, u32x4 v)
-{
-#if DXTLT_NONTEMPORAL
-    store_streaming16(p, v);
-#else
-    *reinterpret_cast<u32x4*>(p) = v;
-#endif
-}
-
-// AoS-side store of the inverse kernels: the write-through streaming store when the block array is 16-byte aligned (a
-// tile's 4 KiB are whole lines); plain `nt` when it is not -- every tile then shares its first and last line with its
-// neighbours, and write-through on shared lines is what collapsed to 0.39-0.50 in round 1
-__device__ __forceinline__ void gstore16_aos(uint8_t* aos_base, void* p, u32x4 v)
-{
-    if ((reinterpret_cast<uintptr_t>(aos_base) & 15) == 0)   // uniform
-        gstore16(p, v);
-    else
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
-}
-
-__host__ __device__ constexpr int fmt_block(int fmt) { return fmt == kBc1 ? 8 : 16; }
-// one 16-byte vector per lane: a THREADS-wide workgroup owns THREADS*16 bytes of blocks
-__host__ __device__ constexpr int tile_blocks(int fmt, int threads) { return threads * 16 / fmt_block(fmt); }
-
-// Byte offset, inside the whole transformed buffer, of LDS-image byte `o` (a lane's 16-byte segment) for
-// the tile whose first block is `blk0` (global block index).  Stream boundaries inside the image are
-// multiples of 256 bytes, so a 16-byte segment never straddles two streams.
-template <int FMT, bool SA, bool SC, int T>
-__device__ __forceinline__ uint64_t soa_offset_of_image_byte(int o, uint64_t total_blocks, uint64_t blk0)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    uint64_t r = 0;
-#pragma unroll
-    for (int s = 0; s < S.n; ++s) {
-        const int lo = S.off[s] * T;
-        const int hi = lo + S.width[s] * T;
-        if (o >= lo && o < hi)
-            r = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 + (uint64_t)(o - lo);
-    }
-    return r;
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS image <-> block registers.  `u` is the index of the lane's 16-byte vector inside the tile.
-// BC1: the vector holds blocks 2u and 2u+1; BC2/BC3: block u.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T& lds_at(uint8_t* lds, int byte_off)
-{
-    return *reinterpret_cast<T*>(lds + byte_off);
-}
-
-// volatile halfword view in the LDS address space (a plain volatile pointer would become flat_* instructions)
-typedef volatile uint16_t __attribute__((address_space(3))) lds_halfword;
-__device__ __forceinline__ lds_halfword* lds_halfwords(uint8_t* lds, int byte_off)
-{
-    return (lds_halfword*)(lds + byte_off);
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int T>
-__device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
-{
-    if constexpr (FMT == kBc1) {
-        // q = { colours A, indices A, colours B, indices B }
-        const uint32_t ca = decorrelate2<VARIANT>(q.x);
-        const uint32_t cb = decorrelate2<VARIANT>(q.z);
-        if constexpr (SC) {
-            lds_at<uint32_t>(lds, 0 * T + 4 * u) = (ca & 0xFFFFu) | (cb << 16);          // c0 of A, B
-            lds_at<uint32_t>(lds, 2 * T + 4 * u) = (ca >> 16) | (cb & 0xFFFF0000u);      // c1 of A, B
-        } else {
-            lds_at<u32x2>(lds, 0 * T + 8 * u) = u32x2{ca, cb};
-        }
-        lds_at<u32x2>(lds, 4 * T + 8 * u) = u32x2{q.y, q.w};
-    } else if constexpr (FMT == kBc2) {
-        // q = { alpha lo, alpha hi, colours, indices }
-        const uint32_t c = decorrelate2<VARIANT>(q.z);
-        lds_at<u32x2>(lds, 0 * T + 8 * u) = u32x2{q.x, q.y};
-        if constexpr (SC) {
-            lds_at<uint16_t>(lds, 8 * T + 2 * u) = (uint16_t)c;
-            lds_at<uint16_t>(lds, 10 * T + 2 * u) = (uint16_t)(c >> 16);
-        } else {
-            lds_at<uint32_t>(lds, 8 * T + 4 * u) = c;
-        }
-        lds_at<uint32_t>(lds, 12 * T + 4 * u) = q.w;
-    } else {
-        // q = { a0 a1 i0 i1, i2 i3 i4 i5, colours, indices }
-        const uint32_t c = decorrelate2<VARIANT>(q.z);
-        if constexpr (SA) {
-            lds_at<uint8_t>(lds, 0 * T + u) = (uint8_t)q.x;
-            lds_at<uint8_t>(lds, 1 * T + u) = (uint8_t)(q.x >> 8);
-        } else {
-            lds_at<uint16_t>(lds, 0 * T + 2 * u) = (uint16_t)q.x;
-        }
-        // 6-byte alpha-index record, only 2-byte aligned: three halfword stores.  Volatile, or clang fuses the last
-        // two into a ds_write_b32 that is misaligned for every other lane -- such DS accesses run several times
-        // slower than aligned ones on gfx950 (profiles/r01_s).
-        lds_halfwords(lds, 2 * T + 6 * u)[0] = (uint16_t)(q.x >> 16);
-        lds_halfwords(lds, 2 * T + 6 * u)[1] = (uint16_t)q.y;
-        lds_halfwords(lds, 2 * T + 6 * u)[2] = (uint16_t)(q.y >> 16);
-        if constexpr (SC) {
-            lds_at<uint16_t>(lds, 8 * T + 2 * u) = (uint16_t)c;
-            lds_at<uint16_t>(lds, 10 * T + 2 * u) = (uint16_t)(c >> 16);
-        } else {
-            lds_at<uint32_t>(lds, 8 * T + 4 * u) = c;
-        }
-        lds_at<uint32_t>(lds, 12 * T + 4 * u) = q.w;
-    }
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int T>
-__device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
-{
-    u32x4 q;
-    if constexpr (FMT == kBc1) {
-        uint32_t ca, cb;
-        if constexpr (SC) {
-            const uint32_t c0 = lds_at<uint32_t>(lds, 0 * T + 4 * u);
-            const uint32_t c1 = lds_at<uint32_t>(lds, 2 * T + 4 * u);
-            ca = (c0 & 0xFFFFu) | (c1 << 16);
-            cb = (c0 >> 16) | (c1 & 0xFFFF0000u);
-        } else {
-            const u32x2 p = lds_at<u32x2>(lds, 0 * T + 8 * u);
-            ca = p.x;
-            cb = p.y;
-        }
-        const u32x2 idx = lds_at<u32x2>(lds, 4 * T + 8 * u);
-        q.x = recorrelate2<VARIANT>(ca);
-        q.y = idx.x;
-        q.z = recorrelate2<VARIANT>(cb);
-        q.w = idx.y;
-    } else if constexpr (FMT == kBc2) {
-        const u32x2 a = lds_at<u32x2>(lds, 0 * T + 8 * u);
-        uint32_t c;
-        if constexpr (SC)
-            c = (uint32_t)lds_at<uint16_t>(lds, 8 * T + 2 * u) | ((uint32_t)lds_at<uint16_t>(lds, 10 * T + 2 * u) << 16);
-        else
-            c = lds_at<uint32_t>(lds, 8 * T + 4 * u);
-        q.x = a.x;
-        q.y = a.y;
-        q.z = recorrelate2<VARIANT>(c);
-        q.w = lds_at<uint32_t>(lds, 12 * T + 4 * u);
-    } else {
-        uint32_t a01;
-        if constexpr (SA)
-            a01 = (uint32_t)lds_at<uint8_t>(lds, 0 * T + u) | ((uint32_t)lds_at<uint8_t>(lds, 1 * T + u) << 8);
-        else
-            a01 = lds_at<uint16_t>(lds, 0 * T + 2 * u);
-        const uint32_t i01 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 0);
-        const uint32_t i23 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 2);
-        const uint32_t i45 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 4);
-        uint32_t c;
-        if constexpr (SC)
-            c = (uint32_t)lds_at<uint16_t>(lds, 8 * T + 2 * u) | ((uint32_t)lds_at<uint16_t>(lds, 10 * T + 2 * u) << 16);
-        else
-            c = lds_at<uint32_t>(lds, 8 * T + 4 * u);
-        q.x = a01 | (i01 << 16);
-        q.y = i23 | (i45 << 16);
-        q.z = recorrelate2<VARIANT>(c);
-        q.w = lds_at<uint32_t>(lds, 12 * T + 4 * u);
-    }
-    return q;
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group; observed, used for speed
-// only).  This bijective remap hands each group one contiguous eighth of the tiles, so two neighbouring tiles --
-// which share a 128-byte line whenever a stream base is misaligned -- meet in the same XCD's L2 and leave (arrive)
-// as one full line instead of two partial ones.
-__device__ __forceinline__ uint64_t xcd_contiguous_tile(uint32_t orig, uint32_t nwg)
-{
-    // every product below is smaller than nwg: 32-bit arithmetic is exact (and half the scalar instructions)
-    const uint32_t q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + (orig >> 3);
-}
-
-// Tried and dropped (profiles/r01_z/shift_probe_rotation_and_chunks.txt): handing each XCD chunks of 4 / 16 / 64
-// consecutive tiles in turn, so that the chip keeps one moving window -- slower than both this order and the identity
-// on every alignment class (BC3 forward, 128-byte aligned bases: 0.75 against 0.84 identity / 0.78 contiguous).
-// Neither did staggering the eight XCDs' starting points inside their eighths by 7 / 61 / 509 tiles (the idea: eighths of
-// a power-of-two buffer start on the same memory channel): no change (profiles/r01_z/shift_probe_xcd_stagger.txt).
-
-// ------------------------------------------------------------------------------------------------
-// Tiled kernels: one tile per workgroup.  `aos` points at the range's first block, `soa` at byte 0 of the
-// whole transformed buffer.  Preconditions (checked on the host): both pointers 16-byte aligned; every
-// stream base off*total_blocks + width*first_block is a multiple of 16; gridDim.x == number of FULL tiles
-// at the start of the range.
-// ------------------------------------------------------------------------------------------------
-// BC1 block normalisation fused into the forward kernels (experimental module of the reference,
-// transform_bc1_with_normalize_blocks, experimental/normalize_blocks/transform.rs:65-166): the two blocks of the
-// lane's vector are normalised in registers right after the load, so the fused path moves the same 2*len bytes.
-template <int FMT, int NORM>
-__device__ __forceinline__ u32x4 normalize_vector(u32x4 q)
-{
-    if constexpr (FMT == kBc1 && NORM != kNormNone) {
-        uint32_t ca = q.x, xa = q.y, cb = q.z, xb = q.w;
-        normalize_bc1_block<NORM>(ca, xa);
-        normalize_bc1_block<NORM>(cb, xb);
-        q = u32x4{ca, xa, cb, xb};
-    }
-    return q;
-}
-
-// bit 1 of the tiled kernels' `xcd_remap` argument: the launch is two-dimensional, blockIdx.y numbers the buffers of a regular
-// array whose sources / destinations lie `*_stride` bytes apart (first pointer argument, second pointer argument)
-constexpr int kTiledArray = 2;
-
-// One aligned tile (the body of fwd_tiled / inv_tiled; the batch kernel runs it for buffers whose stream bases are aligned).
-// `lds`: THREADS * 16 bytes.
-template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
-__device__ __forceinline__ void fwd_aligned_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
-                                                 uint64_t total_blocks, uint64_t first_block, uint64_t tile, uint8_t* lds)
-{
-    constexpr int T = tile_blocks(FMT, THREADS);
-    const int t = threadIdx.x;
-    const u32x4 q = normalize_vector<FMT, NORM>(gload16(aos + tile * (THREADS * 16) + t * 16));
-    scatter_to_image<FMT, VARIANT, SA, SC, T>(lds, t, q);
-    __syncthreads();
-    const u32x4 v = lds_at<u32x4>(lds, t * 16);
-    const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
-    gstore16(soa + o, v);
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
-__device__ __forceinline__ void inv_aligned_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
-                                                 uint64_t total_blocks, uint64_t first_block, uint64_t tile, uint8_t* lds)
-{
-    constexpr int T = tile_blocks(FMT, THREADS);
-    const int t = threadIdx.x;
-    const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
-    lds_at<u32x4>(lds, t * 16) = gload16(soa + o);
-    __syncthreads();
-    const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC, T>(lds, t);
-    gstore16_aos(aos, aos + tile * (THREADS * 16) + t * 16, q);
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int THREADS, int NORM = kNormNone>
-__global__ void __launch_bounds__(THREADS)
-fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-          int xcd_remap, int64_t aos_stride, int64_t soa_stride)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
-    if (xcd_remap & kTiledArray) {   // a regular array of buffers: blockIdx.y is the buffer (launch_batch)
-        aos += (int64_t)blockIdx.y * aos_stride;
-        soa += (int64_t)blockIdx.y * soa_stride;
-    }
-    const uint64_t tile = (xcd_remap & 1) ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    fwd_aligned_tile<FMT, VARIANT, SA, SC, THREADS, NORM>(aos, soa, total_blocks, first_block, tile, lds);
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
-          int xcd_remap, int64_t soa_stride, int64_t aos_stride)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
-    if (xcd_remap & kTiledArray) {
-        soa += (int64_t)blockIdx.y * soa_stride;
-        aos += (int64_t)blockIdx.y * aos_stride;
-    }
-    const uint64_t tile = (xcd_remap & 1) ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    inv_aligned_tile<FMT, VARIANT, SA, SC, THREADS>(soa, aos, total_blocks, first_block, tile, lds);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Shifted tiles: the tiled structure for transformed buffers whose stream bases are NOT 16-byte aligned
-// (odd block counts -- e.g. a DDS payload with a full mip chain -- or ranges that start at an odd block).
-// Stream s lands at global address G_s = soa + off_s*N + w_s*first_block with misalignment d_s = G_s & 15.
-// Its slice of the LDS image is stored d_s bytes further in (each stream gets 16 bytes of padding), so an
-// LDS byte and the global byte it maps to have the same address modulo 16: the body of every slice still
-// leaves (arrives) as aligned 16-byte vectors, and only the first and last 16-byte segment of a slice are
-// partial; those are moved with 1/2/4/8-byte accesses that touch exactly the slice's own bytes, so the
-// neighbouring tile (which owns the rest of that 16-byte segment) never races with it.
-// The AoS pointer is 16-byte aligned in the common case; any other address works (unaligned vector accesses), a little
-// slower.  256-thread tiles.
-// ------------------------------------------------------------------------------------------------
-struct Shifts {
-    int d[6];
-    int xcd_remap;    // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
-    int line_policy;  // 1: forward stores of lines written whole by one wave instruction are write-through (sc1 nt)
-    int skip_partial; // timing experiment only (wrong output): 1 = leave out the partial head / tail segments
-    int natural;      // 1: every d[s] is a multiple of stream s's element width (always so when the SoA pointer is 8-byte aligned)
-    int halo_vecs;    // halo tiles: 16-byte vectors in front of a tile whose blocks have bytes in the tile's windows
-    // offset from the SoA pointer of the aligned segment that holds the first byte of stream s of the RANGE:
-    // off_s * total_blocks + w_s * first_block - d[s] (may be "negative": wraps).  Filled by the host (launch_transform)
-    // or by the batch kernel from its table entry: the tiles then add one multiple of a constant per stream instead of
-    // redoing two 64-bit products and a difference per stream and workgroup on the scalar unit (PMC: 107 scalar
-    // instructions per wave in the inverse shifted tile, 95 in the halo tile, against 36-40 in the aligned tiles).
-    uint64_t gbase[6];
-};
-
-template <typename STREAMS>
-__host__ __device__ inline void fill_gbase(Shifts& sh, const STREAMS& S, uint64_t total_blocks, uint64_t first_block)
-{
-    for (int i = 0; i < 6; ++i)
-        sh.gbase[i] = i < S.n ? (uint64_t)S.off[i] * total_blocks + (uint64_t)S.width[i] * first_block - (uint64_t)sh.d[i] : 0;
-}
-
-// element width of a stream: its bytes per block, except the 6-byte alpha index records, which move as three halfwords
-__host__ __device__ constexpr int stream_element_width(int bytes_per_block) { return bytes_per_block == 6 ? 2 : bytes_per_block; }
-
-template <typename STREAMS>
-__host__ __device__ inline int shifts_are_natural(const STREAMS& S, const int (&d)[6])
-{
-    int ok = 1;
-    for (int i = 0; i < 6; ++i)
-        if (i < S.n && (d[i] & (stream_element_width(S.width[i]) - 1)) != 0)
-            ok = 0;
-    return ok;
-}
-
-
-// LDS accesses of the shifted tiles.  A field of W bytes sits at an address that is only known to be congruent to
-// `addr & (W - 1)` (the stream's shift, uniform over the wave).  DS instructions at addresses that are not multiples
-// of their width execute on gfx950, but several times slower than aligned ones (profiles/r01_s), and clang -- which
-// assumes they are free -- fuses neighbouring narrow accesses into exactly such instructions.  So the field is moved
-// as the shortest sequence of naturally aligned 1/2/4/8-byte pieces for its misalignment, through volatile pointers
-// in the LDS address space (volatile stops the fusion; a plain volatile pointer would become flat_* instructions).
-template <typename T>
-using lds_volatile = volatile T __attribute__((address_space(3)));
-
-template <int SIZE>
-__device__ __forceinline__ void lds_put_piece(uint8_t* lds, int addr, uint64_t v)
-{
-    if constexpr (SIZE == 1) *(lds_volatile<uint8_t>*)(lds + addr) = (uint8_t)v;
-    if constexpr (SIZE == 2) *(lds_volatile<uint16_t>*)(lds + addr) = (uint16_t)v;
-    if constexpr (SIZE == 4) *(lds_volatile<uint32_t>*)(lds + addr) = (uint32_t)v;
-    if constexpr (SIZE == 8) *(lds_volatile<uint64_t>*)(lds + addr) = v;
-}
-
-template <int SIZE>
-__device__ __forceinline__ uint64_t lds_get_piece(uint8_t* lds, int addr)
-{
-    if constexpr (SIZE == 1) return *(lds_volatile<uint8_t>*)(lds + addr);
-    if constexpr (SIZE == 2) return *(lds_volatile<uint16_t>*)(lds + addr);
-    if constexpr (SIZE == 4) return *(lds_volatile<uint32_t>*)(lds + addr);
-    if constexpr (SIZE == 8) return *(lds_volatile<uint64_t>*)(lds + addr);
-    return 0;
-}
-
-// size of the piece that starts P bytes into a W-byte field whose address is K modulo W
-constexpr int lds_piece_size(int W, int K, int P)
-{
-    const int a = K + P;
-    int align = a == 0 ? W : (a & -a);
-    if (align > W) align = W;
-    int size = 1;
-    while (size * 2 <= align && size * 2 <= W - P) size *= 2;
-    return size;
-}
-
-template <int W, int K, int P = 0>
-__device__ __forceinline__ void lds_put_seq(uint8_t* lds, int addr, uint64_t v)
-{
-    if constexpr (P < W) {
-        constexpr int size = lds_piece_size(W, K, P);
-        lds_put_piece<size>(lds, addr + P, v >> (8 * P));
-        lds_put_seq<W, K, P + size>(lds, addr, v);
-    }
-}
-
-template <int W, int K, int P = 0>
-__device__ __forceinline__ uint64_t lds_get_seq(uint8_t* lds, int addr)
-{
-    if constexpr (P < W) {
-        constexpr int size = lds_piece_size(W, K, P);
-        return (lds_get_piece<size>(lds, addr + P) << (8 * P)) | lds_get_seq<W, K, P + size>(lds, addr);
-    }
-    return 0;
-}
-
-// NAT: the caller guarantees addr % W == 0 (every stream shift is a multiple of its field width: Shifts::natural)
-template <int W, bool NAT = false>
-__device__ __forceinline__ void lds_put(uint8_t* lds, int addr, uint64_t v)
-{
-    if constexpr (W == 1 || NAT) {
-        lds_put_piece<W>(lds, addr, v);
-    } else {
-        switch (addr & (W - 1)) {
-        case 0: lds_put_seq<W, 0>(lds, addr, v); break;
-        case 1: lds_put_seq<W, 1>(lds, addr, v); break;
-        case 2: if constexpr (W > 2) lds_put_seq<W, 2>(lds, addr, v); break;
-        case 3: if constexpr (W > 2) lds_put_seq<W, 3>(lds, addr, v); break;
-        case 4: if constexpr (W > 4) lds_put_seq<W, 4>(lds, addr, v); break;
-        case 5: if constexpr (W > 4) lds_put_seq<W, 5>(lds, addr, v); break;
-        case 6: if constexpr (W > 4) lds_put_seq<W, 6>(lds, addr, v); break;
-        default: if constexpr (W > 4) lds_put_seq<W, 7>(lds, addr, v); break;
-        }
-    }
-}
-
-template <int W, bool NAT = false>
-__device__ __forceinline__ uint64_t lds_get(uint8_t* lds, int addr)
-{
-    if constexpr (W == 1 || NAT) {
-        return lds_get_piece<W>(lds, addr);
-    } else {
-        switch (addr & (W - 1)) {
-        case 0: return lds_get_seq<W, 0>(lds, addr);
-        case 1: return lds_get_seq<W, 1>(lds, addr);
-        case 2: if constexpr (W > 2) return lds_get_seq<W, 2>(lds, addr); break;
-        case 3: if constexpr (W > 2) return lds_get_seq<W, 3>(lds, addr); break;
-        case 4: if constexpr (W > 4) return lds_get_seq<W, 4>(lds, addr); break;
-        case 5: if constexpr (W > 4) return lds_get_seq<W, 5>(lds, addr); break;
-        case 6: if constexpr (W > 4) return lds_get_seq<W, 6>(lds, addr); break;
-        default: if constexpr (W > 4) return lds_get_seq<W, 7>(lds, addr); break;
-        }
-        return 0;
-    }
-}
-
-// stream indices of the fields (make_streams order)
-template <int FMT, bool SA, bool SC>
-struct FieldStreams {
-    static constexpr int alpha = 0;                                       // BC2 alpha, BC3 a0 or (a0,a1)
-    static constexpr int a1 = 1;                                          // BC3 split alphas
-    static constexpr int aidx = SA ? 2 : 1;                               // BC3
-    static constexpr int col = FMT == kBc1 ? 0 : FMT == kBc2 ? 1 : (SA ? 3 : 2);  // c0 or (c0,c1)
-    static constexpr int c1 = col + 1;                                    // split colours
-    static constexpr int idx = col + (SC ? 2 : 1);
-};
-
-// NAT (Shifts::natural): every stream's shift is a multiple of its element width, so each element goes out as one aligned
-// DS instruction and the per-access alignment switch disappears.  BC1 then writes its two blocks' fields separately
-// (the pair is only element-aligned); the other formats' accesses are element-wide already.
-template <int FMT, int VARIANT, bool SA, bool SC, bool NAT>
-__device__ __forceinline__ void scatter_shifted(uint8_t* lds, int u, u32x4 q, const int (&base)[6])
-{
-    using F = FieldStreams<FMT, SA, SC>;
-    if constexpr (FMT == kBc1) {
-        const uint32_t ca = decorrelate2<VARIANT>(q.x);
-        const uint32_t cb = decorrelate2<VARIANT>(q.z);
-        if constexpr (NAT) {
-            if constexpr (SC) {
-                lds_put<2, true>(lds, base[F::col] + 4 * u, ca & 0xFFFFu);
-                lds_put<2, true>(lds, base[F::col] + 4 * u + 2, cb & 0xFFFFu);
-                lds_put<2, true>(lds, base[F::c1] + 4 * u, ca >> 16);
-                lds_put<2, true>(lds, base[F::c1] + 4 * u + 2, cb >> 16);
-            } else {
-                lds_put<4, true>(lds, base[F::col] + 8 * u, ca);
-                lds_put<4, true>(lds, base[F::col] + 8 * u + 4, cb);
-            }
-            lds_put<4, true>(lds, base[F::idx] + 8 * u, q.y);
-            lds_put<4, true>(lds, base[F::idx] + 8 * u + 4, q.w);
-        } else {
-            if constexpr (SC) {
-                lds_put<4>(lds, base[F::col] + 4 * u, (ca & 0xFFFFu) | (cb << 16));
-                lds_put<4>(lds, base[F::c1] + 4 * u, (ca >> 16) | (cb & 0xFFFF0000u));
-            } else {
-                lds_put<8>(lds, base[F::col] + 8 * u, (uint64_t)ca | ((uint64_t)cb << 32));
-            }
-            lds_put<8>(lds, base[F::idx] + 8 * u, (uint64_t)q.y | ((uint64_t)q.w << 32));
-        }
-    } else {
-        const uint32_t c = decorrelate2<VARIANT>(q.z);
-        if constexpr (FMT == kBc2) {
-            lds_put<8, NAT>(lds, base[F::alpha] + 8 * u, (uint64_t)q.x | ((uint64_t)q.y << 32));
-        } else {
-            if constexpr (SA) {
-                lds_put<1>(lds, base[F::alpha] + u, q.x & 0xFF);
-                lds_put<1>(lds, base[F::a1] + u, (q.x >> 8) & 0xFF);
-            } else {
-                lds_put<2, NAT>(lds, base[F::alpha] + 2 * u, q.x & 0xFFFF);
-            }
-            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 0, q.x >> 16);
-            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 2, q.y & 0xFFFF);
-            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 4, q.y >> 16);
-        }
-        if constexpr (SC) {
-            lds_put<2, NAT>(lds, base[F::col] + 2 * u, c & 0xFFFF);
-            lds_put<2, NAT>(lds, base[F::c1] + 2 * u, c >> 16);
-        } else {
-            lds_put<4, NAT>(lds, base[F::col] + 4 * u, c);
-        }
-        lds_put<4, NAT>(lds, base[F::idx] + 4 * u, q.w);
-    }
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, bool NAT>
-__device__ __forceinline__ u32x4 gather_shifted(uint8_t* lds, int u, const int (&base)[6])
-{
-    using F = FieldStreams<FMT, SA, SC>;
-    u32x4 q;
-    if constexpr (FMT == kBc1) {
-        uint32_t ca, cb;
-        uint64_t idx;
-        if constexpr (NAT) {
-            if constexpr (SC) {
-                ca = (uint32_t)lds_get<2, true>(lds, base[F::col] + 4 * u) | ((uint32_t)lds_get<2, true>(lds, base[F::c1] + 4 * u) << 16);
-                cb = (uint32_t)lds_get<2, true>(lds, base[F::col] + 4 * u + 2) |
-                     ((uint32_t)lds_get<2, true>(lds, base[F::c1] + 4 * u + 2) << 16);
-            } else {
-                ca = (uint32_t)lds_get<4, true>(lds, base[F::col] + 8 * u);
-                cb = (uint32_t)lds_get<4, true>(lds, base[F::col] + 8 * u + 4);
-            }
-            idx = lds_get<4, true>(lds, base[F::idx] + 8 * u) | (lds_get<4, true>(lds, base[F::idx] + 8 * u + 4) << 32);
-        } else {
-            if constexpr (SC) {
-                const uint32_t c0 = (uint32_t)lds_get<4>(lds, base[F::col] + 4 * u);
-                const uint32_t c1 = (uint32_t)lds_get<4>(lds, base[F::c1] + 4 * u);
-                ca = (c0 & 0xFFFFu) | (c1 << 16);
-                cb = (c0 >> 16) | (c1 & 0xFFFF0000u);
-            } else {
-                const uint64_t p = lds_get<8>(lds, base[F::col] + 8 * u);
-                ca = (uint32_t)p;
-                cb = (uint32_t)(p >> 32);
-            }
-            idx = lds_get<8>(lds, base[F::idx] + 8 * u);
-        }
-        q.x = recorrelate2<VARIANT>(ca);
-        q.y = (uint32_t)idx;
-        q.z = recorrelate2<VARIANT>(cb);
-        q.w = (uint32_t)(idx >> 32);
-    } else {
-        if constexpr (FMT == kBc2) {
-            const uint64_t a = lds_get<8, NAT>(lds, base[F::alpha] + 8 * u);
-            q.x = (uint32_t)a;
-            q.y = (uint32_t)(a >> 32);
-        } else {
-            uint32_t a01;
-            if constexpr (SA)
-                a01 = (uint32_t)lds_get<1>(lds, base[F::alpha] + u) | ((uint32_t)lds_get<1>(lds, base[F::a1] + u) << 8);
-            else
-                a01 = (uint32_t)lds_get<2, NAT>(lds, base[F::alpha] + 2 * u);
-            const uint32_t i01 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 0);
-            const uint32_t i23 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 2);
-            const uint32_t i45 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 4);
-            q.x = a01 | (i01 << 16);
-            q.y = i23 | (i45 << 16);
-        }
-        uint32_t c;
-        if constexpr (SC)
-            c = (uint32_t)lds_get<2, NAT>(lds, base[F::col] + 2 * u) | ((uint32_t)lds_get<2, NAT>(lds, base[F::c1] + 2 * u) << 16);
-        else
-            c = (uint32_t)lds_get<4, NAT>(lds, base[F::col] + 4 * u);
-        q.z = recorrelate2<VARIANT>(c);
-        q.w = (uint32_t)lds_get<4, NAT>(lds, base[F::idx] + 4 * u);
-    }
-    return q;
-}
-
-// Copy bytes [lo, hi) of one 16-byte segment between two pointers that are both 16-byte aligned at byte 0 of
-// the segment; either lo == 0 (a slice's tail) or hi == 16 (a slice's head).  Typed 1/2/4/8-byte moves.
-template <bool TO_GLOBAL>
-__device__ __forceinline__ void copy_partial_segment(uint8_t* dst, const uint8_t* src, int lo, int hi)
-{
-    auto mv = [&](int p, int w) {
-        if (w == 1) dst[p] = src[p];
-        if (w == 2) *reinterpret_cast<uint16_t*>(dst + p) = *reinterpret_cast<const uint16_t*>(src + p);
-        if (w == 4) *reinterpret_cast<uint32_t*>(dst + p) = *reinterpret_cast<const uint32_t*>(src + p);
-        if (w == 8) *reinterpret_cast<u32x2*>(dst + p) = *reinterpret_cast<const u32x2*>(src + p);
-    };
-    if (hi == 16) {  // head: [lo, 16)
-        int p = lo;
-        if (p & 1) { mv(p, 1); p += 1; }
-        if (p & 2) { mv(p, 2); p += 2; }
-        if (p & 4) { mv(p, 4); p += 4; }
-        if (p & 8) { mv(p, 8); }
-    } else {  // tail: [0, hi)
-        int p = 0;
-        if (hi & 8) { mv(p, 8); p += 8; }
-        if (hi & 4) { mv(p, 4); p += 4; }
-        if (hi & 2) { mv(p, 2); p += 2; }
-        if (hi & 1) { mv(p, 1); }
-    }
-}
-
-// 64-bit value that is the same in every lane, kept in SGPRs (the compiler otherwise sinks the per-stream base
-// computations into the per-lane branches and does them with quarter-rate v_mad_u64_u32)
-__device__ __forceinline__ uint64_t uniform64(uint64_t v)
-{
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
-
-// global offset (from the SoA pointer) of segment 0 of every stream's slice of tile `tile` of the range (T blocks per
-// tile): aligned, d[s] bytes before the slice
-template <int FMT, bool SA, bool SC, int T>
-__device__ __forceinline__ void slice_bases(uint64_t tile, const Shifts& sh, uint64_t (&gb)[6])
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-#pragma unroll
-    for (int s = 0; s < 6; ++s)
-        gb[s] = s < S.n ? uniform64(sh.gbase[s] + tile * (uint64_t)(S.width[s] * T)) : 0;
-}
-
-// For image byte o (a multiple of 16): stream index, segment number within the slice, LDS address of the segment, global
-// offset of the segment (aligned), the stream's shift and the number of whole segments of the slice.
-template <int FMT, bool SA, bool SC, int T>
-__device__ __forceinline__ void shifted_segment(int o, const uint64_t (&gb)[6], const Shifts& sh, int& s_out, int& k_out,
-                                                int& lds_addr, uint64_t& g_off, int& shift, int& nseg)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    s_out = 0; k_out = 0; lds_addr = 0; g_off = 0; shift = 0; nseg = 0;
-#pragma unroll
-    for (int s = 0; s < S.n; ++s) {
-        const int lo = S.off[s] * T;
-        const int hi = lo + S.width[s] * T;
-        if (o >= lo && o < hi) {
-            s_out = s;
-            k_out = (o - lo) >> 4;
-            lds_addr = lo + 16 * s + (o - lo);
-            g_off = gb[s] + (uint64_t)(o - lo);
-            shift = sh.d[s];
-            nseg = S.width[s] * T / 16;
-        }
-    }
-}
-
-// LDS bytes of a shifted tile of R x 256 lanes' worth of blocks: the image plus 16 bytes of padding per stream
-constexpr int shift_lds_bytes(int r) { return r * 256 * 16 + 16 * 6; }
-constexpr int kShiftLdsBytes = shift_lds_bytes(1);
-// R = sub-tiles of 256 lanes per workgroup.  Only R = 1 is instantiated: with misaligned stream bases every slice shares
-// its first and last 128-byte line with the neighbouring tiles (BC3, 256 blocks per tile: 12 of 38 lines), and R = 4
-// cuts that to 12 of 134 -- but it measured slower, not faster (BC3 odd count 0.710 / 0.773 forward / inverse against
-// 0.702 / 0.797, BC1 0.755 / 0.777 against 0.775 / 0.818; profiles/r01_z/shift_probe_with_big_tiles.txt).  L2 merges the
-// shared lines either way: HBM traffic is 1.003 x the algorithmic bytes on odd counts (PMC).
-
-// one shifted tile, forward; `lds` is the workgroup's shift_lds_bytes(R) scratch (R = 1: shared with the batch kernel)
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone, int R = 1>
-__device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
-                                               uint64_t /*total_blocks: in sh.gbase*/, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
-                                               uint8_t* lds)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256) * R;
-    const int t = threadIdx.x;
-    int base[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s)
-        base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
-
-    u32x4 q[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-        q[j] = gload16(aos + tile * (4096 * R) + (t + 256 * j) * 16);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const u32x4 v = normalize_vector<FMT, NORM>(q[j]);
-        if (sh.natural)
-            scatter_shifted<FMT, VARIANT, SA, SC, true>(lds, t + 256 * j, v, base);
-        else
-            scatter_shifted<FMT, VARIANT, SA, SC, false>(lds, t + 256 * j, v, base);
-    }
-    __syncthreads();
-
-    uint64_t gb[6];
-    slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        int s, k, la, shift, nseg;
-        uint64_t g;
-        shifted_segment<FMT, SA, SC, T>((t + 256 * j) * 16, gb, sh, s, k, la, g, shift, nseg);
-        if (k == 0 && shift > 0) {
-            if (!sh.skip_partial)
-                copy_partial_segment<true>(soa + g, lds + la, shift, 16);   // (one LDS read + stores from registers: 0.68 against 0.705)
-        } else {
-            // A 128-byte line that this wave instruction writes completely may use the write-through streaming store of
-            // the aligned kernels.  A line that is completed by another wave or by the neighbouring tile must stay in
-            // L2 until then: plain `nt` (write-through on those: 0.39-0.50 of peak instead of 0.72-0.76).
-            // In segment numbers of the slice: p = this segment's place in its line, kf = the line's first segment.
-            // The line lies inside the slice when kf is not the partial head and kf + 8 segments are whole ones; its
-            // eight lanes sit in one wave when the first of them is at most lane 56 of the wave.  (Rotating the lanes
-            // of a stream so that groups of eight coincide with lines, which makes nearly every line whole, changed
-            // nothing: 0.711 against 0.714, profiles/r01_z/shift_probe_rotation_and_chunks.txt.)
-            const int p = (int)(((uint32_t)(reinterpret_cast<uintptr_t>(soa) + g) >> 4) & 7u);   // low address bits are enough
-            const int kf = k - p;
-            const bool whole_line = kf >= (shift > 0 ? 1 : 0) && kf + 8 <= nseg && ((t - p) & 63) <= 56;
-            if (sh.line_policy && whole_line)
-                gstore16(soa + g, lds_at<u32x4>(lds, la));
-            else if (sh.line_policy == 2)
-                *reinterpret_cast<u32x4*>(soa + g) = lds_at<u32x4>(lds, la);
-            else
-                __builtin_nontemporal_store(lds_at<u32x4>(lds, la), reinterpret_cast<u32x4*>(soa + g));
-        }
-    }
-    if (t < S.n && !sh.skip_partial) {  // the extra, partial last segment of stream t
-#pragma unroll
-        for (int ss = 0; ss < S.n; ++ss) {
-            if (ss == t && sh.d[ss] > 0) {
-                const int bytes = S.width[ss] * T;
-                copy_partial_segment<true>(soa + gb[ss] + bytes, lds + S.off[ss] * T + 16 * ss + bytes, 0, sh.d[ss]);
-            }
-        }
-    }
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone, int R = 1>
-__global__ void __launch_bounds__(256)
-fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-                Shifts sh)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[shift_lds_bytes(R)];
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    fwd_shift_tile<FMT, VARIANT, SA, SC, NORM, R>(aos, soa, total_blocks, first_block, sh, tile, lds);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Forward shifted tiles, second form ("halo tiles").  What the counters said about the form above on odd block counts
-// (profiles/r02_a_shift_pmc.txt, BC3 default settings, 2^26 + 1 blocks against 2^26): HBM requests identical and all of
-// them full 64-byte ones (TCC_EA0_WRREQ == TCC_EA0_WRREQ_64B, no read-modify-write), memory-side write stalls 50 x
-// LOWER -- but 5.5 x the vector-memory store instructions per wave (the typed partial segments), 2 x the VALU and 3.6 x
-// the SALU instructions, 2.65 x the issue-stall cycles: the kernel is bound by its own instruction stream, not by memory.
-// So the partial segments go: a tile's window on stream s is moved back by the stream's misalignment d_s, to the
-// aligned segments [G_s - d_s, G_s - d_s + w_s * T).  Its first d_s bytes are records of the up to 16 blocks BEFORE the
-// tile: the workgroup loads that halo too (16 blocks, one more load instruction for a quarter of wave 0; the lines were
-// just fetched by the previous tile, which the XCD-contiguous tile order keeps on the same L2), every stream region of
-// the LDS image is 16 blocks longer at the front, and what leaves the workgroup is exactly what leaves an aligned tile:
-// one full, aligned 16-byte store per lane.  Bytes no window covers -- the first 16 - d_s bytes of every stream of the
-// RANGE (tile 0 has no halo: the blocks before it may not exist or belong to another call) and everything behind the
-// last tile's windows -- are records of the first 16 and of the last 16 + (num_blocks mod T) blocks of the range, which
-// the element kernel writes (launch_transform); where the two overlap they write the same values.
-// ------------------------------------------------------------------------------------------------
-// Windows are moved back to a 64-BYTE boundary, not just a 16-byte one (d_s = stream base mod 64): two tiles that meet
-// inside a 128-byte line then each write whole 64-byte sectors of it, which is what the memory side writes without a
-// read-modify-write -- with 16-byte boundaries such lines had to meet in one L2 (XCD-contiguous tile order, itself worth
-// -0.04) or cost 0.08 (profiles/r02_b_shift_probe.txt).  The halo grows to at most 63 bytes per stream = at most 63
-// blocks for a 1-byte stream; only as many vectors as some stream needs are fetched (Shifts::halo_vecs).
-constexpr int kHaloBlocks = 64;
-constexpr int kHaloPad = 64;   // bytes between the stream regions of the LDS image: room for d_s
-template <int FMT>
-constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, 256) + kHaloBlocks) + kHaloPad * 6; }
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// Copy-out of wave W of a halo tile: lane t moves image byte 16 t of the tile's windows.  A wave's 1 KiB of the image
-// meets at most three streams (BC3 with split alphas, wave 0) and usually one, and which ones is known at compile time:
-// the per-lane select over the streams -- a third of the first version's vector instructions -- shrinks to the streams
-// the wave can meet.
-template <int FMT, bool SA, bool SC, int W>
-__device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, const uint8_t* lds, int t, bool first_tile,
-                                                   const uint64_t (&gb)[6], const Shifts& sh)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
-    constexpr int H = kHaloBlocks;
-    constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
-    const int o = t * 16;
-    int la = 0;
-    uint64_t g = 0;
-    bool skip = false;
-    static_for<0, S.n>([&](auto si) {
-        constexpr int s = decltype(si)::value;
-        constexpr int lo = S.off[s] * T;
-        constexpr int hi = lo + S.width[s] * T;
-        if constexpr (lo < wave_hi && hi > wave_lo) {
-            constexpr bool only = lo <= wave_lo && hi >= wave_hi;   // the whole wave sits in this stream
-            if (only || (o >= lo && o < hi)) {
-                la = S.off[s] * (T + H) + kHaloPad * s + S.width[s] * H + (o - lo);
-                g = gb[s] + (uint64_t)(o - lo);
-                // no halo in front of the range: segments that start before the stream's first byte are left to the
-                // element kernel (it writes the records of the range's first 64 blocks)
-                skip = first_tile && (o - lo) < sh.d[s];
-            }
-        }
-    });
-    if (skip)
-        return;
-    // line_policy 3 (launch_transform: every window starts on a 128-byte line, so no line is shared between tiles):
-    // write-through streaming stores as in the aligned tiles; otherwise plain nt, which lets L2 merge the two halves
-    // of a shared line
-    if (sh.line_policy == 3)
-        gstore16(soa + g, lds_at<u32x4>(const_cast<uint8_t*>(lds), la));
-    else
-        __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
-}
-
-// one halo tile; `lds`: halo_lds_bytes<FMT>() bytes
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
-__device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
-                                              uint64_t /*total_blocks: in sh.gbase*/, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
-                                              uint8_t* lds)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
-    constexpr int H = kHaloBlocks;
-    constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors at most: 64 (BC2 / BC3) or 32 (BC1)
-    const int t = threadIdx.x;
-    // region of stream s: starts at off_s * (T + H) + 64 * s (16-byte aligned), holds the records of blocks
-    // [blk0 - H, blk0 + T) from byte d_s on (d_s = 0..63); base[s] = address of the record of the tile's block 0
-    int base[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s)
-        base[s] = s < S.n ? S.off[s] * (T + H) + kHaloPad * s + sh.d[s] + S.width[s] * H : 0;
-
-    const uint8_t* tile_aos = aos + tile * 4096;
-    // TEMPORAL load (no `nt`): the tile's last blocks are read a second time, as the next tile's halo, by a workgroup on
-    // another XCD; a line fetched with `nt` is gone by then and comes from HBM again (PMC: 1.25 x the algorithmic read with
-    // a 63-block halo), a line fetched temporally is still in the memory-side cache.  Found by accident -- the compiler
-    // merged an experiment's two loads and dropped the hint -- and worth 0.05-0.07 of peak on large halos
-    // (profiles/r02_b_shift_probe.txt); on small halos it costs nothing.
-    const u32x4 q = *reinterpret_cast<const u32x4*>(tile_aos + t * 16);
-    // Only the blocks that have bytes inside a window are fetched: max over the streams of ceil(d_s / w_s) blocks, at
-    // most 16 (the whole halo costs 0.02 of peak on BC3 -- 6 % more bytes read -- profiles/r02_b_shift_probe.txt).
-    // skip_partial: timing experiment (wrong output)
-    const int hv = sh.halo_vecs;
-    const bool has_halo = tile > 0 && t < hv && !sh.skip_partial;
-    if (has_halo) {
-        // plain load: the previous tile has just fetched these lines
-        const u32x4 qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
-        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
-    }
-    static_assert(HV <= 64, "the halo is loaded by lanes of wave 0");
-    scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
-    __syncthreads();
-
-    uint64_t gb[6];
-    slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    const bool first_tile = tile == 0;
-    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
-    case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, first_tile, gb, sh); break;
-    case 1: halo_copy_out_wave<FMT, SA, SC, 1>(soa, lds, t, first_tile, gb, sh); break;
-    case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, first_tile, gb, sh); break;
-    default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, first_tile, gb, sh); break;
-    }
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
-__global__ void __launch_bounds__(256)
-fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-               Shifts sh)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    fwd_halo_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, total_blocks, first_block, sh, tile, lds);
-}
-
-// Loads of wave W of an inverse shifted tile: lane t fetches the aligned 16-byte segment that holds image byte 16 t.
-// Which streams a wave's 1 KiB of the image can meet is known at compile time (BC3 with both splits: wave 0 meets the two
-// alpha endpoint streams and the start of the alpha indices, wave 1 the indices only, wave 2 the two colour streams, wave 3
-// the colour indices), so the per-lane select over the streams shrinks to those, and the extra partial last segment of
-// every stream -- lanes 0 .. n-1 -- is wave 0's business alone.  The kernel is bound by its instruction stream (a wave
-// instruction takes the SIMD four cycles: the first form ran 146 VALU + 114 SALU per wave against 67 + 36 in the aligned
-// tile, PMC, profiles/r02_a_shift_pmc.txt; with the per-wave loads 69 + 107, r02_b_shift_probe.txt), which is why this
-// matters -- and why what is left of the distance to the aligned tiles is not instructions any more.
-// A load may fetch the whole aligned segment even when only part of it belongs to this tile's slice: the other bytes land
-// in the stream's LDS padding.  Only a segment that pokes outside the transformed buffer itself (first tile of the first
-// stream, last tile of the last stream) is fetched piecewise.  All loads of the wave are issued before the first wait.
-template <int FMT, bool SA, bool SC, int W>
-__device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ soa, uint8_t* lds, int t,
-                                                    const uint64_t (&gb)[6], const Shifts& sh, uint64_t total_bytes)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
-    constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
-    const int o = t * 16;
-    int la = 0, k = 0, shift = 0;
-    uint64_t g = 0;
-    static_for<0, S.n>([&](auto si) {
-        constexpr int s = decltype(si)::value;
-        constexpr int lo = S.off[s] * T;
-        constexpr int hi = lo + S.width[s] * T;
-        if constexpr (lo < wave_hi && hi > wave_lo) {
-            constexpr bool only = lo <= wave_lo && hi >= wave_hi;   // the whole wave sits in this stream
-            if (only || (o >= lo && o < hi)) {
-                la = lo + 16 * s + (o - lo);
-                g = gb[s] + (uint64_t)(o - lo);
-                k = (o - lo) >> 4;
-                shift = sh.d[s];
-            }
-        }
-    });
-    // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
-    const bool main_inside = g + 16 <= total_bytes;
-    u32x4 v_main = {0, 0, 0, 0};
-    if (main_inside)
-        v_main = gload16(soa + g);
-    if constexpr (W == 0) {
-        // the extra, partial last segment of stream t (lanes 0..n-1), selected by data, not by control flow
-        int la_t = 0, shift_t = 0;
-        uint64_t g_t = 0;
-#pragma unroll
-        for (int ss = 0; ss < S.n; ++ss) {
-            if (ss == t) {
-                const int bytes = S.width[ss] * T;
-                la_t = S.off[ss] * T + 16 * ss + bytes;
-                shift_t = sh.d[ss];
-                g_t = gb[ss] + bytes;
-            }
-        }
-        const bool has_tail = t < S.n && shift_t > 0;
-        const bool tail_inside = g_t + 16 <= total_bytes;
-        // (Making these two loads branch-free -- every lane also loading a "tail", lanes without one re-reading their main
-        // segment -- cost 0.08 of peak: the second load instruction is not free even when it hits L1.)
-        u32x4 v_tail = {0, 0, 0, 0};
-        if (has_tail && tail_inside)
-            v_tail = gload16(soa + g_t);
-        if (has_tail) {
-            if (tail_inside)
-                lds_at<u32x4>(lds, la_t) = v_tail;
-            else
-                copy_partial_segment<false>(lds + la_t, soa + g_t, 0, shift_t);
-        }
-    }
-    if (main_inside)
-        lds_at<u32x4>(lds, la) = v_main;
-    else
-        copy_partial_segment<false>(lds + la, soa + g, (k == 0) ? shift : 0, (k == 0) ? 16 : shift);
-}
-
-// one shifted tile, inverse; `lds`: kShiftLdsBytes
-template <int FMT, int VARIANT, bool SA, bool SC>
-__device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
-                                               uint64_t total_blocks, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
-                                               uint8_t* lds)
-{
-    constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
-    const int t = threadIdx.x;
-    int base[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s)
-        base[s] = s < S.n ? S.off[s] * T + 16 * s + sh.d[s] : 0;
-
-    const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
-    uint64_t gb[6];
-    slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
-    case 0: inv_shift_load_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, total_bytes); break;
-    case 1: inv_shift_load_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, total_bytes); break;
-    case 2: inv_shift_load_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, total_bytes); break;
-    default: inv_shift_load_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, total_bytes); break;
-    }
-    __syncthreads();
-    const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t, base)
-                               : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t, base);
-    gstore16_aos(aos, aos + tile * 4096 + t * 16, q);
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC>
-__global__ void __launch_bounds__(256)
-inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
-                Shifts sh)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
-    inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Element-granular kernels: one lane per block, any alignment, any block count.  Used for the tail of a
-// tiled range and for buffers whose pointers / stream bases are not 16-byte aligned.
-// ------------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, bool natural)
-{
-    // W in {1,2,4,8}; `natural` = p is W-aligned (uniform per stream)
-    if (natural) {
-        if constexpr (W == 1) *p = (uint8_t)v;
-        if constexpr (W == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)v;
-        if constexpr (W == 4) *reinterpret_cast<uint32_t*>(p) = (uint32_t)v;
-        if constexpr (W == 8) *reinterpret_cast<uint64_t*>(p) = v;
-    } else {
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-            p[i] = (uint8_t)(v >> (8 * i));
-    }
-}
-
-template <int W>
-__device__ __forceinline__ uint64_t load_bytes(const uint8_t* p, bool natural)
-{
-    if (natural) {
-        if constexpr (W == 1) return *p;
-        if constexpr (W == 2) return *reinterpret_cast<const uint16_t*>(p);
-        if constexpr (W == 4) return *reinterpret_cast<const uint32_t*>(p);
-        if constexpr (W == 8) return *reinterpret_cast<const uint64_t*>(p);
-    }
-    uint64_t v = 0;
-#pragma unroll
-    for (int i = 0; i < W; ++i)
-        v |= (uint64_t)p[i] << (8 * i);
-    return v;
-}
-
-__device__ __forceinline__ bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
-
-// block i (0 <= i < count) of the element-granular range; shared by generic_kernel and the batch kernel
-template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int NORM = kNormNone>
-__device__ __forceinline__ void generic_block(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                              uint64_t total_blocks, uint64_t first_block, uint64_t local_first,
-                                              uint64_t count, uint64_t i)
-{
-    // AoS side: block (local_first + i) of the range lives at aos + (local_first + i) * BLOCK.
-    // SoA side: global block index first_block + local_first + i.
-    constexpr int B = fmt_block(FMT);
-    if (i >= count)
-        return;
-    const uint64_t lb = local_first + i;
-    const uint64_t gb = first_block + lb;
-    const uint64_t N = total_blocks;
-
-    const uint8_t* aos_c = INVERSE ? nullptr : src + lb * B;
-    uint8_t* aos_m = INVERSE ? dst + lb * B : nullptr;
-    const uint8_t* soa_c = INVERSE ? src : nullptr;
-    uint8_t* soa_m = INVERSE ? nullptr : dst;
-
-    const void* aos_any = INVERSE ? (const void*)aos_m : (const void*)aos_c;
-    const void* soa_any = INVERSE ? (const void*)soa_c : (const void*)soa_m;
-    const bool aos4 = aligned_to(aos_any, 4);  // block size is a multiple of 8, so uniform per launch
-    const bool aos2 = aligned_to(aos_any, 2);
-    const uintptr_t soa_base = reinterpret_cast<uintptr_t>(soa_any);
-
-    // field values of the block
-    uint64_t alpha8 = 0;          // BC2 alpha
-    uint32_t a0 = 0, a1 = 0;      // BC3 alpha endpoints
-    uint32_t i01 = 0, i23 = 0, i45 = 0;  // BC3 alpha index halfwords
-    uint32_t colours = 0, indices = 0;
-    constexpr int CO = (FMT == kBc1) ? 0 : 8;   // colour dword offset in block
-
-    if constexpr (!INVERSE) {
-        if constexpr (FMT == kBc2)
-            alpha8 = load_bytes<4>(aos_c, aos4) | (load_bytes<4>(aos_c + 4, aos4) << 32);
-        if constexpr (FMT == kBc3) {
-            a0 = aos_c[0];
-            a1 = aos_c[1];
-            i01 = (uint32_t)load_bytes<2>(aos_c + 2, aos2);
-            i23 = (uint32_t)load_bytes<2>(aos_c + 4, aos2);
-            i45 = (uint32_t)load_bytes<2>(aos_c + 6, aos2);
-        }
-        colours = (uint32_t)load_bytes<4>(aos_c + CO, aos4);
-        indices = (uint32_t)load_bytes<4>(aos_c + CO + 4, aos4);
-        if constexpr (FMT == kBc1 && NORM != kNormNone)
-            normalize_bc1_block<NORM>(colours, indices);
-        colours = decorrelate2<VARIANT>(colours);
-    }
-
-    // stream addresses (byte offsets from the start of the transformed buffer)
-    uint64_t o_alpha = 0, o_a1 = 0, o_aidx = 0, o_col, o_c1 = 0, o_idx;
-    if constexpr (FMT == kBc1) {
-        o_col = SC ? 2 * gb : 4 * gb;
-        o_c1 = 2 * N + 2 * gb;
-        o_idx = 4 * N + 4 * gb;
-    } else {
-        if constexpr (FMT == kBc2) {
-            o_alpha = 8 * gb;
-        } else {
-            o_alpha = SA ? gb : 2 * gb;
-            o_a1 = N + gb;
-            o_aidx = 2 * N + 6 * gb;
-        }
-        o_col = 8 * N + (SC ? 2 * gb : 4 * gb);
-        o_c1 = 10 * N + 2 * gb;
-        o_idx = 12 * N + 4 * gb;
-    }
-    const bool n2 = ((soa_base) & 1) == 0;  // every 2-byte stream element offset is even, so parity = base parity
-    // 4-/8-byte alignment of a stream depends on base + off*N (uniform per launch)
-    auto al = [&](uint64_t off, int a) { return ((soa_base + off) & (uint64_t)(a - 1)) == 0; };
-
-    if constexpr (!INVERSE) {
-        if constexpr (FMT == kBc2)
-            store_bytes<8>(soa_m + o_alpha, alpha8, al(o_alpha, 8));
-        if constexpr (FMT == kBc3) {
-            if constexpr (SA) {
-                soa_m[o_alpha] = (uint8_t)a0;
-                soa_m[o_a1] = (uint8_t)a1;
-            } else {
-                store_bytes<2>(soa_m + o_alpha, a0 | (a1 << 8), n2);
-            }
-            store_bytes<2>(soa_m + o_aidx + 0, i01, al(o_aidx, 2));
-            store_bytes<2>(soa_m + o_aidx + 2, i23, al(o_aidx, 2));
-            store_bytes<2>(soa_m + o_aidx + 4, i45, al(o_aidx, 2));
-        }
-        if constexpr (SC) {
-            store_bytes<2>(soa_m + o_col, colours & 0xFFFFu, al(o_col, 2));
-            store_bytes<2>(soa_m + o_c1, colours >> 16, al(o_c1, 2));
-        } else {
-            store_bytes<4>(soa_m + o_col, colours, al(o_col, 4));
-        }
-        store_bytes<4>(soa_m + o_idx, indices, al(o_idx, 4));
-    } else {
-        if constexpr (FMT == kBc2)
-            alpha8 = load_bytes<8>(soa_c + o_alpha, al(o_alpha, 8));
-        if constexpr (FMT == kBc3) {
-            if constexpr (SA) {
-                a0 = soa_c[o_alpha];
-                a1 = soa_c[o_a1];
-            } else {
-                const uint32_t p = (uint32_t)load_bytes<2>(soa_c + o_alpha, n2);
-                a0 = p & 0xFF;
-                a1 = p >> 8;
-            }
-            i01 = (uint32_t)load_bytes<2>(soa_c + o_aidx + 0, al(o_aidx, 2));
-            i23 = (uint32_t)load_bytes<2>(soa_c + o_aidx + 2, al(o_aidx, 2));
-            i45 = (uint32_t)load_bytes<2>(soa_c + o_aidx + 4, al(o_aidx, 2));
-        }
-        if constexpr (SC)
-            colours = (uint32_t)load_bytes<2>(soa_c + o_col, al(o_col, 2)) |
-                      ((uint32_t)load_bytes<2>(soa_c + o_c1, al(o_c1, 2)) << 16);
-        else
-            colours = (uint32_t)load_bytes<4>(soa_c + o_col, al(o_col, 4));
-        indices = (uint32_t)load_bytes<4>(soa_c + o_idx, al(o_idx, 4));
-        colours = recorrelate2<VARIANT>(colours);
-
-        if constexpr (FMT == kBc2) {
-            store_bytes<4>(aos_m, (uint32_t)alpha8, aos4);
-            store_bytes<4>(aos_m + 4, (uint32_t)(alpha8 >> 32), aos4);
-        }
-        if constexpr (FMT == kBc3) {
-            aos_m[0] = (uint8_t)a0;
-            aos_m[1] = (uint8_t)a1;
-            store_bytes<2>(aos_m + 2, i01, aos2);
-            store_bytes<2>(aos_m + 4, i23, aos2);
-            store_bytes<2>(aos_m + 6, i45, aos2);
-        }
-        store_bytes<4>(aos_m + CO, colours, aos4);
-        store_bytes<4>(aos_m + CO + 4, indices, aos4);
-    }
-}
-
-template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int NORM = kNormNone>
-__global__ void __launch_bounds__(kThreads)
-generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t total_blocks,
-               uint64_t first_block, uint64_t local_first, uint64_t count)
-{
-    generic_block<FMT, VARIANT, SA, SC, INVERSE, NORM>(src, dst, total_blocks, first_block, local_first, count,
-                                                       (uint64_t)blockIdx.x * kThreads + threadIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Batch kernel: many buffers of one format and direction in ONE launch (dxtlt_transform_batch_device).  A texture of
-// a few MiB cannot fill 256 CUs and launching them one by one is bound by the ~5 us a launch costs the host; here
-// every workgroup looks up which buffer it belongs to and runs one tile of it -- the aligned tile, a forward halo tile or
-// a shifted tile, whichever launch_transform would choose for that buffer (BatchEntry::form, plan_batch_entry) -- or, past
-// the buffer's last full tile, 256 blocks of the element path.
-// Settings are per buffer, so the variant / split combination is a run-time switch over the instantiated bodies;
-// workgroups of one buffer all take the same case.
-// ------------------------------------------------------------------------------------------------
-// A table entry as the workgroup sees it: everything arrives through scalar (dword) loads -- byte fields read one by
-// one would go through the vector memory path and add a second round trip before the tile's own load can start --
-// and the buffer pointers are tagged as global memory again (a pointer that was loaded from memory is a generic one
-// to the compiler, which would turn every access of the tile into a flat_* instruction).
-struct BatchView {
-    const uint8_t* src;
-    uint8_t* dst;
-    uint64_t blocks;
-    uint32_t first_wg, tile_wgs;
-    uint32_t flags;       // variant | split_alpha << 8 | split_colour << 16 | form << 24
-    uint32_t shifts[2];   // shift[0..3], shift[4..5] | halo_vecs << 16
-};
-
-__device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
-{
-    typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
-    typedef __attribute__((address_space(1))) uint8_t* global_ptr;
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(entry);
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(entry);
-    BatchView v;
-    v.src = (const uint8_t*)(global_cptr)q[0];
-    v.dst = (uint8_t*)(global_ptr)q[1];
-    v.blocks = q[2];
-    v.first_wg = w[6];
-    v.tile_wgs = w[7];
-    v.flags = w[8];
-    v.shifts[0] = w[9];
-    v.shifts[1] = w[10];
-    return v;
-}
-static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, variant) == 32 && offsetof(BatchEntry, shift) == 36,
-              "load_batch_entry reads BatchEntry by dword offsets");
-
-// BatchEntry::form
-constexpr uint32_t kBatchAligned = 1, kBatchHalo = 2;   // 0: shifted tiles, first form
-
-template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
-__device__ __forceinline__ void batch_unit(const BatchView& en, uint32_t local, uint8_t* lds)
-{
-    constexpr uint64_t T = tile_blocks(FMT, 256);
-    const uint32_t form = en.flags >> 24;
-    if constexpr (!INVERSE) {
-        if (form == kBatchHalo) {
-            // stream bases off their lines, forward: halo tiles in launch order (as the single-buffer call), then one
-            // workgroup for the records of the first 64 blocks and the rest for everything behind the last window
-            if (local < en.tile_wgs) {
-                Shifts sh;
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 63u);
-                sh.xcd_remap = 0;
-                sh.line_policy = 3;
-                sh.skip_partial = 0;
-                sh.natural = 1;
-                sh.halo_vecs = (int)(en.shifts[1] >> 16) & 0xFF;
-                fill_gbase(sh, make_streams(FMT, SA, SC), en.blocks, 0);
-                fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, en.blocks, 0, sh, local, lds);
-            } else if (local == en.tile_wgs) {
-                generic_block<FMT, VARIANT, SA, SC, false>(en.src, en.dst, en.blocks, 0, 0, kHaloBlocks, threadIdx.x);
-            } else {
-                const uint64_t done = (uint64_t)en.tile_wgs * T - kHaloBlocks;
-                generic_block<FMT, VARIANT, SA, SC, false>(en.src, en.dst, en.blocks, 0, done, en.blocks - done,
-                                                           (uint64_t)(local - en.tile_wgs - 1) * 256 + threadIdx.x);
-            }
-            return;
-        }
-    }
-    if (local < en.tile_wgs && form == kBatchAligned) {
-        // every stream base on a 128-byte line: the aligned tile, tiles in launch order (as the single-buffer call runs it)
-        if constexpr (INVERSE)
-            inv_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
-        else
-            fwd_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
-    } else if (local < en.tile_wgs) {
-        Shifts sh;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 15u);
-        sh.xcd_remap = 0;
-        sh.line_policy = 1;
-        sh.skip_partial = 0;
-        sh.halo_vecs = 0;
-        sh.natural = shifts_are_natural(make_streams(FMT, SA, SC), sh.d);
-        fill_gbase(sh, make_streams(FMT, SA, SC), en.blocks, 0);
-        // every buffer's first workgroup is a multiple of 8 (the host pads), so local % 8 is the XCD this workgroup
-        // runs on and the XCD-contiguous tile order of the single-buffer shifted kernels applies per buffer
-        const uint64_t tile = xcd_contiguous_tile(local, en.tile_wgs);
-        if constexpr (INVERSE)
-            inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
-        else
-            fwd_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
-    } else {
-        const uint64_t done = (uint64_t)en.tile_wgs * T;
-        generic_block<FMT, VARIANT, SA, SC, INVERSE>(en.src, en.dst, en.blocks, 0, done, en.blocks - done,
-                                                     (uint64_t)(local - en.tile_wgs) * 256 + threadIdx.x);
-    }
-}
-
-template <int FMT, int VARIANT, bool INVERSE>
-__device__ __forceinline__ void batch_splits(const BatchView& en, uint32_t local, uint8_t* lds)
-{
-    const bool split_alpha = ((en.flags >> 8) & 0xFF) != 0, split_colour = ((en.flags >> 16) & 0xFF) != 0;
-    if constexpr (FMT == kBc3) {
-        if (split_alpha) {
-            if (split_colour) batch_unit<FMT, VARIANT, true, true, INVERSE>(en, local, lds);
-            else batch_unit<FMT, VARIANT, true, false, INVERSE>(en, local, lds);
-            return;
-        }
-    }
-    if (split_colour) batch_unit<FMT, VARIANT, false, true, INVERSE>(en, local, lds);
-    else batch_unit<FMT, VARIANT, false, false, INVERSE>(en, local, lds);
-}
-
-// uniform_wgs != 0: every buffer of the launch owns exactly that many workgroups (buffers of one size -- the texture
-// sets a batch is made for), so the owning entry is wg / uniform_wgs and ONE scalar load -- the entry, a line every
-// workgroup of the buffer shares -- stands between the start of the workgroup and its tile's load instead of two
-// dependent ones (coarse index, then entry).  The quotient comes from a multiply-high with magic = floor(2^32 /
-// uniform_wgs): exact or one short for wg < 2^24, put right by one compare.
-//
-// strided.on: the batch is a regular array of buffers -- one size, one set of settings, sources and destinations each a
-// constant stride apart (an array texture, the mip level of a texture set that a decompressor wrote into one
-// allocation).  Its first entry then travels in the kernel arguments with the two strides, and a workgroup reaches its
-// tile without any table load at all: entry = first entry with both pointers advanced by (wg / uniform_wgs) strides.
-struct StridedBatch {
-    BatchEntry first;
-    int64_t src_stride, dst_stride;
-    uint32_t on;
-};
-
-template <int FMT, bool INVERSE>
-__global__ void __launch_bounds__(256)
-batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t n_entries,
-             uint32_t uniform_wgs, uint32_t magic, StridedBatch strided)
-{
-    constexpr int kLds = (!INVERSE && halo_lds_bytes<FMT>() > kShiftLdsBytes) ? halo_lds_bytes<FMT>() : kShiftLdsBytes;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
-    const uint32_t wg = blockIdx.x;
-    uint32_t e;
-    BatchView en;
-    if (uniform_wgs != 0) {
-        e = __umulhi(wg, magic);
-        if ((e + 1) * uniform_wgs <= wg)
-            ++e;
-        if (strided.on != 0) {
-            // kernel arguments: scalar loads off the kernarg pointer, nothing depends on a table
-            typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
-            typedef __attribute__((address_space(1))) uint8_t* global_ptr;
-            const BatchEntry& f = strided.first;
-            en.src = (const uint8_t*)(global_cptr)(reinterpret_cast<uintptr_t>(f.src) + (uint64_t)((int64_t)e * strided.src_stride));
-            en.dst = (uint8_t*)(global_ptr)(reinterpret_cast<uintptr_t>(f.dst) + (uint64_t)((int64_t)e * strided.dst_stride));
-            en.blocks = f.blocks;
-            en.first_wg = e * uniform_wgs;
-            en.tile_wgs = f.tile_wgs;
-            en.flags = (uint32_t)f.variant | ((uint32_t)f.split_alpha << 8) | ((uint32_t)f.split_colour << 16) | ((uint32_t)f.form << 24);
-            en.shifts[0] = (uint32_t)f.shift[0] | ((uint32_t)f.shift[1] << 8) | ((uint32_t)f.shift[2] << 16) | ((uint32_t)f.shift[3] << 24);
-            en.shifts[1] = (uint32_t)f.shift[4] | ((uint32_t)f.shift[5] << 8) | ((uint32_t)f.halo_vecs << 16);
-        } else {
-            en = load_batch_entry(entries + e);
-        }
-    } else {
-        // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each.
-        // The entry and its successor's first workgroup are fetched TOGETHER, so that two dependent scalar loads stand between
-        // the start of the workgroup and its tile's load, not three: with buffers of a few hundred workgroups every one of
-        // these loads misses the scalar cache (a CU sees about one workgroup per buffer).  The empty asm pins the entry's loads
-        // in front of the loop -- the compiler otherwise sinks them behind it (round 2's binary did: coarse -> successor's
-        // first workgroup -> entry, three levels).
-        e = coarse[wg >> 6];
-        en = load_batch_entry(entries + e);
-        uint32_t next_first = e + 1 < n_entries ? entries[e + 1].first_wg : 0xFFFFFFFFu;
-        asm volatile("" ::"s"(en.src), "s"(en.dst), "s"(en.blocks), "s"(en.flags), "s"(en.tile_wgs), "s"(next_first));
-        while (next_first <= wg) {   // only buffers of fewer than 64 workgroups take this
-            ++e;
-            en = load_batch_entry(entries + e);
-            next_first = e + 1 < n_entries ? entries[e + 1].first_wg : 0xFFFFFFFFu;
-        }
-    }
-    const uint32_t local = wg - en.first_wg;
-    switch (en.flags & 0xFF) {
-    case kNone: batch_splits<FMT, kNone, INVERSE>(en, local, lds); break;
-    case kVar1: batch_splits<FMT, kVar1, INVERSE>(en, local, lds); break;
-    case kVar2: batch_splits<FMT, kVar2, INVERSE>(en, local, lds); break;
-    default: batch_splits<FMT, kVar3, INVERSE>(en, local, lds); break;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Synthetic data: counter-based splitmix64, one qword per lane-iteration (bench / test plumbing).
@@ -1637,21 +279,6 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         // XCD-contiguous one) is right for every halo size.
         shh.xcd_remap = remap_override >= 0 ? remap_override : 0;
     }
-    if (num_tiles > 0) {
-        if (use_halo)
-            hipLaunchKernelGGL(ks.halo[shh.natural ? 1 : 0], dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8,
-                               r.total_blocks, r.first_block, shh);
-        else if (use_shift)
-            hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
-                               r.first_block, sh);
-        else
-            hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream,
-                               src8, dst8, r.total_blocks, r.first_block, aligned_remap, (int64_t)0, (int64_t)0);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess)
-            return e;
-    }
-    uint64_t done = num_tiles * T;
     auto element_range = [&](uint64_t local_first, uint64_t count) -> hipError_t {
         if (count == 0)
             return hipSuccess;
@@ -1660,96 +287,121 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
                            r.first_block, local_first, count);
         return hipGetLastError();
     };
+    // Shifts of the sub-range [local_first, local_first + count) of the range as ONE edge tile (count < T): what is left
+    // behind the aligned tiles, or a range smaller than a tile.  Forward: a halo tile 0 (no halo, writes every stream from its
+    // first byte to its last); inverse: a shifted tile 0.
+    auto edge_tile_of = [&](uint64_t local_first, uint64_t count) -> hipError_t {
+        if (count == 0)
+            return hipSuccess;
+        Shifts e{};
+        const int mask = inverse ? 15 : 63;
+        for (int i = 0; i < S.n; ++i) {
+            const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
+                                  (uint64_t)S.width[i] * (r.first_block + local_first);
+            e.d[i] = (int)(base & (uint64_t)mask);
+        }
+        fill_gbase(e, S, r.total_blocks, r.first_block + local_first);
+        e.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, e.d);
+        e.line_policy = 1;
+        e.full_tiles = 0;
+        e.range_blocks = count;
+        const uint64_t aos_off = local_first * (uint64_t)fmt_block(fmt);
+        if (inverse)
+            hipLaunchKernelGGL(ks.shifted, dim3(1), dim3(256), 0, stream, src8, dst8 + aos_off, r.total_blocks, r.first_block, e);
+        else
+            hipLaunchKernelGGL(ks.halo[e.natural ? 1 : 0], dim3(1), dim3(256), 0, stream, src8 + aos_off, dst8, r.total_blocks,
+                               r.first_block, e);
+        return hipGetLastError();
+    };
+    const uint64_t rest = r.num_blocks - num_tiles * T;
+    // experiment switch 0x2000: the round-3 routing (heads and tails through the element kernel)
+    const bool edge_tiles = use_tiles && !(force_bits & 0x2000) && (inverse || ks.halo[0] != nullptr);
+    if (use_halo && edge_tiles) {
+        // halo tiles + edge tiles in ONE launch: tile 0 writes the head of every stream itself, and one more workgroup takes the
+        // blocks behind the last whole tile and the last d_s bytes of every stream
+        bool tail = rest > 0;
+        for (int i = 0; i < S.n; ++i)
+            tail = tail || shh.d[i] > 0;
+        shh.full_tiles = (uint32_t)num_tiles;
+        shh.range_blocks = r.num_blocks;
+        hipLaunchKernelGGL(ks.halo[shh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
+                           r.total_blocks, r.first_block, shh);
+        return hipGetLastError();
+    }
+    if (use_shift && inverse && edge_tiles) {
+        sh.full_tiles = (uint32_t)num_tiles;
+        sh.range_blocks = r.num_blocks;
+        hipLaunchKernelGGL(ks.shifted, dim3((unsigned)(num_tiles + (rest > 0 ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
+                           r.total_blocks, r.first_block, sh);
+        return hipGetLastError();
+    }
+    if (num_tiles > 0) {
+        if (use_halo) {   // (switch 0x2000)
+            shh.full_tiles = (uint32_t)num_tiles;
+            shh.range_blocks = num_tiles * T;
+            shh.skip_partial = 0;
+            hipLaunchKernelGGL(ks.halo[shh.natural ? 1 : 0], dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8,
+                               r.total_blocks, r.first_block, shh);
+        } else if (use_shift) {
+            sh.full_tiles = (uint32_t)num_tiles;
+            sh.range_blocks = num_tiles * T;
+            hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
+                               r.first_block, sh);
+        } else {
+            hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream,
+                               src8, dst8, r.total_blocks, r.first_block, aligned_remap, (int64_t)0, (int64_t)0);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    uint64_t done = num_tiles * T;
     if (use_halo && num_tiles > 0) {
-        // what the halo tiles' windows leave out: the head of every stream of the range (records of its first 64 blocks)
-        // and everything behind the last window (records of the last 64 blocks of the tiles, and the rest)
+        // (switch 0x2000) what the halo tiles' windows leave out: the head of every stream of the range (records of its first 64
+        // blocks) and everything behind the last window (records of the last 64 blocks of the tiles, and the rest)
         if (hipError_t e = element_range(0, kHaloBlocks); e != hipSuccess)
             return e;
         done -= kHaloBlocks;
+        return element_range(done, r.num_blocks - done);
+    }
+    // behind aligned tiles (or a range smaller than a tile): one edge tile -- 256 threads' worth of blocks at most
+    if (edge_tiles && rest <= (uint64_t)tile_blocks(fmt, 256))
+        return edge_tile_of(done, rest);
+    if (edge_tiles) {   // BC1 with 512-thread tiles (an experiment size): up to 1023 blocks left
+        const uint64_t T256 = (uint64_t)tile_blocks(fmt, 256);
+        for (uint64_t at = done; at < r.num_blocks; at += T256)
+            if (hipError_t e = edge_tile_of(at, std::min(T256, r.num_blocks - at)); e != hipSuccess)
+                return e;
+        return hipSuccess;
     }
     return element_range(done, r.num_blocks - done);
 }
 
-uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e)
+// A regular array of buffers whose stream bases all sit on 128-byte lines and whose block count is a whole number of tiles IS
+// the single-buffer aligned kernel with one more grid dimension: no table, no lookup (the batch kernel's lookup and entry
+// decode are scalar instructions every wave of a workgroup executes on the one scalar unit a CU's four SIMDs share: 0.80
+// against 0.835 of peak on one 1 GiB BC3 buffer, profiles/r03_batch_spacing.txt).  Returns hipErrorNotSupported when the
+// array does not fit that shape (the caller then takes the batch kernel).
+hipError_t launch_tiled_array(Format fmt, bool inverse, const Settings& s, const void* first_src, void* first_dst,
+                              uint64_t blocks, uint32_t n_buffers, int64_t src_stride, int64_t dst_stride, hipStream_t stream)
 {
-    const bool sa = fmt == kBc3 && e.split_alpha;
-    const Streams S = make_streams(fmt, sa, e.split_colour != 0);
-    const void* soa = inverse ? (const void*)e.src : (const void*)e.dst;
-    // any AoS alignment: unaligned 16-byte vector accesses are exact and cheap on gfx950 (launch_transform)
-    const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
-    const uint64_t tiles = e.blocks / T;
-    // The same three tile forms as launch_transform: aligned tiles when every stream base is on a 128-byte line; forward,
-    // otherwise, halo tiles (windows moved back to a 64-byte boundary; needs naturally aligned shifts, which an 8-byte
-    // aligned pointer gives); the first shifted form for the rest.
-    bool on_lines = true;
-    int d64[6] = {0, 0, 0, 0, 0, 0}, halo_blocks = 0;
-    for (int i = 0; i < S.n; ++i) {
-        const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * e.blocks;
-        d64[i] = (int)(base & 63);
-        on_lines = on_lines && (base & 127) == 0;
-        halo_blocks = std::max(halo_blocks, (d64[i] + S.width[i] - 1) / S.width[i]);
-    }
-    const bool halo = !on_lines && !inverse && tiles > 0 && shifts_are_natural(S, d64);
-    e.form = on_lines ? 1 : halo ? 2 : 0;
-    for (int i = 0; i < 6; ++i)
-        e.shift[i] = (uint8_t)(halo ? d64[i] : d64[i] & 15);
-    const int per_vec = 16 / fmt_block(fmt);
-    e.halo_vecs = halo ? (uint8_t)((halo_blocks + per_vec - 1) / per_vec) : 0;
-    e.tile_wgs = (uint32_t)tiles;
-    if (halo)   // one workgroup for the first 64 blocks, then the element path from 64 blocks before the end of the tiles
-        return (uint32_t)(tiles + 1 + (e.blocks - tiles * T + kHaloBlocks + 255) / 256);
-    return (uint32_t)(tiles + (e.blocks - tiles * T + 255) / 256);
-}
-
-hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
-                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream, const BatchEntry* strided_first,
-                        int64_t src_stride, int64_t dst_stride)
-{
-    if (n_entries == 0 || total_wgs == 0)
-        return hipSuccess;
-    if (uniform_wgs != 0 && ((uint64_t)uniform_wgs * n_entries != total_wgs || total_wgs > 0xFFFFFFu))
-        return hipErrorInvalidValue;
-    const uint32_t magic = uniform_wgs > 1 ? (uint32_t)((1ull << 32) / uniform_wgs) : 0;
-    if (uniform_wgs == 1)
-        uniform_wgs = 0;   // 2^32 does not fit the magic word; one workgroup per buffer takes the general lookup
-    // A regular array of buffers whose stream bases all sit on 128-byte lines and whose block count is a whole number of
-    // tiles IS the single-buffer aligned kernel with one more grid dimension: no table, no per-workgroup settings switch
-    // (the batch kernel runs 92 scalar instructions per wave where the tiled kernel runs 34 -- one scalar unit serves a
-    // CU's four SIMDs: 0.80 against 0.835 of peak on one 1 GiB BC3 buffer, profiles/r03_batch_spacing.txt).
-    static const bool no_array = std::getenv("DXTLT_BATCH_NO_ARRAY") != nullptr;   // A/B switch
-    if (strided_first != nullptr && uniform_wgs != 0 && !no_array && strided_first->form == 1 && n_entries <= 65535) {
-        const BatchEntry& f = *strided_first;
-        const int threads = default_tile_threads(fmt, inverse);
-        const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
-        // (HIP refuses a launch of 2^32 threads or more)
-        if (f.blocks % T == 0 && f.blocks / T <= 0x7FFFFFFFull && (f.blocks / T) * n_entries * (uint64_t)threads < (1ull << 32)) {
-            const bool sa = fmt == kBc3 && f.split_alpha != 0, sc = f.split_colour != 0;
-            KernelSet ks;
-            switch (fmt) {
-            case kBc1: ks = pick_variant<kBc1>(f.variant, false, sc, inverse); break;
-            case kBc2: ks = pick_variant<kBc2>(f.variant, false, sc, inverse); break;
-            default: ks = pick_variant<kBc3>(f.variant, sa, sc, inverse); break;
-            }
-            hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)(f.blocks / T), n_entries), dim3(threads), 0, stream,
-                               f.src, f.dst, f.blocks, (uint64_t)0, kTiledArray, src_stride, dst_stride);
-            return hipGetLastError();
-        }
-    }
-    StridedBatch strided{};
-    if (strided_first != nullptr && uniform_wgs != 0) {
-        strided.first = *strided_first;
-        strided.src_stride = src_stride;
-        strided.dst_stride = dst_stride;
-        strided.on = 1;
-    }
-    void (*k)(const BatchEntry*, const uint32_t*, uint32_t, uint32_t, uint32_t, StridedBatch) = nullptr;
+    const int threads = default_tile_threads(fmt, inverse);
+    const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
+    // (HIP refuses a launch of 2^32 threads or more)
+    if (n_buffers == 0 || n_buffers > 65535 || blocks == 0 || blocks % T != 0 || blocks / T > 0x7FFFFFFFull ||
+        (blocks / T) * n_buffers * (uint64_t)threads >= (1ull << 32))
+        return hipErrorNotSupported;
+    const bool sa = fmt == kBc3 && s.split_alpha, sc = s.split_colour;
+    KernelSet ks;
     switch (fmt) {
-    case kBc1: k = inverse ? batch_kernel<kBc1, true> : batch_kernel<kBc1, false>; break;
-    case kBc2: k = inverse ? batch_kernel<kBc2, true> : batch_kernel<kBc2, false>; break;
-    case kBc3: k = inverse ? batch_kernel<kBc3, true> : batch_kernel<kBc3, false>; break;
+    case kBc1: ks = pick_variant<kBc1>(s.variant, false, sc, inverse); break;
+    case kBc2: ks = pick_variant<kBc2>(s.variant, false, sc, inverse); break;
+    case kBc3: ks = pick_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, n_entries, uniform_wgs, magic, strided);
+    hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)(blocks / T), n_buffers), dim3(threads), 0, stream,
+                       static_cast<const uint8_t*>(first_src), static_cast<uint8_t*>(first_dst), blocks, (uint64_t)0, kTiledArray,
+                       src_stride, dst_stride);
     return hipGetLastError();
 }
 

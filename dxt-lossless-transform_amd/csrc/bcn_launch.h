@@ -77,43 +77,51 @@ hipError_t launch_normalize_bc2_split(void* colours, void* indices, uint64_t num
 hipError_t launch_normalize_bc3_split(void* alpha_endpoints, void* alpha_indices, void* color_endpoints, void* color_indices,
                                       uint64_t num_blocks, int alpha_mode, int color_mode, hipStream_t stream);
 
-// ---- batch launch: many buffers of one format and direction in one kernel (bcn_kernels.hip, batch_kernel) --------
-// One entry per buffer, sorted by first_wg (a multiple of 8).  Workgroups [first_wg, first_wg + tile_wgs) run one
-// 256-lane tile each, in the form `form` names (the one launch_transform would pick for the buffer); the workgroups after
-// them (up to the next entry's first_wg) run 256 blocks of the element path each -- for halo tiles the first of them takes
-// the buffer's first 64 blocks and the others start 64 blocks before the end of the tiles -- or nothing once the buffer's
-// blocks are exhausted (padding up to the next multiple of 8).
+// ---- batch launch: many buffers of one format, direction and settings in one kernel (batch_kernels.hip) ------------
+// One entry per buffer, in workgroup order.  Workgroups [first_wg, first_wg + full_tiles) run one whole 256-lane tile each, in
+// the form `form` names (the one launch_transform would pick for the buffer); workgroup first_wg + full_tiles, when
+// end_wg says it exists, is the buffer's edge tile: the blocks behind the last whole tile and, forward, the last bytes of every
+// stream (bcn_device.h, "Edge tiles").  No element path, no padding between buffers.
 struct BatchEntry {
     const uint8_t* src;
     uint8_t* dst;
     uint64_t blocks;
     uint32_t first_wg;
-    uint32_t tile_wgs;
-    uint8_t variant, split_alpha, split_colour;
-    uint8_t form;           // 0: shifted tiles, 1: aligned tiles, 2: forward halo tiles; filled by plan_batch_entry
-    uint8_t shift[6];       // misalignment of every stream base: mod 16, halo tiles mod 64
+    uint32_t end_wg;        // first_wg + workgroups of this buffer = the next buffer's first_wg
+    uint32_t full_tiles;
+    uint8_t form;           // 1: every stream base on a 128-byte line (aligned tiles); 0: halo tiles forward, shifted tiles inverse
     uint8_t halo_vecs;      // halo tiles: 16-byte vectors of blocks in front of a tile that have bytes in its windows
-    uint8_t reserved2;
+    uint8_t natural;        // every shift a multiple of its stream's element width (the kernel handles nothing else: plan_batch_entry)
+    uint8_t reserved;
+    uint8_t shift[6];       // misalignment of every stream base: mod 64 forward, mod 16 inverse
+    uint8_t reserved2[2];
+    uint64_t gbase[6];      // Shifts::gbase: off_s * blocks - shift[s], from the transformed-side pointer
 };
-static_assert(sizeof(BatchEntry) == 48, "BatchEntry layout is shared between host and device");
+static_assert(sizeof(BatchEntry) == 96, "BatchEntry layout is shared between host and device");
 
-// Fills tile_wgs and shift[] of `e` (src, dst, blocks, variant, split_* set by the caller) and returns the number of
-// workgroups the buffer needs (0 for an empty buffer).
-uint32_t plan_batch_entry(Format fmt, bool inverse, BatchEntry& e);
+// Fills first_wg-relative planning fields of `e` (src, dst, blocks set by the caller; first_wg too) for settings `s` and
+// returns the number of workgroups the buffer needs (0 for an empty buffer), or 0xFFFFFFFF when the batch kernel cannot take the
+// buffer (a transformed-side pointer whose stream shifts are not multiples of the element widths: the caller launches it alone).
+uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntry& e);
 
-// d_entries / d_coarse: device copies of the entry table and of the coarse index (coarse[k] = index of the entry that
-// owns workgroup 64 * k), total_wgs = first_wg + workgroups of the last entry.
 // Copies a table of `bytes` (a multiple of 16) from mapped pinned host memory (its device-side address) to device memory
 // with a small kernel on `stream` -- no copy-engine hand-over in front of the batch kernel.
 hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes, hipStream_t stream);
 
-// uniform_wgs: 0, or the number of workgroups EVERY entry owns (first_wg == index * uniform_wgs, total_wgs == n_entries *
-// uniform_wgs): the kernel then finds a workgroup's entry by division instead of through the coarse index.
+// d_entries / d_coarse: device copies of the entry table and of the coarse index (coarse[k] = index of the entry that
+// owns workgroup 64 * k), total_wgs = end_wg of the last entry.
+// uniform_wgs: 0, or the number of workgroups EVERY entry owns (first_wg == index * uniform_wgs): the kernel then finds a
+// workgroup's entry by division instead of through the coarse index.
 // strided_first != nullptr (needs uniform_wgs != 0): the batch is a regular array -- every entry equals *strided_first but for
 // its pointers, which advance by src_stride / dst_stride bytes per entry; the kernel then reads no table at all.
-hipError_t launch_batch(Format fmt, bool inverse, const BatchEntry* d_entries, const uint32_t* d_coarse, uint32_t n_entries,
-                        uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream, const BatchEntry* strided_first = nullptr,
-                        int64_t src_stride = 0, int64_t dst_stride = 0);
+hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint32_t* d_coarse,
+                        uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
+                        const BatchEntry* strided_first = nullptr, int64_t src_stride = 0, int64_t dst_stride = 0);
+
+// A regular array of aligned buffers as the single-buffer aligned kernel with blockIdx.y = buffer (bcn_kernels.hip);
+// hipErrorNotSupported when the array does not have that shape.
+hipError_t launch_tiled_array(Format fmt, bool inverse, const Settings& s, const void* first_src, void* first_dst,
+                              uint64_t blocks, uint32_t n_buffers, int64_t src_stride, int64_t dst_stride, hipStream_t stream);
 
 inline int block_bytes(Format f) { return f == kBc1 ? 8 : 16; }
 
