@@ -654,7 +654,11 @@ def corpus_textures(count_scale: float = 1.0, seed: int = 0xC0A9005) -> list:
     for w, h, c in CORPUS_CLASSES:
         texs += [(w, h, mip_chain_blocks(w, h))] * max(1, int(round(c * count_scale)))
     random.Random(seed).shuffle(texs)
-    return texs
+    # experiment knobs (tools/corpus_probe.py): the textures in size order; only textures of at least so many blocks
+    if os.environ.get("DXTLT_CORPUS_SORT") == "1":
+        texs.sort(key=lambda t: t[2])
+    least = int(os.environ.get("DXTLT_CORPUS_MIN_BLOCKS", "0"))
+    return [t for t in texs if t[2] >= least]
 
 
 def corpus_layout(texs, block_bytes: int, align: int = 256):
@@ -666,7 +670,8 @@ def corpus_layout(texs, block_bytes: int, align: int = 256):
     return offs, at
 
 
-def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_scale: float = 1.0, cpu: bool = True) -> dict:
+def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_scale: float = 1.0, cpu: bool = True,
+                   align: int = 256) -> dict:
     """One corpus-shaped leg (see CORPUS_CLASSES): device-resident textures, one batch call per direction, HIP events per
     direction, exact round trip over the whole arena, oracle equality on three whole textures (the smallest, a middle one,
     one of the largest)."""
@@ -680,7 +685,7 @@ def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_sca
     texs = corpus_textures(count_scale)
     if fmt != "bc1":
         texs = texs[::2]                     # 16-byte blocks: every second texture, the same ~8.5 GiB
-    offs, arena = corpus_layout(texs, B)
+    offs, arena = corpus_layout(texs, B, align)
     x = torch.empty(arena, dtype=torch.uint8, device=dev)
     y = torch.zeros(arena, dtype=torch.uint8, device=dev)
     z = torch.zeros(arena, dtype=torch.uint8, device=dev)
@@ -689,12 +694,19 @@ def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_sca
     for (w, h, blocks), o in zip(texs, offs):   # the gaps between textures: zero in all three arenas
         end = o + blocks * B
         nbytes += blocks * B
-        x[end:(end + 255) // 256 * 256].zero_()
+        x[end:(end + align - 1) // align * align].zero_()
     views = [(x[o:o + n * B], y[o:o + n * B], z[o:o + n * B]) for (_, _, n), o in zip(texs, offs)]
     fwd_items = batch.prepare_batch([(fmt, False, xi, yi, st) for xi, yi, _ in views])
     inv_items = batch.prepare_batch([(fmt, True, yi, zi, st) for _, yi, zi in views])
-    f_ms, i_ms, wall = timed_pair(torch, lambda: batch.run_prepared_batch(fwd_items),
-                                  lambda: batch.run_prepared_batch(inv_items), steps, warmup)
+    run_fwd, run_inv = (lambda: batch.run_prepared_batch(fwd_items)), (lambda: batch.run_prepared_batch(inv_items))
+    if os.environ.get("DXTLT_BENCH_CORPUS_BY_SIZE") == "1":
+        # experiment: one batch call per distinct texture size (what a size-class split inside the library would launch)
+        sizes = sorted({n for _, _, n in texs})
+        fw = [batch.prepare_batch([(fmt, False, v[0], v[1], st) for v, t in zip(views, texs) if t[2] == n]) for n in sizes]
+        iv = [batch.prepare_batch([(fmt, True, v[1], v[2], st) for v, t in zip(views, texs) if t[2] == n]) for n in sizes]
+        run_fwd = lambda: [batch.run_prepared_batch(p) for p in fw]
+        run_inv = lambda: [batch.run_prepared_batch(p) for p in iv]
+    f_ms, i_ms, wall = timed_pair(torch, run_fwd, run_inv, steps, warmup)
     order = sorted(range(len(texs)), key=lambda i: texs[i][2])
     ok = True
     mode, sa, sc = int(st.decorrelation_mode), getattr(st, "split_alpha_endpoints", True), st.split_colour_endpoints

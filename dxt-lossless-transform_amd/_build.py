@@ -19,6 +19,8 @@ SOURCES = ["bcn_kernels.hip", "batch_kernels.hip", "dxtlt_api.cpp", "c_api_core.
            "normalize23_api.cpp", "color565_ops.hip", "color565_api.cpp", "bcn_decode.hip", "decode_api.cpp",
            "auto_kernels.hip", "numa_affinity.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-command-line-argument"]
+# A/B experiments (tools/ab_build_rev.sh): extra compiler flags for a side build, never set for the shipped library
+FLAGS += os.environ.get("DXTLT_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -34,9 +34,6 @@ struct BatchView {
     uint64_t gbase[6];
 };
 
-typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
-typedef __attribute__((address_space(1))) uint8_t* global_ptr;
-
 __device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
 {
     const uint64_t* q = reinterpret_cast<const uint64_t*>(entry);
@@ -55,6 +52,17 @@ __device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
     for (int i = 0; i < 6; ++i)
         v.gbase[i] = q[6 + i];
     return v;
+}
+__device__ __forceinline__ void pin_batch_view(BatchView& v)
+{
+    uint64_t s = reinterpret_cast<uintptr_t>(v.src), d = reinterpret_cast<uintptr_t>(v.dst);
+    asm("" : "+s"(s), "+s"(d), "+s"(v.blocks));
+    v.src = (const uint8_t*)(global_cptr)s;
+    v.dst = (uint8_t*)(global_ptr)d;
+    asm("" : "+s"(v.first_wg), "+s"(v.end_wg), "+s"(v.full_tiles), "+s"(v.flags), "+s"(v.shifts[0]), "+s"(v.shifts[1]));
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        asm("" : "+s"(v.gbase[i]));
 }
 static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, full_tiles) == 32 && offsetof(BatchEntry, form) == 36 &&
                   offsetof(BatchEntry, shift) == 40 && offsetof(BatchEntry, gbase) == 48,
@@ -80,13 +88,19 @@ struct StridedBatch {
 
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
 __global__ void __launch_bounds__(256)
-batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict__ coarse, uint32_t uniform_wgs, uint32_t magic,
+batch_kernel(const BatchEntry* __restrict__ entries_arg, const BatchIndex* __restrict__ index_arg, uint32_t uniform_wgs, uint32_t magic,
              StridedBatch strided)
 {
     constexpr int kLds = INVERSE ? kShiftLdsBytes : halo_lds_bytes<FMT>();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
     const uint32_t wg = blockIdx.x;
     BatchView en;
+    // both table pointers in the FIRST scalar round trip (the compiler otherwise fetches `index` on the path that uses it, behind
+    // the first wait); through integers: see fetched_now
+    uint64_t entries_at = reinterpret_cast<uintptr_t>(entries_arg), index_at = reinterpret_cast<uintptr_t>(index_arg);
+    asm("" : "+s"(entries_at), "+s"(index_at), "+s"(uniform_wgs), "+s"(magic));
+    const BatchEntry* entries = (const BatchEntry*)(const __attribute__((address_space(1))) BatchEntry*)entries_at;
+    const BatchIndex* index = (const BatchIndex*)(const __attribute__((address_space(1))) BatchIndex*)index_at;
     if (uniform_wgs != 0) {
         uint32_t e = __umulhi(wg, magic);
         if ((e + 1) * uniform_wgs <= wg)
@@ -110,12 +124,19 @@ batch_kernel(const BatchEntry* __restrict__ entries, const uint32_t* __restrict_
             en = load_batch_entry(entries + e);
         }
     } else {
-        // coarse[wg / 64] = the entry that owns workgroup 64 * (wg / 64); entries own at least one workgroup each and carry
-        // their own end, so a workgroup of a buffer with 64 workgroups or more is two dependent scalar loads away from its
-        // tile's load (with buffers of a few hundred workgroups every one of these loads misses the scalar cache: a CU sees
-        // about one workgroup per buffer)
-        uint32_t e = coarse[wg >> 6];
+        // index[wg / 64] = the entry that owns workgroup 64 * (wg / 64); an entry carries its own end, so a workgroup of a buffer
+        // of 64 workgroups or more is two dependent table loads away from its tile (three scalar round trips with the kernel
+        // arguments).  What was measured on the way here (profiles/r04_batch_edge_tiles.txt; one 2 GiB odd-count buffer or the
+        // corpus, forward): no table load 0.80, ONE load of an entry that thousands of workgroups share 0.80 -- a scalar-cache
+        // hit costs next to nothing -- but an index record that every workgroup of a CU sees for the first time 0.72-0.76
+        // whatever it saves in round trips (a 144-byte record per 256 workgroups with the entry inline: 0.72; a 16-byte bit
+        // mask per 64: 0.76).  So the index is as small as it can be -- 4 bytes per 64 workgroups, a cache line per 1024 -- and
+        // the entry, shared by all workgroups of its buffer, is what is fetched behind it.
+        uint32_t e = index[wg >> 6];
         en = load_batch_entry(entries + e);
+        // every field is needed HERE (empty non-volatile asm: the value becomes opaque, memory is untouched, the loads stay
+        // scalar): left alone the compiler fetches end_wg, runs the loop and only then asks for the rest of the entry
+        pin_batch_view(en);
         while (en.end_wg <= wg) {   // only buffers of fewer than 64 workgroups take this
             ++e;
             en = load_batch_entry(entries + e);
@@ -204,9 +225,21 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
     return wgs;
 }
 
+void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, BatchIndex* index)
+{
+    const size_t n = ((size_t)total_wgs + kBatchIndexWgs - 1) / kBatchIndexWgs;
+    size_t cur = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t wg = (uint32_t)(k * kBatchIndexWgs);
+        while (cur + 1 < n_entries && entries[cur].end_wg <= wg)
+            ++cur;
+        index[k] = (BatchIndex)cur;
+    }
+}
+
 namespace {
 
-using BatchFn = void (*)(const BatchEntry*, const uint32_t*, uint32_t, uint32_t, StridedBatch);
+using BatchFn = void (*)(const BatchEntry*, const BatchIndex*, uint32_t, uint32_t, StridedBatch);
 
 template <int FMT, int VARIANT, bool SA, bool SC>
 BatchFn batch_fn(bool inverse) { return inverse ? batch_kernel<FMT, VARIANT, SA, SC, true> : batch_kernel<FMT, VARIANT, SA, SC, false>; }
@@ -234,7 +267,7 @@ BatchFn batch_variant(int variant, bool sa, bool sc, bool inverse)
 
 }  // namespace
 
-hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint32_t* d_coarse,
+hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const BatchIndex* d_index,
                         uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
                         const BatchEntry* strided_first, int64_t src_stride, int64_t dst_stride)
 {
@@ -269,7 +302,7 @@ hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const Batch
     case kBc3: k = batch_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_coarse, uniform_wgs, magic, strided);
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_index, uniform_wgs, magic, strided);
     return hipGetLastError();
 }
 

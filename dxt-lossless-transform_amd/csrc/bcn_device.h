@@ -347,6 +347,43 @@ __host__ __device__ inline void fill_gbase(Shifts& sh, const STREAMS& S, uint64_
         sh.gbase[i] = i < S.n ? (uint64_t)S.off[i] * total_blocks + (uint64_t)S.width[i] * first_block - (uint64_t)sh.d[i] : 0;
 }
 
+// A copy of the kernel's Shifts argument whose every field is needed HERE (an empty, non-volatile asm makes each value opaque
+// at this point), so that all of them leave the kernel-argument segment in ONE scalar round trip at the top of the kernel.
+// Left alone the compiler fetches an argument in the block that first uses it: the arguments of the first branch first, the
+// whole tile's own -- tile order, store policy, bases -- behind a second and third wait: dependent round trips in front of the
+// tile's load.  The batch kernel, whose regular-array path happens to fetch everything at once, ran a buffer as its only entry
+// at 0.80 where the single call ran it at 0.77 (tools/batch_vs_single_probe.py, profiles/r04_batch_edge_tiles.txt).
+typedef const __attribute__((address_space(1))) uint8_t* global_cptr;
+typedef __attribute__((address_space(1))) uint8_t* global_ptr;
+
+// the same for a pointer argument (through an integer: a pointer that went through an asm would come back as a generic one,
+// and every access of the tile would become a flat_* instruction)
+__device__ __forceinline__ const uint8_t* fetched_now(const uint8_t* p)
+{
+    uint64_t v = reinterpret_cast<uintptr_t>(p);
+    asm("" : "+s"(v));
+    return (const uint8_t*)(global_cptr)v;
+}
+__device__ __forceinline__ uint8_t* fetched_now(uint8_t* p)
+{
+    uint64_t v = reinterpret_cast<uintptr_t>(p);
+    asm("" : "+s"(v));
+    return (uint8_t*)(global_ptr)v;
+}
+
+__device__ __forceinline__ Shifts shifts_fetched_at_once(const Shifts& in)
+{
+    Shifts s = in;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        asm("" : "+s"(s.d[i]));
+        asm("" : "+s"(s.gbase[i]));
+    }
+    asm("" : "+s"(s.xcd_remap), "+s"(s.line_policy), "+s"(s.skip_partial), "+s"(s.natural), "+s"(s.halo_vecs), "+s"(s.full_tiles));
+    asm("" : "+s"(s.range_blocks));
+    return s;
+}
+
 // element width of a stream: its bytes per block, except the 6-byte alpha index records, which move as three halfwords
 __host__ __device__ constexpr int stream_element_width(int bytes_per_block) { return bytes_per_block == 6 ? 2 : bytes_per_block; }
 
@@ -886,8 +923,59 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
 // bytes [lo, hi) of a 16-byte segment, one at a time (a few lanes per stream and range)
 __device__ __forceinline__ void copy_segment_bytes(uint8_t* dst, const uint8_t* src, int lo, int hi)
 {
+#pragma clang loop vectorize(disable) unroll(disable)
     for (int p = lo; p < hi; ++p)
         dst[p] = src[p];
+}
+
+// The window segment a lane looks after, selected by data (no control flow: the memory instructions that follow are then one
+// per lane for the whole workgroup, issued together -- a first version branched per stream and ran a stream's load, wait and
+// LDS store after the other: 9-18 us per edge tile against the 2.5 us of a whole one).
+struct EdgeSlot {
+    int wo;        // byte offset of the segment in its stream's window
+    int width;     // bytes per block of the stream
+    int d;         // the stream's shift
+    int lds_base;  // LDS address of window byte 0
+    uint64_t g;    // offset from the transformed-side pointer of window byte 0 (may wrap)
+};
+
+// LDS address of window byte 0 of stream s: off_s * LA + LB * s + w_s * LC (halo image: T + H, kHaloPad, H; shifted image: T, 16, 0)
+template <int FMT, bool SA, bool SC, int T, int LA, int LB, int LC>
+__device__ __forceinline__ EdgeSlot edge_slot_of_image_byte(int o, const Shifts& sh, const uint64_t (&gb)[6])
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    EdgeSlot e{0, 1, 0, 0, 0};
+    static_for<0, S.n>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int lo = S.off[s] * T, hi = lo + S.width[s] * T;
+        if (o >= lo && o < hi) {
+            e.wo = o - lo;
+            e.width = S.width[s];
+            e.d = sh.d[s];
+            e.lds_base = S.off[s] * LA + LB * s + S.width[s] * LC;
+            e.g = gb[s];
+        }
+    });
+    return e;
+}
+
+// the k-th extra segment behind stream s_sel's window
+template <int FMT, bool SA, bool SC, int T, int LA, int LB, int LC>
+__device__ __forceinline__ EdgeSlot edge_slot_behind_window(int s_sel, int k, const Shifts& sh, const uint64_t (&gb)[6])
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    EdgeSlot e{0, 1, 0, 0, 0};
+    static_for<0, S.n>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        if (s == s_sel) {
+            e.wo = S.width[s] * T + 16 * k;
+            e.width = S.width[s];
+            e.d = sh.d[s];
+            e.lds_base = S.off[s] * LA + LB * s + S.width[s] * LC;
+            e.g = gb[s];
+        }
+    });
+    return e;
 }
 
 // The forward edge tile: halo tile `tile` of a range of sh.range_blocks blocks, of which it owns min(T, what is left) -- none
@@ -913,82 +1001,64 @@ __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ a
     const int own = left < (uint64_t)T ? (int)left : T;
     const uint8_t* tile_aos = aos + tile * 4096;
     const int hv = sh.halo_vecs;
-    if (tile > 0 && t < hv) {
-        const u32x4 qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
-        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
-    }
-    if ((t + 1) * PV <= own) {
-        const u32x4 q = *reinterpret_cast<const u32x4*>(tile_aos + t * 16);
-        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
-    } else if (PV == 2 && t * PV < own) {
-        // BC1, odd count: the vector's second block does not exist (its 8 bytes may lie outside the caller's buffer)
+    const bool has_halo = tile > 0 && t < hv;
+    const bool whole_vec = (t + 1) * PV <= own;
+    const bool half_vec = PV == 2 && !whole_vec && t * PV < own;   // BC1, odd count: the vector's second block does not exist
+    u32x4 q = {0u, 0u, 0u, 0u}, qh = {0u, 0u, 0u, 0u};
+    if (whole_vec)
+        q = *reinterpret_cast<const u32x4*>(tile_aos + t * 16);
+    if (half_vec) {   // (its 8 bytes may lie outside the caller's buffer)
         const u32x2 h = *reinterpret_cast<const u32x2*>(tile_aos + t * 16);
-        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(u32x4{h.x, h.y, 0u, 0u}), base);
+        q = u32x4{h.x, h.y, 0u, 0u};
     }
+    if (has_halo)
+        qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
+    if (has_halo)
+        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
+    if (whole_vec || half_vec)
+        scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
     __syncthreads();
 
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    // slot: one 16-byte segment of a stream's window; wo = its byte offset in the window
-    auto store_slot = [&](int s_sel, int wo) {
-        static_for<0, S.n>([&](auto si) {
-            constexpr int s = decltype(si)::value;
-            if (s == s_sel) {
-                const int vlo = tile == 0 ? sh.d[s] : 0;
-                const int vhi = own == T ? S.width[s] * T : sh.d[s] + S.width[s] * own;
-                const int lo = vlo - wo > 0 ? vlo - wo : 0;
-                const int hi = vhi - wo < 16 ? vhi - wo : 16;
-                if (hi > lo) {
-                    uint8_t* la = lds + S.off[s] * (T + H) + kHaloPad * s + S.width[s] * H + wo;
-                    uint8_t* g = soa + gb[s] + (uint64_t)(int64_t)wo;
-                    if (lo == 0 && hi == 16)
-                        __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(la), reinterpret_cast<u32x4*>(g));
-                    else
-                        copy_segment_bytes(g, la, lo, hi);
-                }
-            }
-        });
+    auto store_slot = [&](const EdgeSlot& e) {
+        // the stream's bytes of the range, in window coordinates: from d_s on in tile 0 (nothing in front of the range is
+        // ours), up to the end of the window when another tile follows, else to the stream's last byte
+        const int vlo = tile == 0 ? e.d : 0;
+        const int vhi = own == T ? e.width * T : e.d + e.width * own;
+        const int lo = vlo - e.wo > 0 ? vlo - e.wo : 0;
+        const int hi = vhi - e.wo < 16 ? vhi - e.wo : 16;
+        if (hi > lo) {
+            uint8_t* la = lds + e.lds_base + e.wo;
+            uint8_t* g = soa + e.g + (uint64_t)(int64_t)e.wo;
+            if (lo == 0 && hi == 16)
+                __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(la), reinterpret_cast<u32x4*>(g));
+            else
+                copy_segment_bytes(g, la, lo, hi);
+        }
     };
-    {
-        const int o = t * 16;
-        int s_sel = 0, wo = 0;
-        static_for<0, S.n>([&](auto si) {
-            constexpr int s = decltype(si)::value;
-            constexpr int lo = S.off[s] * T, hi = lo + S.width[s] * T;
-            if (o >= lo && o < hi) {
-                s_sel = s;
-                wo = o - lo;
-            }
-        });
-        store_slot(s_sel, wo);
-    }
-    if (t < 4 * S.n) {
-        int wo = 0;
-        static_for<0, S.n>([&](auto si) {
-            constexpr int s = decltype(si)::value;
-            if (s == (t >> 2))
-                wo = S.width[s] * T + 16 * (t & 3);
-        });
-        store_slot(t >> 2, wo);
-    }
+    store_slot(edge_slot_of_image_byte<FMT, SA, SC, T, T + H, kHaloPad, H>(t * 16, sh, gb));
+    if (t < 4 * S.n)   // up to 63 bytes of a stream lie behind its window
+        store_slot(edge_slot_behind_window<FMT, SA, SC, T, T + H, kHaloPad, H>(t >> 2, t & 3, sh, gb));
 }
 
 // Workgroups [0, sh.full_tiles) are whole tiles (tile 0 through the edge body: it has a head to write); a workgroup behind
 // them, when the launch has one, is the edge tile at the end of the range.
 template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
 __global__ void __launch_bounds__(256)
-fwd_tiled_halo(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t total_blocks, uint64_t first_block,
-               Shifts sh)
+fwd_tiled_halo(const uint8_t* __restrict__ aos_arg, uint8_t* __restrict__ soa_arg, uint64_t total_blocks, uint64_t first_block,
+               Shifts sh_arg)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
     const uint32_t wg = blockIdx.x;
-    if (wg >= sh.full_tiles) {
-        fwd_halo_edge_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, sh, sh.full_tiles, lds);
-        return;
-    }
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
-    if (tile == 0)
-        fwd_halo_edge_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, sh, 0, lds);
+    const Shifts sh = shifts_fetched_at_once(sh_arg);
+    const uint8_t* __restrict__ aos = fetched_now(aos_arg);
+    uint8_t* __restrict__ soa = fetched_now(soa_arg);
+    const bool whole = wg < sh.full_tiles;
+    const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : sh.xcd_remap ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
+    const bool edge = !whole || tile == 0;
+    if (edge)
+        fwd_halo_edge_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, sh, tile, lds);
     else
         fwd_halo_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
@@ -1030,13 +1100,15 @@ __device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ 
     });
     // g is an offset from soa; a head segment of stream 0 may start before the buffer (wraps to a huge value)
     const bool main_inside = g + 16 <= total_bytes;
-    u32x4 v_main = {0, 0, 0, 0};
-    if (main_inside)
-        v_main = gload16(soa + g);
+    // Everything both loads need is computed first and both destinations are cleared before the first load is issued: with
+    // the clearing of v_tail between the two loads the compiler (28 VGPRs instead of 48 once the kernel around this tile got
+    // smaller) put an s_waitcnt vmcnt(0) between them -- wave 0 of every workgroup then waited out a whole memory round
+    // trip before asking for its tail segments: BC3 inverse on odd counts 0.77 -> 0.70 (profiles/r04_batch_edge_tiles.txt).
+    int la_t = 0, shift_t = 0;
+    uint64_t g_t = 0;
+    bool has_tail = false, tail_inside = false;
     if constexpr (W == 0) {
         // the extra, partial last segment of stream t (lanes 0..n-1), selected by data, not by control flow
-        int la_t = 0, shift_t = 0;
-        uint64_t g_t = 0;
 #pragma unroll
         for (int ss = 0; ss < S.n; ++ss) {
             if (ss == t) {
@@ -1046,11 +1118,16 @@ __device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ 
                 g_t = gb[ss] + bytes;
             }
         }
-        const bool has_tail = t < S.n && shift_t > 0;
-        const bool tail_inside = g_t + 16 <= total_bytes;
+        has_tail = t < S.n && shift_t > 0;
+        tail_inside = g_t + 16 <= total_bytes;
+    }
+    u32x4 v_main = {0, 0, 0, 0}, v_tail = {0, 0, 0, 0};
+    asm volatile("" : "+v"(v_main), "+v"(v_tail));   // both cleared here, not between the loads
+    if (main_inside)
+        v_main = gload16(soa + g);
+    if constexpr (W == 0) {
         // (Making these two loads branch-free -- every lane also loading a "tail", lanes without one re-reading their main
         // segment -- cost 0.08 of peak: the second load instruction is not free even when it hits L1.)
-        u32x4 v_tail = {0, 0, 0, 0};
         if (has_tail && tail_inside)
             v_tail = gload16(soa + g_t);
         if (has_tail) {
@@ -1115,45 +1192,40 @@ __device__ __forceinline__ void inv_shift_edge_tile(const uint8_t* __restrict__ 
     const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    auto load_slot = [&](int s_sel, int wo) {
-        static_for<0, S.n>([&](auto si) {
-            constexpr int s = decltype(si)::value;
-            if (s == s_sel) {
-                const int vhi = sh.d[s] + S.width[s] * own;
-                const int lo = sh.d[s] - wo > 0 ? sh.d[s] - wo : 0;
-                const int hi = vhi - wo < 16 ? vhi - wo : 16;
-                if (hi > lo) {
-                    uint8_t* la = lds + S.off[s] * T + 16 * s + wo;
-                    const uint64_t g = gb[s] + (uint64_t)(int64_t)wo;      // wraps for a head segment in front of the buffer
-                    if (g + 16 <= total_bytes)
-                        *reinterpret_cast<u32x4*>(la) = *reinterpret_cast<const u32x4*>(soa + g);
-                    else
-                        copy_segment_bytes(la, soa + g, lo, hi);
-                }
-            }
-        });
+    // which bytes of a segment belong to the records of this tile's blocks, and whether the segment can be fetched whole
+    auto plan = [&](const EdgeSlot& e, int& lo, int& hi, bool& whole) {
+        const int vhi = e.d + e.width * own;
+        lo = e.d - e.wo > 0 ? e.d - e.wo : 0;
+        hi = vhi - e.wo < 16 ? vhi - e.wo : 16;
+        const uint64_t g = e.g + (uint64_t)(int64_t)e.wo;   // wraps for a head segment in front of the buffer
+        whole = total_bytes >= 16 && g <= total_bytes - 16;
     };
-    {
-        const int o = t * 16;
-        int s_sel = 0, wo = 0;
-        static_for<0, S.n>([&](auto si) {
-            constexpr int s = decltype(si)::value;
-            constexpr int lo = S.off[s] * T, hi = lo + S.width[s] * T;
-            if (o >= lo && o < hi) {
-                s_sel = s;
-                wo = o - lo;
-            }
-        });
-        load_slot(s_sel, wo);
+    const EdgeSlot em = edge_slot_of_image_byte<FMT, SA, SC, T, T, 16, 0>(t * 16, sh, gb);
+    // the extra segment behind stream t's slice (a slice shifted by d_s reaches up to 15 bytes into it)
+    const EdgeSlot ex = edge_slot_behind_window<FMT, SA, SC, T, T, 16, 0>(t, 0, sh, gb);
+    int mlo, mhi, xlo = 0, xhi = 0;
+    bool mwhole, xwhole = false;
+    plan(em, mlo, mhi, mwhole);
+    if (t < S.n)
+        plan(ex, xlo, xhi, xwhole);
+    const uint8_t* gm = soa + em.g + (uint64_t)(int64_t)em.wo;
+    const uint8_t* gx = soa + ex.g + (uint64_t)(int64_t)ex.wo;
+    u32x4 vm = {0u, 0u, 0u, 0u}, vx = {0u, 0u, 0u, 0u};
+    if (mhi > mlo && mwhole)
+        vm = *reinterpret_cast<const u32x4*>(gm);
+    if (xhi > xlo && xwhole)
+        vx = *reinterpret_cast<const u32x4*>(gx);
+    if (mhi > mlo) {
+        if (mwhole)
+            *reinterpret_cast<u32x4*>(lds + em.lds_base + em.wo) = vm;
+        else
+            copy_segment_bytes(lds + em.lds_base + em.wo, gm, mlo, mhi);
     }
-    if (t < S.n) {   // the extra segment behind stream t's slice (a slice shifted by d_s reaches up to 15 bytes into it)
-        int wo = 0;
-        static_for<0, S.n>([&](auto si) {
-            constexpr int s = decltype(si)::value;
-            if (s == t)
-                wo = S.width[s] * T;
-        });
-        load_slot(t, wo);
+    if (xhi > xlo) {
+        if (xwhole)
+            *reinterpret_cast<u32x4*>(lds + ex.lds_base + ex.wo) = vx;
+        else
+            copy_segment_bytes(lds + ex.lds_base + ex.wo, gx, xlo, xhi);
     }
     __syncthreads();
     if (t * PV < own) {
@@ -1170,17 +1242,22 @@ __device__ __forceinline__ void inv_shift_edge_tile(const uint8_t* __restrict__ 
 // Workgroups [0, sh.full_tiles) are whole tiles; a workgroup behind them, when the launch has one, is the edge tile.
 template <int FMT, int VARIANT, bool SA, bool SC>
 __global__ void __launch_bounds__(256)
-inv_tiled_shift(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t total_blocks, uint64_t first_block,
-                Shifts sh)
+inv_tiled_shift(const uint8_t* __restrict__ soa_arg, uint8_t* __restrict__ aos_arg, uint64_t total_blocks, uint64_t first_block,
+                Shifts sh_arg)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
     const uint32_t wg = blockIdx.x;
-    if (wg >= sh.full_tiles) {
-        inv_shift_edge_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, sh, sh.full_tiles, lds);
-        return;
-    }
-    const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
-    inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
+    const Shifts sh = shifts_fetched_at_once(sh_arg);
+    const uint8_t* __restrict__ soa = fetched_now(soa_arg);
+    uint8_t* __restrict__ aos = fetched_now(aos_arg);
+    asm("" : "+s"(total_blocks));
+    const bool whole = wg < sh.full_tiles;
+    const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : sh.xcd_remap ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
+    const bool edge = !whole;
+    if (edge)
+        inv_shift_edge_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, sh, tile, lds);
+    else
+        inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -99,6 +99,11 @@ struct BatchEntry {
 };
 static_assert(sizeof(BatchEntry) == 96, "BatchEntry layout is shared between host and device");
 
+// The workgroup -> entry index of a batch launch: index[k] = the entry that owns workgroup 64 * k (every entry also carries
+// its own end_wg: batch_kernels.hip walks on from there for buffers of fewer than 64 workgroups).
+typedef uint32_t BatchIndex;
+constexpr uint32_t kBatchIndexWgs = 64;
+
 // Fills first_wg-relative planning fields of `e` (src, dst, blocks set by the caller; first_wg too) for settings `s` and
 // returns the number of workgroups the buffer needs (0 for an empty buffer), or 0xFFFFFFFF when the batch kernel cannot take the
 // buffer (a transformed-side pointer whose stream shifts are not multiples of the element widths: the caller launches it alone).
@@ -108,15 +113,18 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
 // with a small kernel on `stream` -- no copy-engine hand-over in front of the batch kernel.
 hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes, hipStream_t stream);
 
-// d_entries / d_coarse: device copies of the entry table and of the coarse index (coarse[k] = index of the entry that
-// owns workgroup 64 * k), total_wgs = end_wg of the last entry.
+// d_entries / d_index: device copies of the entry table and of the workgroup index (build_batch_index), total_wgs = end_wg of
+// the last entry.
 // uniform_wgs: 0, or the number of workgroups EVERY entry owns (first_wg == index * uniform_wgs): the kernel then finds a
 // workgroup's entry by division instead of through the coarse index.
 // strided_first != nullptr (needs uniform_wgs != 0): the batch is a regular array -- every entry equals *strided_first but for
 // its pointers, which advance by src_stride / dst_stride bytes per entry; the kernel then reads no table at all.
-hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint32_t* d_coarse,
+hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const BatchIndex* d_index,
                         uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
                         const BatchEntry* strided_first = nullptr, int64_t src_stride = 0, int64_t dst_stride = 0);
+
+// index[0 .. ceil(total_wgs / kBatchIndexWgs)) from the entries (sorted by first_wg, each owning at least one workgroup, no gaps)
+void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, BatchIndex* index);
 
 // A regular array of aligned buffers as the single-buffer aligned kernel with blockIdx.y = buffer (bcn_kernels.hip);
 // hipErrorNotSupported when the array does not have that shape.
