@@ -818,22 +818,54 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
+// bytes [lo, hi) of a 16-byte segment (both pointers 16-byte aligned at byte 0) as the fewest naturally aligned 1/2/4/8-byte
+// pieces -- at most six.  A first version moved them one byte at a time: fifteen dependent narrow stores into one 64-byte
+// sector cost an edge tile more than all its vector stores together (4096 x (256 KiB - 1 block) BC3 forward: 0.61 with byte
+// loops, 0.67 without them, 0.71 with no edge tiles at all; profiles/r04_batch_edge_tiles.txt).
+__device__ __forceinline__ void copy_segment_bytes(uint8_t* dst, const uint8_t* src, int lo, int hi)
+{
+    int p = lo;
+#pragma clang loop vectorize(disable) unroll(disable)
+    while (p < hi) {
+        const int left = hi - p;
+        if ((p & 7) == 0 && left >= 8) {
+            *reinterpret_cast<u32x2*>(dst + p) = *reinterpret_cast<const u32x2*>(src + p);
+            p += 8;
+        } else if ((p & 3) == 0 && left >= 4) {
+            *reinterpret_cast<uint32_t*>(dst + p) = *reinterpret_cast<const uint32_t*>(src + p);
+            p += 4;
+        } else if ((p & 1) == 0 && left >= 2) {
+            *reinterpret_cast<uint16_t*>(dst + p) = *reinterpret_cast<const uint16_t*>(src + p);
+            p += 2;
+        } else {
+            dst[p] = src[p];
+            p += 1;
+        }
+    }
+}
+
 // Copy-out of wave W of a halo tile: lane t moves image byte 16 t of the tile's windows.  A wave's 1 KiB of the image
 // meets at most three streams (BC3 with split alphas, wave 0) and usually one, and which ones is known at compile time:
 // the per-lane select over the streams -- a third of the first version's vector instructions -- shrinks to the streams
 // the wave can meet.
-template <int FMT, bool SA, bool SC, int W>
-__device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, const uint8_t* lds, int t, bool first_tile,
-                                                   const uint64_t (&gb)[6], const Shifts& sh)
+// EDGE: the tile is the first or the last of its range: vlo[s] .. vhi[s] (window coordinates, uniform) are the bytes of stream
+// s that are this tile's to write.  A segment they cut leaves as a few narrow pieces, a segment outside them not at all, a
+// segment inside them whole -- with a plain nt store: the lines at both ends of an edge tile's windows are completed by other
+// workgroups (the neighbouring tile, the tile at the other end of the buffer where one stream ends and the next begins, a
+// neighbouring buffer's), some of them with narrow stores, and write-through next to that is the collapse round 1 met on shared
+// lines.  Measured on 4096 x (256 KiB - 1 block) BC3, forward: plain nt throughout 0.66; write-through for every sector that is
+// the tile's alone 0.49; write-through except in the line where the stream begins or ends 0.55 (profiles/r04_batch_edge_tiles.txt).
+template <int FMT, bool SA, bool SC, int W, bool EDGE = false>
+__device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, const uint8_t* lds, int t, const uint64_t (&gb)[6],
+                                                   const Shifts& sh, const int (&vlo)[6], const int (&vhi)[6])
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
     constexpr int T = tile_blocks(FMT, 256);
     constexpr int H = kHaloBlocks;
     constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
     const int o = t * 16;
-    int la = 0;
+    int la = 0, wo = 0, lo_s = 0, hi_s = 0;
     uint64_t g = 0;
-    bool skip = false;
     static_for<0, S.n>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int lo = S.off[s] * T;
@@ -843,17 +875,27 @@ __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, co
             if (only || (o >= lo && o < hi)) {
                 la = S.off[s] * (T + H) + kHaloPad * s + S.width[s] * H + (o - lo);
                 g = gb[s] + (uint64_t)(o - lo);
-                // no halo in front of the range: segments that start before the stream's first byte are left to the
-                // element kernel (it writes the records of the range's first 64 blocks)
-                skip = first_tile && (o - lo) < sh.d[s];
+                if constexpr (EDGE) {
+                    wo = o - lo;
+                    lo_s = vlo[s];
+                    hi_s = vhi[s];
+                }
             }
         }
     });
-    if (skip)
+    if constexpr (EDGE) {
+        const int lo = lo_s - wo > 0 ? lo_s - wo : 0;
+        const int hi = hi_s - wo < 16 ? hi_s - wo : 16;
+        if (hi <= lo)
+            return;
+        if (lo != 0 || hi != 16)
+            copy_segment_bytes(soa + g, lds + la, lo, hi);
+        else
+            __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
         return;
-    // line_policy 3 (launch_transform: every window starts on a 128-byte line, so no line is shared between tiles):
-    // write-through streaming stores as in the aligned tiles; otherwise plain nt, which lets L2 merge the two halves
-    // of a shared line
+    }
+    // line_policy 3 (launch_transform: every window starts on a 64-byte sector, so no sector is shared between tiles):
+    // write-through streaming stores as in the aligned tiles; otherwise plain nt, which lets L2 merge the parts of a shared line
     if (sh.line_policy == 3)
         gstore16(soa + g, lds_at<u32x4>(const_cast<uint8_t*>(lds), la));
     else
@@ -901,12 +943,12 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
 
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    const bool first_tile = tile == 0;
+    const int none[6] = {0, 0, 0, 0, 0, 0};   // (tile 0 and the last tile of a range run fwd_halo_edge_tile)
     switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
-    case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, first_tile, gb, sh); break;
-    case 1: halo_copy_out_wave<FMT, SA, SC, 1>(soa, lds, t, first_tile, gb, sh); break;
-    case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, first_tile, gb, sh); break;
-    default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, first_tile, gb, sh); break;
+    case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, none, none); break;
+    case 1: halo_copy_out_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, none, none); break;
+    case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, none, none); break;
+    default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, none, none); break;
     }
 }
 
@@ -921,17 +963,11 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
 // profiles/r03_batch_spacing.txt).  Here every full segment of an edge still moves as one 16-byte vector.
 // ------------------------------------------------------------------------------------------------
 // bytes [lo, hi) of a 16-byte segment, one at a time (a few lanes per stream and range)
-__device__ __forceinline__ void copy_segment_bytes(uint8_t* dst, const uint8_t* src, int lo, int hi)
-{
-#pragma clang loop vectorize(disable) unroll(disable)
-    for (int p = lo; p < hi; ++p)
-        dst[p] = src[p];
-}
-
 // The window segment a lane looks after, selected by data (no control flow: the memory instructions that follow are then one
 // per lane for the whole workgroup, issued together -- a first version branched per stream and ran a stream's load, wait and
 // LDS store after the other: 9-18 us per edge tile against the 2.5 us of a whole one).
 struct EdgeSlot {
+    int s;         // stream
     int wo;        // byte offset of the segment in its stream's window
     int width;     // bytes per block of the stream
     int d;         // the stream's shift
@@ -944,11 +980,12 @@ template <int FMT, bool SA, bool SC, int T, int LA, int LB, int LC>
 __device__ __forceinline__ EdgeSlot edge_slot_of_image_byte(int o, const Shifts& sh, const uint64_t (&gb)[6])
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    EdgeSlot e{0, 1, 0, 0, 0};
+    EdgeSlot e{0, 0, 1, 0, 0, 0};
     static_for<0, S.n>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int lo = S.off[s] * T, hi = lo + S.width[s] * T;
         if (o >= lo && o < hi) {
+            e.s = s;
             e.wo = o - lo;
             e.width = S.width[s];
             e.d = sh.d[s];
@@ -964,10 +1001,11 @@ template <int FMT, bool SA, bool SC, int T, int LA, int LB, int LC>
 __device__ __forceinline__ EdgeSlot edge_slot_behind_window(int s_sel, int k, const Shifts& sh, const uint64_t (&gb)[6])
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    EdgeSlot e{0, 1, 0, 0, 0};
+    EdgeSlot e{0, 0, 1, 0, 0, 0};
     static_for<0, S.n>([&](auto si) {
         constexpr int s = decltype(si)::value;
         if (s == s_sel) {
+            e.s = s;
             e.wo = S.width[s] * T + 16 * k;
             e.width = S.width[s];
             e.d = sh.d[s];
@@ -1021,25 +1059,37 @@ __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ a
 
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    auto store_slot = [&](const EdgeSlot& e) {
-        // the stream's bytes of the range, in window coordinates: from d_s on in tile 0 (nothing in front of the range is
-        // ours), up to the end of the window when another tile follows, else to the stream's last byte
-        const int vlo = tile == 0 ? e.d : 0;
-        const int vhi = own == T ? e.width * T : e.d + e.width * own;
-        const int lo = vlo - e.wo > 0 ? vlo - e.wo : 0;
-        const int hi = vhi - e.wo < 16 ? vhi - e.wo : 16;
-        if (hi > lo) {
+    // the stream's bytes of the range that are this tile's, in window coordinates: from d_s on in tile 0 (nothing in front of the
+    // range is ours), up to the end of the window when another tile follows, else to the stream's last byte
+    int vlo[6], vhi[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int d = s < S.n ? sh.d[s] : 0, w = s < S.n ? S.width[s] : 0;
+        vlo[s] = tile == 0 ? d : 0;
+        vhi[s] = own == T ? w * T : d + w * own;
+    }
+    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+    case 0: halo_copy_out_wave<FMT, SA, SC, 0, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+    case 1: halo_copy_out_wave<FMT, SA, SC, 1, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+    case 2: halo_copy_out_wave<FMT, SA, SC, 2, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+    default: halo_copy_out_wave<FMT, SA, SC, 3, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+    }
+    if (t < 4 * S.n) {   // up to 63 bytes of a stream lie behind its window: four more segments per stream
+        const EdgeSlot e = edge_slot_behind_window<FMT, SA, SC, T, T + H, kHaloPad, H>(t >> 2, t & 3, sh, gb);
+        int hi_s = 0;
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            hi_s = s == e.s ? vhi[s] : hi_s;
+        const int hi = hi_s - e.wo < 16 ? hi_s - e.wo : 16;
+        if (hi > 0) {
             uint8_t* la = lds + e.lds_base + e.wo;
             uint8_t* g = soa + e.g + (uint64_t)(int64_t)e.wo;
-            if (lo == 0 && hi == 16)
-                __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(la), reinterpret_cast<u32x4*>(g));
+            if (hi != 16)
+                copy_segment_bytes(g, la, 0, hi);
             else
-                copy_segment_bytes(g, la, lo, hi);
+                __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(la), reinterpret_cast<u32x4*>(g));
         }
-    };
-    store_slot(edge_slot_of_image_byte<FMT, SA, SC, T, T + H, kHaloPad, H>(t * 16, sh, gb));
-    if (t < 4 * S.n)   // up to 63 bytes of a stream lie behind its window
-        store_slot(edge_slot_behind_window<FMT, SA, SC, T, T + H, kHaloPad, H>(t >> 2, t & 3, sh, gb));
+    }
 }
 
 // Workgroups [0, sh.full_tiles) are whole tiles (tile 0 through the edge body: it has a head to write); a workgroup behind
