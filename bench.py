@@ -1021,6 +1021,44 @@ def archive_main(args) -> None:
     R.finish()
 
 
+def pcie_pair_ceiling(torch, dev, nbytes: int = 1 << 30, reps: int = 3) -> dict:
+    """The ceiling of the host path, measured in this run: ONE pinned host -> device copy and ONE pinned device -> host copy
+    of `nbytes` each, concurrently on two streams of `dev` -- what the link gives a caller whose buffers are already
+    pinned, with no kernel and no placement in the way.  GiB/s per direction (both directions are busy at once)."""
+    h_up = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    h_down = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    h_up.zero_()
+    h_down.zero_()
+    d_up = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d_down = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    best = {"pair": None, "up": None, "down": None}
+
+    def run(up: bool, down: bool) -> float:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if up:
+            with torch.cuda.stream(s1):
+                d_up.copy_(h_up, non_blocking=True)
+        if down:
+            with torch.cuda.stream(s2):
+                h_down.copy_(d_down, non_blocking=True)
+        s1.synchronize()
+        s2.synchronize()
+        return time.perf_counter() - t0
+
+    run(True, True)
+    for _ in range(reps):
+        for key, (u, d) in (("pair", (True, True)), ("up", (True, False)), ("down", (False, True))):
+            dt = run(u, d)
+            best[key] = dt if best[key] is None else min(best[key], dt)
+    del h_up, h_down, d_up, d_down
+    return {"bytes_each_way": nbytes,
+            "concurrent_GiBps_per_direction": round(nbytes / best["pair"] / 2**30, 2),
+            "h2d_alone_GiBps": round(nbytes / best["up"] / 2**30, 2), "d2h_alone_GiBps": round(nbytes / best["down"] / 2**30, 2),
+            "what": "one pinned H2D and one pinned D2H hipMemcpyAsync of 1 GiB each on two streams of the same device, best of 3"}
+
+
 def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, want_devices: int) -> dict:
     """north_star's multi-GPU statement as ONE call: a host-resident block array is split by contiguous block range over
     every visible device and each shard's slice of every stream lands at its final host offset (dxtlt_transform_sharded;
@@ -1114,7 +1152,18 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
             got[off * win: off * win + w * win] = a_soa[off * blocks + w * first: off * blocks + w * (first + win)]
         ok = ok and bool(np.array_equal(got, want))
     assert ok, "sharded host array: result differs from the oracle / round trip failed"
+    # the link's own ceiling, same run, same device: a sharded call moves every byte up and every byte down, both directions busy
+    try:
+        ceiling = pcie_pair_ceiling(torch, dev, min(1 << 30, max(nbytes, 1 << 20)))
+        peak = ceiling["concurrent_GiBps_per_direction"]
+        for row in per_device:
+            row["roofline"] = {"bound": "pcie", "unit": "GiB/s per direction", "peak": peak,
+                               "achieved": row["fwd_GiBps"], "frac": round(row["fwd_GiBps"] / peak, 4),
+                               "inverse": {"achieved": row["inv_GiBps"], "frac": round(row["inv_GiBps"] / peak, 4)}}
+    except Exception as e:  # noqa: BLE001
+        ceiling = {"error": f"{type(e).__name__}: {e}"}
     return {
+        "pcie_ceiling": ceiling,
         "entry_point": "dxtlt_transform_sharded (one process, one host thread per device, chunked H2D | kernel | per-stream D2H)",
         "array_bytes": nbytes, "devices": n_dev, "host_memory": "pinned" if pinned else "pageable",
         "fwd_GiBps": round(nbytes / fwd_s / 2**30, 2), "inv_GiBps": round(nbytes / inv_s / 2**30, 2),

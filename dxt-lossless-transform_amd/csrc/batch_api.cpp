@@ -519,6 +519,11 @@ extern "C" int32_t dxtlt_transform_batch_host(const DxtltBatchItem* items, size_
     auto packer = [&](int tid) {
         hipError_t e = hipSetDevice(dev);
         for (int c = 0; c < nchunks && e == hipSuccess; ++c) {
+            if (c < 2) {   // (chunks 0 and 1 wait for nothing -- but not for a call that is already being abandoned)
+                std::lock_guard<std::mutex> lk(sh.m);
+                if (sh.failed)
+                    return;
+            }
             if (c >= 2) {
                 // arena c % 2 is free once chunk c - 2 has left it
                 {

@@ -161,6 +161,7 @@ int32_t sharded(bool inverse, const uint8_t* in, uint8_t* out, size_t len, int32
     std::vector<std::string> msgs((size_t)shards);
     std::vector<std::thread> threads;
     bool spawn_failed = false;
+    dxtlt_host::init_runtime_for_devices(shards < count ? shards : count);   // on the caller's thread, before any worker binds itself
     for (int s = 0; s < shards && !spawn_failed; ++s) {
         try {
             threads.emplace_back([&, s] {
@@ -175,9 +176,10 @@ int32_t sharded(bool inverse, const uint8_t* in, uint8_t* out, size_t len, int32
     }
     for (auto& t : threads)
         t.join();
+    dxtlt_host::trim_idle_shard_buffers();
     (void)hipSetDevice(prev);
     if (spawn_failed)
-        return fail(kDevice, "could not start a shard worker thread");
+        return fail(kAllocation, "could not start a shard worker thread");   // a host resource ran out, as in every other spawn path
     for (int s = 0; s < shards; ++s)
         if (codes[(size_t)s] != kOk)
             return fail(codes[(size_t)s], msgs[(size_t)s].c_str());

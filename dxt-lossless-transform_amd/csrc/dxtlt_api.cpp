@@ -614,30 +614,48 @@ ShardCtx* shard_ctx_acquire(int dev, size_t bytes, hipError_t* err)
 // dxtlt_release_thread_resources().  Retained memory per device is thus bounded by 2 buffers x the largest shard x 2.
 constexpr int kIdleShardCtxPerDevice = 2;
 
+// Handing a context back only marks it idle: hipFree synchronises the whole device, so nothing is freed on a shard's
+// completion path while other shards of the call are still moving data.  The surplus is trimmed by the call itself, after
+// its workers have joined (shard_pool_trim).
 void shard_ctx_release(ShardCtx* c)
+{
+    std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
+    c->busy = false;
+}
+
+void shard_pool_trim()
 {
     std::vector<ShardCtx*> drop;
     {
         std::lock_guard<std::mutex> lk(g_shard_pool_mutex);
-        c->busy = false;
         std::vector<ShardCtx*> idle;
         for (ShardCtx* x : g_shard_pool)
-            if (!x->busy && x->dev == c->dev)
+            if (!x->busy)
                 idle.push_back(x);
-        if ((int)idle.size() > kIdleShardCtxPerDevice) {
-            std::sort(idle.begin(), idle.end(), [](const ShardCtx* l, const ShardCtx* r) { return l->cap > r->cap; });
-            drop.assign(idle.begin() + kIdleShardCtxPerDevice, idle.end());
-            for (ShardCtx* x : drop)
-                g_shard_pool.erase(std::find(g_shard_pool.begin(), g_shard_pool.end(), x));
+        // per device: keep the kIdleShardCtxPerDevice largest idle contexts
+        std::sort(idle.begin(), idle.end(), [](const ShardCtx* l, const ShardCtx* r) { return l->dev != r->dev ? l->dev < r->dev : l->cap > r->cap; });
+        int run = 0;
+        for (size_t i = 0; i < idle.size(); ++i) {
+            run = (i > 0 && idle[i]->dev == idle[i - 1]->dev) ? run + 1 : 0;
+            if (run >= kIdleShardCtxPerDevice)
+                drop.push_back(idle[i]);
         }
+        for (ShardCtx* x : drop)
+            g_shard_pool.erase(std::find(g_shard_pool.begin(), g_shard_pool.end(), x));
     }
-    // the calling shard thread has c->dev current and has drained its stream; the dropped contexts are idle ones of that device
+    if (drop.empty())
+        return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
     for (ShardCtx* x : drop) {
-        if (x->a) (void)hipFree(x->a);
-        if (x->b) (void)hipFree(x->b);
-        if (x->st) (void)hipStreamDestroy(x->st);
+        if (hipSetDevice(x->dev) == hipSuccess) {
+            if (x->a) (void)hipFree(x->a);
+            if (x->b) (void)hipFree(x->b);
+            if (x->st) (void)hipStreamDestroy(x->st);
+        }
         delete x;
     }
+    (void)hipSetDevice(prev);
 }
 
 void shard_pool_clear()
@@ -737,6 +755,16 @@ int32_t dxtlt_host::acquire_shard_buffers(int dev, size_t bytes, ShardBuffers* o
 }
 
 void dxtlt_host::release_shard_buffers(const ShardBuffers& sb) { shard_ctx_release(static_cast<ShardCtx*>(sb.handle)); }
+void dxtlt_host::trim_idle_shard_buffers() { shard_pool_trim(); }
+void dxtlt_host::init_runtime_for_devices(int devices)
+{
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int d = 0; d < devices; ++d)
+        if (hipSetDevice(d) == hipSuccess)
+            (void)hipFree(nullptr);
+    (void)hipSetDevice(prev);
+}
 
 bool dxtlt_host::pipelined_bc7_shard(const ShardBuffers& sb, int dev, bool inverse, const uint8_t* in, uint8_t* out,
                                      uint64_t total_main, uint64_t first, uint64_t count, int32_t* rc)
@@ -852,6 +880,10 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in,
     std::vector<std::string> msgs((size_t)shards);
     std::vector<DxtltShardStat> stats((size_t)shards);
     std::vector<std::thread> threads;
+    // The workers narrow their own affinity before their first HIP call, and threads the HIP / ROCr runtime starts lazily
+    // from a worker would inherit that mask for the life of the process.  So the runtime is brought up for every device
+    // this call uses HERE, on the caller's unbound thread, before any worker exists (DXTLT_NUMA_BIND in the header).
+    dxtlt_host::init_runtime_for_devices(std::min(shards, count));
     // thread creation can fail (EAGAIN under a process limit): whatever was started is joined before the error leaves
     int32_t spawn_rc = DXTLT_OK;
     for (int d = 0; d < shards && spawn_rc == DXTLT_OK; ++d) {
@@ -868,11 +900,12 @@ int32_t dxtlt_transform_sharded(int32_t format, bool inverse, const uint8_t* in,
                     msgs[(size_t)d] = g_last_error;
             });
         } catch (const std::exception&) {
-            spawn_rc = fail(DXTLT_E_DEVICE, "could not start a shard worker thread");
+            spawn_rc = fail(DXTLT_E_ALLOCATION, "could not start a shard worker thread");   // a host resource ran out (batch_host, auto pool: the same code)
         }
     }
     for (auto& t : threads)
         t.join();
+    shard_pool_trim();   // idle contexts beyond the cap, now that no shard of this call is moving data
     g_shard_stats = stats;
     if (spawn_rc != DXTLT_OK) {
         (void)hipSetDevice(prev);
@@ -914,6 +947,24 @@ int32_t dxtlt_device_count(void)
         return 0;
     return count;
 }
+
+// The host-pointer crossover a size-routing caller should use (include/dxtlt_gfx950.h).  32 MiB: the size at which the
+// chunked host pipeline (upload | kernel | download) overtakes one core of the reference's SIMD path on this class of host
+// (profiles/r01_w_host_path_latency_vs_cpu.json, r01_j_host_pointer_pipeline_threshold.txt).
+static std::atomic<size_t> g_host_route_threshold{size_t(32) << 20};
+
+size_t dxtlt_host_route_threshold_bytes(void)
+{
+    if (const char* v = std::getenv("DXTLT_HOST_ROUTE_THRESHOLD_BYTES")) {
+        char* end = nullptr;
+        const unsigned long long x = std::strtoull(v, &end, 10);
+        if (end != v)
+            return (size_t)x;
+    }
+    return g_host_route_threshold.load();
+}
+
+void dxtlt_set_host_route_threshold_bytes(size_t bytes) { g_host_route_threshold.store(bytes); }
 
 void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 {

@@ -59,6 +59,12 @@ struct ShardBuffers {
 };
 int32_t acquire_shard_buffers(int dev, size_t bytes, ShardBuffers* out);
 void release_shard_buffers(const ShardBuffers& sb);
+// A sharded call, before it starts its workers: the HIP runtime brought up for devices [0, devices) on the CALLER's thread
+// (workers narrow their affinity before their first HIP call; runtime threads started lazily from one would inherit the mask).
+// After its workers have joined: idle contexts beyond the per-device cap are freed (never on a shard's completion path:
+// hipFree synchronises the device).
+void init_runtime_for_devices(int devices);
+void trim_idle_shard_buffers();
 // Blocks [first, first + count) of the main part (total_main blocks, whole granules) of a BC7 host array through the
 // chunked pipeline on the shard's buffers; false = below the pipeline's threshold (nothing done).
 bool pipelined_bc7_shard(const ShardBuffers& sb, int dev, bool inverse, const uint8_t* in, uint8_t* out, uint64_t total_main,

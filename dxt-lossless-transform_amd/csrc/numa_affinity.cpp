@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -140,6 +141,16 @@ int32_t dxtlt_device_local_cpulist(int32_t device, char* out, size_t cap)
     if (out == nullptr || cap == 0 || device < 0)
         return 0;
     out[0] = 0;
+    // a device ordinal the runtime does not know must not size the cache (a huge one would allocate gigabytes, or throw
+    // through this extern "C" boundary); nothing below may throw either
+    int known = 0;
+    if (hipGetDeviceCount(&known) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (device >= known)
+        return 0;
+    try {
     std::string cached = "?";
     {
         std::lock_guard<std::mutex> lk(g_cache_mutex);
@@ -165,6 +176,9 @@ int32_t dxtlt_device_local_cpulist(int32_t device, char* out, size_t cap)
         return 0;
     std::memcpy(out, cached.c_str(), cached.size() + 1);
     return (int32_t)cached.size();
+    } catch (const std::exception&) {   // std::bad_alloc from the cache
+        return 0;
+    }
 }
 
 }  // extern "C"

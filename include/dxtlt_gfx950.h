@@ -219,6 +219,15 @@ int32_t dxtlt_fill_splitmix64_device(void *d_dst, size_t len_bytes, uint64_t see
 const char *dxtlt_last_error(void);
 /* Number of visible HIP devices (0 if the runtime cannot initialise). */
 int32_t dxtlt_device_count(void);
+/* Size routing for callers that keep a CPU implementation of their own next to this library (the reference's crates do:
+ * rust/core-bodies).  A host-pointer call is a PCIe round trip: at least ~17 us, at most ~25-43 GiB/s, where one CPU core of
+ * the reference moves 20-50 GiB/s out of cache -- below the crossover the caller's own CPU path is faster (64 KiB: 20 us
+ * here against 2.9 us there; measured crossover ~32 MiB).  Returns that crossover in bytes: the
+ * value of $DXTLT_HOST_ROUTE_THRESHOLD_BYTES when set (0 = route everything to the device), else what
+ * the setter below stored, else 32 MiB.  The library itself routes nothing: it has no CPU
+ * implementation, and every entry point does what its name says on the device. */
+size_t dxtlt_host_route_threshold_bytes(void);
+void dxtlt_set_host_route_threshold_bytes(size_t bytes);
 /* Knobs for experiments and tests.  tile_threads: 64/128/256/512 (0 = per-format default).
  * force_path: 0 = automatic, 1 = always the element-granular kernel, 2 = always the shifted-tile kernel.
  * Process-wide. */

@@ -3,7 +3,7 @@
 //! Candidate order, the estimated section, the strict `<` tie-break and the final transform with the winner are
 //! implemented on the library side exactly as in the reference (csrc/auto_transform.cpp), so the same estimator
 //! yields the same settings and the same bytes.
-use crate::gfx950_glue::{abort_on_device_failure, vtable, EstimatorBridge};
+use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge};
 use crate::transform::{Bc2EstimateSettings, DetermineBestTransformError};
 use crate::Bc2TransformSettings;
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
@@ -20,6 +20,12 @@ pub unsafe fn transform_bc2_auto<T>(
 where
     T: SizeEstimationOperations,
 {
+    // small inputs stay on the crate's own CPU path (the reference's body of this function, renamed `transform_bc2_auto_cpu`
+    // and kept unchanged behind the `cpu` feature; gfx950_glue.rs "size routing")
+    #[cfg(feature = "cpu")]
+    if stays_on_cpu(len) {
+        return transform_bc2_auto_cpu(input_ptr, output_ptr, len, transform_options);
+    }
     let bridge = EstimatorBridge::new(&transform_options.size_estimator);
     let table = vtable(&bridge);
     let (mut mode, mut split_colour, mut estimator_error) = (0u8, false, 0u32);
@@ -36,6 +42,8 @@ where
         DXTLT_E_ESTIMATOR => Err(DetermineBestTransformError::SizeEstimationError(
             bridge.take_error().expect("the estimator callback failed, so it parked its error"))),
         DXTLT_E_ALLOCATION => Err(DetermineBestTransformError::AllocateError(AllocateError::default())),
+        #[cfg(feature = "cpu")]
+        other if device_is_absent(other) => transform_bc2_auto_cpu(input_ptr, output_ptr, len, transform_options),
         other => abort_on_device_failure("transform_bc2_auto", other),
     }
 }

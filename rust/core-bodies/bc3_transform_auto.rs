@@ -1,7 +1,7 @@
 //! UNCOMPILED (see ../README.md).  New body for
 //! core/dxt-lossless-transform-bc3/src/transform/transform_auto.rs (:196-294).  Two estimator calls per candidate
 //! (alpha endpoints, colour endpoints), sizes added, as in the reference; implemented in csrc/auto_transform.cpp.
-use crate::gfx950_glue::{abort_on_device_failure, vtable, EstimatorBridge};
+use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge};
 use crate::transform::{Bc3EstimateSettings, DetermineBestTransformError};
 use crate::Bc3TransformSettings;
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
@@ -18,6 +18,12 @@ pub unsafe fn transform_bc3_auto<T>(
 where
     T: SizeEstimationOperations,
 {
+    // small inputs stay on the crate's own CPU path (the reference's body of this function, renamed `transform_bc3_auto_cpu`
+    // and kept unchanged behind the `cpu` feature; gfx950_glue.rs "size routing")
+    #[cfg(feature = "cpu")]
+    if stays_on_cpu(len) {
+        return transform_bc3_auto_cpu(input_ptr, output_ptr, len, transform_options);
+    }
     let bridge = EstimatorBridge::new(&transform_options.size_estimator);
     let table = vtable(&bridge);
     let (mut mode, mut split_alpha, mut split_colour, mut estimator_error) = (0u8, false, false, 0u32);
@@ -35,6 +41,8 @@ where
         DXTLT_E_ESTIMATOR => Err(DetermineBestTransformError::SizeEstimationError(
             bridge.take_error().expect("the estimator callback failed, so it parked its error"))),
         DXTLT_E_ALLOCATION => Err(DetermineBestTransformError::AllocateError(AllocateError::default())),
+        #[cfg(feature = "cpu")]
+        other if device_is_absent(other) => transform_bc3_auto_cpu(input_ptr, output_ptr, len, transform_options),
         other => abort_on_device_failure("transform_bc3_auto", other),
     }
 }

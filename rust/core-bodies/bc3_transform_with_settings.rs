@@ -1,6 +1,14 @@
 //! UNCOMPILED (see ../README.md).  New bodies for
 //! core/dxt-lossless-transform-bc3/src/transform/transform_with_settings.rs (:32-142 and :162-272).
-use crate::gfx950_glue::abort_on_device_failure;
+//! Doc comments and safety sections of the reference stay as they are.  The reference's OWN bodies stay too: renamed
+//! `transform_bc3_with_settings_cpu` / `untransform_bc3_with_settings_cpu`, unchanged, behind the crate's `cpu` feature
+//! (default on) -- they are this crate's CPU implementation, on the reference's side of the boundary; libdxtlt_gfx950 has
+//! none and is never asked for one.
+//!
+//! Routing (gfx950_glue.rs): a call below `dxtlt_host_route_threshold_bytes()` (measured crossover 32 MiB) goes to the
+//! crate's own dispatch -- a PCIe round trip costs a small texture 2.5-7 x what one CPU core does -- everything else to the
+//! device.  Without the `cpu` feature every call goes to the device.
+use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu};
 use crate::{Bc3TransformSettings, Bc3UntransformSettings};
 use dxtlt_gfx950_sys::{dxtlt_transform_bc3_with_settings, dxtlt_untransform_bc3_with_settings};
 
@@ -12,6 +20,11 @@ pub unsafe fn transform_bc3_with_settings(
     transform_options: Bc3TransformSettings,
 ) {
     debug_assert!(len.is_multiple_of(16));
+    #[cfg(feature = "cpu")]
+    if stays_on_cpu(len) {
+        return transform_bc3_with_settings_cpu(input_ptr, output_ptr, len, transform_options);
+    }
+    // YCoCgVariant is repr(u8) with the core numbering None = 0, Variant1..3 (common color_565/decorrelate.rs:72-84)
     let rc = dxtlt_transform_bc3_with_settings(
         input_ptr, output_ptr, len,
         transform_options.decorrelation_mode as u8,
@@ -19,6 +32,10 @@ pub unsafe fn transform_bc3_with_settings(
         transform_options.split_colour_endpoints,
     );
     if rc != 0 {
+        #[cfg(feature = "cpu")]
+        if device_is_absent(rc) {
+            return transform_bc3_with_settings_cpu(input_ptr, output_ptr, len, transform_options);
+        }
         abort_on_device_failure("transform_bc3_with_settings", rc);
     }
 }
@@ -31,6 +48,10 @@ pub unsafe fn untransform_bc3_with_settings(
     untransform_options: Bc3UntransformSettings,
 ) {
     debug_assert!(len.is_multiple_of(16));
+    #[cfg(feature = "cpu")]
+    if stays_on_cpu(len) {
+        return untransform_bc3_with_settings_cpu(input_ptr, output_ptr, len, untransform_options);
+    }
     let rc = dxtlt_untransform_bc3_with_settings(
         input_ptr, output_ptr, len,
         untransform_options.decorrelation_mode as u8,
@@ -38,6 +59,15 @@ pub unsafe fn untransform_bc3_with_settings(
         untransform_options.split_colour_endpoints,
     );
     if rc != 0 {
+        #[cfg(feature = "cpu")]
+        if device_is_absent(rc) {
+            return untransform_bc3_with_settings_cpu(input_ptr, output_ptr, len, untransform_options);
+        }
         abort_on_device_failure("untransform_bc3_with_settings", rc);
     }
 }
+
+// ---- the reference's own bodies, verbatim, under their new names -----------------------------------------------------------
+// (not reproduced in this repository: they are the lines :32-142 and :162-272 of the file this one replaces, with
+//  `pub unsafe fn transform_bc3_with_settings` -> `#[cfg(feature = "cpu")] unsafe fn transform_bc3_with_settings_cpu` and the
+//  same for the inverse; nothing inside them changes, so the crate's SIMD ladders, tests and benches keep working on them)

@@ -1,41 +1,97 @@
 //! UNCOMPILED (see ../README.md).  `mod gfx950_glue;` of each core crate: what the swapped bodies share.
+//!
+//! `no_std` like the crates it goes into (they make `std` an optional feature): nothing here needs an allocator or a
+//! lock from `std` -- the estimator's first error is parked behind a spin lock built on `core::sync::atomic`.
+use core::cell::UnsafeCell;
 use core::ffi::{c_void, CStr};
+use core::sync::atomic::{AtomicBool, AtomicUsize, Ordering};
 
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
-use dxtlt_gfx950_sys::{dxtlt_last_error, DltSizeEstimator};
+use dxtlt_gfx950_sys::{dxtlt_host_route_threshold_bytes, dxtlt_last_error, DltSizeEstimator};
 
 /// The reference's `transform_bcN_with_settings` cannot fail; a device can.  A failure must be loud -- never a silent
-/// CPU fallback that would hide a broken deployment.
+/// detour that would hide a broken deployment.  (A machine WITHOUT a device is a different matter when the crate was
+/// built with its own CPU path: see `device_is_absent`.)
 #[cold]
 #[inline(never)]
 pub(crate) fn abort_on_device_failure(what: &str, rc: i32) -> ! {
-    let text = unsafe { CStr::from_ptr(dxtlt_last_error()) }.to_string_lossy();
+    let text = unsafe { CStr::from_ptr(dxtlt_last_error()) }.to_str().unwrap_or("(no text)");
     panic!("{what}: libdxtlt_gfx950 status {rc}: {text}");
 }
 
-/// `SizeEstimationOperations` behind the C vtable the library calls back through.  The estimator's error type is
-/// generic, the callback's return value a `u32`: the first error is parked here and handed back to the caller.
+// ---- size routing ------------------------------------------------------------------------------------------------------
+// A host-pointer call into the library is a PCIe round trip: at least ~17 us and at most 25-43 GiB/s, where ONE core of this
+// crate's own SIMD path moves 20-50 GiB/s out of cache.  The reference's call pattern is one call per file from rayon
+// workers (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:154-199) on textures that average 4 MiB, its test
+// assets are 32-64 KiB: below the crossover the crate's own dispatch -- kept, untouched, behind the `cpu` feature -- is the
+// faster path (64 KiB: 2.9 us against 20 us), above it the device is.  The crossover is the library's to know
+// (`dxtlt_host_route_threshold_bytes()`: measured 32 MiB, overridable by $DXTLT_HOST_ROUTE_THRESHOLD_BYTES); it is read
+// once.
+
+/// 0 = not asked yet; otherwise threshold + 1.
+static ROUTE_THRESHOLD_PLUS_ONE: AtomicUsize = AtomicUsize::new(0);
+
+/// `true`: this call is small enough that the crate's own CPU dispatch is the faster path.  Always `false` without the
+/// `cpu` feature (the crate then has no implementation of its own left).
+#[inline]
+pub(crate) fn stays_on_cpu(len: usize) -> bool {
+    if !cfg!(feature = "cpu") {
+        return false;
+    }
+    let mut t = ROUTE_THRESHOLD_PLUS_ONE.load(Ordering::Relaxed);
+    if t == 0 {
+        t = unsafe { dxtlt_host_route_threshold_bytes() }.saturating_add(1).max(1);
+        ROUTE_THRESHOLD_PLUS_ONE.store(t, Ordering::Relaxed);
+    }
+    len < t - 1
+}
+
+/// `true`: the library found no HIP device AND the crate carries its own CPU path AND the `cpu-without-device` feature
+/// asks for it: the same binary then still works on a machine without a GPU.  Off by default: `DXTLT_E_NO_DEVICE` panics
+/// like every other status.
+#[inline]
+pub(crate) fn device_is_absent(rc: i32) -> bool {
+    cfg!(all(feature = "cpu", feature = "cpu-without-device")) && rc == dxtlt_gfx950_sys::DXTLT_E_NO_DEVICE
+}
+
+// ---- transform_bcN_auto: SizeEstimationOperations behind the C vtable ---------------------------------------------------
+
+/// The estimator's error type is generic, the callback's return value a `u32`: the first error is parked here and handed
+/// back to the caller.
 ///
-/// The library may call `estimate_compressed_size` from several threads at once with this one context
-/// (`dxtlt_set_auto_estimator_threads(n > 1)`, opt-in), so the callbacks only ever take a SHARED reference and the error
-/// slot is a `Mutex`: no aliased `&mut`, no data race.  (`T: Sync` is what makes the concurrent calls into the estimator
-/// itself sound; with an estimator that is not `Sync` leave the switch at 1 -- `vtable` asks for the bound.)
+/// The bounds are the reference's own (`T: SizeEstimationOperations`, nothing more): the library calls the callbacks one at
+/// a time from the calling thread unless `dxtlt_set_auto_estimator_threads(n > 1)` was called, and this glue never calls
+/// it.  A caller who opts in must hand over an estimator whose methods may run concurrently (`T: Sync`); that promise is
+/// theirs, at the call to the setter, not a bound on these functions -- which would not compile for the reference's
+/// signatures.  Whatever the setting, the glue itself is sound: it only ever forms SHARED references to the bridge, and the
+/// error slot is written under a lock.
 pub(crate) struct EstimatorBridge<'a, T: SizeEstimationOperations> {
     pub estimator: &'a T,
-    pub error: std::sync::Mutex<Option<T::Error>>,
+    locked: AtomicBool,
+    error: UnsafeCell<Option<T::Error>>,
 }
 
 impl<'a, T: SizeEstimationOperations> EstimatorBridge<'a, T> {
     pub(crate) fn new(estimator: &'a T) -> Self {
-        Self { estimator, error: std::sync::Mutex::new(None) }
+        Self { estimator, locked: AtomicBool::new(false), error: UnsafeCell::new(None) }
+    }
+    fn with_slot<R>(&self, f: impl FnOnce(&mut Option<T::Error>) -> R) -> R {
+        while self.locked.compare_exchange_weak(false, true, Ordering::Acquire, Ordering::Relaxed).is_err() {
+            core::hint::spin_loop();
+        }
+        // SAFETY: the flag above makes this the only reference to the slot until it is cleared again
+        let r = f(unsafe { &mut *self.error.get() });
+        self.locked.store(false, Ordering::Release);
+        r
     }
     fn park(&self, e: T::Error) {
-        let mut slot = self.error.lock().unwrap_or_else(|p| p.into_inner());
-        slot.get_or_insert(e);
+        self.with_slot(|slot| {
+            slot.get_or_insert(e);
+        });
     }
     /// The first error a callback reported, if any (call after the library has returned).
     pub(crate) fn take_error(&self) -> Option<T::Error> {
-        self.error.lock().unwrap_or_else(|p| p.into_inner()).take()
+        self.with_slot(|slot| slot.take())
     }
 }
 
@@ -58,10 +114,7 @@ unsafe extern "C" fn estimate_compressed_size<T: SizeEstimationOperations>(
     }
 }
 
-pub(crate) fn vtable<T: SizeEstimationOperations + Sync>(bridge: &EstimatorBridge<T>) -> DltSizeEstimator
-where
-    T::Error: Send,
-{
+pub(crate) fn vtable<T: SizeEstimationOperations>(bridge: &EstimatorBridge<T>) -> DltSizeEstimator {
     DltSizeEstimator {
         context: bridge as *const EstimatorBridge<T> as *mut c_void,
         max_compressed_size: max_compressed_size::<T>,

@@ -108,6 +108,11 @@ extern "C" {
     pub fn dxtlt_device_local_cpulist(device: i32, out: *mut c_char, cap: usize) -> i32;
     pub fn dxtlt_bind_thread_to_cpulist(cpulist: *const c_char) -> i32;
 
+    /// The host-pointer crossover below which a caller with a CPU path of its own should use it (measured: 32 MiB;
+    /// $DXTLT_HOST_ROUTE_THRESHOLD_BYTES overrides, 0 = everything to the device).
+    pub fn dxtlt_host_route_threshold_bytes() -> usize;
+    pub fn dxtlt_set_host_route_threshold_bytes(bytes: usize);
+
     pub fn dxtlt_last_error() -> *const c_char;
     pub fn dxtlt_device_count() -> i32;
     pub fn dxtlt_release_thread_resources();

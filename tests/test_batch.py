@@ -343,3 +343,62 @@ def test_bc7_items_ride_along_in_both_batch_calls(pkg, oracle):
         assert np.array_equal(h[:n], want) and (h[n:] == 0x5A).all(), ("device", k, dev_items[k][0], n)
     with pytest.raises(pkg.InvalidLength):
         batch.transform_batch_host([("bc7", False, np.zeros(24, np.uint8), np.zeros(24, np.uint8), None)])
+
+
+_SPAWN_FAILURE_SCRIPT = r'''
+import os, resource, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import dxt_lossless_transform_amd as pkg
+from dxt_lossless_transform_amd import batch, bc7
+
+st = pkg.Bc1TransformSettings()
+n = 16 << 20
+src = [np.random.default_rng(i).integers(0, 256, n, dtype=np.uint8) for i in range(9)]
+dst = [np.empty_like(a) for a in src]
+items = [("bc1", False, a, b, st) for a, b in zip(src, dst)]
+big_in = np.concatenate(src[:4]); big_out = np.empty_like(big_in)
+
+def calls():
+    out = {}
+    for name, fn in (("batch_host", lambda: batch.transform_batch_host(items)),
+                     ("sharded", lambda: pkg.transform_sharded("bc1", False, big_in, big_out, st, 2)),
+                     ("bc7_sharded", lambda: bc7.transform_bc7_sharded(big_in, big_out, 2))):
+        t0 = time.perf_counter()
+        try:
+            fn(); out[name] = 0
+        except pkg.DeviceError as e:
+            out[name] = e.code
+        out[name + "_s"] = time.perf_counter() - t0
+    return out
+
+first = calls()                       # every lazily started runtime thread exists after this
+soft, hard = resource.getrlimit(resource.RLIMIT_NPROC)
+resource.setrlimit(resource.RLIMIT_NPROC, (1, hard))      # any further thread creation of this user fails with EAGAIN
+starved = calls()
+resource.setrlimit(resource.RLIMIT_NPROC, (soft, hard))
+after = calls()
+print(repr((first, starved, after)))
+'''
+
+
+@pytest.mark.gpu
+def test_thread_spawn_failure_is_one_clean_status_everywhere(pkg):
+    """The library starts host threads in dxtlt_transform_batch_host, dxtlt_transform_sharded and the BC7 sharded calls.  When
+    the process may not create threads (RLIMIT_NPROC), each of them must come back promptly with DXTLT_E_ALLOCATION (6) --
+    no hang, no partial work left running -- and work again once the limit is lifted.  (Root is exempt from RLIMIT_NPROC.)"""
+    import ast
+    import os
+    import subprocess
+    import sys
+
+    if os.geteuid() == 0:
+        pytest.skip("RLIMIT_NPROC does not bind root")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SPAWN_FAILURE_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    first, starved, after = ast.literal_eval(r.stdout.strip().splitlines()[-1])
+    for name in ("batch_host", "sharded", "bc7_sharded"):
+        assert first[name] == 0 and after[name] == 0, (name, first, after)
+        assert starved[name] == 6, (name, starved)          # DXTLT_E_ALLOCATION, the same code on every path
+        assert starved[name + "_s"] < 30, (name, starved)

@@ -155,3 +155,56 @@ def test_rust_sys_crate_declares_only_exported_symbols(pkg):
         c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
         rust_args = [a for a in args.split(",") if a.strip()]
         assert len(c_args) == len(rust_args), (name, len(c_args), len(rust_args))
+
+
+def test_host_route_threshold_default_setter_and_environment(pkg):
+    """dxtlt_host_route_threshold_bytes: the host-pointer crossover a size-routing caller uses (rust/core-bodies).  Default
+    32 MiB, a setter, and $DXTLT_HOST_ROUTE_THRESHOLD_BYTES on top of both; no device needed."""
+    import ctypes
+    import os
+    import subprocess
+    import sys
+
+    lib = ctypes.CDLL(pkg._lib.lib_path())
+    lib.dxtlt_host_route_threshold_bytes.restype = ctypes.c_size_t
+    lib.dxtlt_set_host_route_threshold_bytes.argtypes = [ctypes.c_size_t]
+    if "DXTLT_HOST_ROUTE_THRESHOLD_BYTES" not in os.environ:
+        assert lib.dxtlt_host_route_threshold_bytes() == 32 << 20
+        lib.dxtlt_set_host_route_threshold_bytes(1 << 20)
+        assert lib.dxtlt_host_route_threshold_bytes() == 1 << 20
+        lib.dxtlt_set_host_route_threshold_bytes(32 << 20)
+    code = ("import ctypes; l = ctypes.CDLL(%r); l.dxtlt_host_route_threshold_bytes.restype = ctypes.c_size_t; "
+            "print(l.dxtlt_host_route_threshold_bytes())" % pkg._lib.lib_path())
+    for value, want in (("0", 0), ("65536", 65536), ("not a number", 32 << 20)):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, DXTLT_HOST_ROUTE_THRESHOLD_BYTES=value))
+        assert r.returncode == 0 and int(r.stdout.strip()) == want, (value, r.stdout, r.stderr)
+
+
+def test_rust_bodies_route_by_size_and_glue_is_no_std():
+    """The shipped Rust bodies (source only) send small inputs to the crate's own CPU dispatch before the FFI call, keep the
+    loud panic for device failures, and the glue they share uses nothing from std (the core crates make std optional) and
+    puts no bound beyond the reference's on `vtable`."""
+    import os
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust", "core-bodies")
+    for n in (1, 2, 3):
+        src = open(os.path.join(root, f"bc{n}_transform_with_settings.rs")).read()
+        for fn in (f"transform_bc{n}_with_settings", f"untransform_bc{n}_with_settings"):
+            body = src[src.index(f"pub unsafe fn {fn}("):]
+            body = body[:body.index("\n}\n") + 3]
+            route, ffi = body.index("if stays_on_cpu(len)"), body.index(f"dxtlt_{fn}(")
+            assert route < ffi and f"return {fn}_cpu(" in body[route:ffi], fn
+            assert "abort_on_device_failure" in body[ffi:] and "device_is_absent(rc)" in body[ffi:], fn
+        auto = open(os.path.join(root, f"bc{n}_transform_auto.rs")).read()
+        assert auto.index("if stays_on_cpu(len)") < auto.index(f"dxtlt_transform_bc{n}_auto(")
+        # the reference's bounds, nothing added
+        assert re.search(r"where\s+T: SizeEstimationOperations,\s*\{", auto), n
+    glue = open(os.path.join(root, "gfx950_glue.rs")).read()
+    code = "\n".join(l for l in glue.splitlines() if not l.lstrip().startswith("//"))
+    assert "std::" not in code and "Mutex" not in code
+    assert re.search(r"pub\(crate\) fn vtable<T: SizeEstimationOperations>\(", code)
+    assert "dxtlt_host_route_threshold_bytes()" in code
+    sys_src = open(os.path.join(os.path.dirname(root), "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read()
+    assert "#![no_std]" in sys_src

@@ -623,6 +623,42 @@ def test_sharded_entry_point_on_every_visible_device(pkg, oracle, dev):
     assert np.array_equal(z, x)
 
 
+def test_mixed_archive_over_every_visible_device(pkg, oracle, dev):
+    """BASELINE.json configs[4] in its defining shape, activated by >= 2 visible devices (the driver's 8-GPU node; skips on
+    a one-GPU box): alternating 256 MiB BC1 / BC3 textures, one per device and format, every texture through
+    dxtlt_transform_sharded over ALL devices (contiguous block ranges, host concatenation), plus a BC7 texture through
+    dxtlt_transform_bc7_sharded.  Whole-buffer equality with the oracle, exact round trips, and one shard per device in the
+    stats."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("one device visible")
+    from dxt_lossless_transform_amd import bc7
+
+    tex = 256 << 20
+    for i in range(2 * n_dev):
+        fmt = "bc1" if i % 2 == 0 else "bc3"
+        st = pkg_settings(pkg, fmt, (1, 1, 1))
+        x = oracle.fill_splitmix64(tex, 0x0A5C0005 + i)
+        y = np.zeros_like(x)
+        pkg.transform_sharded(fmt, False, x, y, st, 0)
+        stats = pkg.sharded_last_stats()
+        assert sorted(s["device"] for s in stats) == list(range(n_dev)), stats
+        assert sum(s["blocks"] for s in stats) == tex // pkg.BLOCK_BYTES[fmt]
+        want = np.empty_like(x)
+        oracle.run_mt(fmt, x, want, 1, True, True, False, 8)
+        assert np.array_equal(y, want), (i, fmt)
+        z = np.zeros_like(x)
+        pkg.transform_sharded(fmt, True, y, z, st, 0)
+        assert np.array_equal(z, x), (i, fmt)
+    x = oracle.fill_splitmix64(tex + 16 * 333, 0x0A5C0707)      # whole granules and a tail part
+    oracle.bc7_force_modes(x)
+    y, z = np.zeros_like(x), np.zeros_like(x)
+    bc7.transform_bc7_sharded(x, y, 0)
+    assert np.array_equal(y, oracle.transform_bc7(x))
+    bc7.transform_bc7_sharded(y, z, 0, inverse=True)
+    assert np.array_equal(z, x)
+
+
 def test_real_textures(pkg, oracle, dev):
     """assets/tests/r2-256-bc{1,2,3}.dds payloads: every settings combination, forward bytes and round trip
     (reference: debug_bcN roundtrip commands)."""
