@@ -262,15 +262,14 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         if (g.entries.empty())
             continue;
         const size_t n = g.entries.size();
-        const size_t index_n = ((size_t)g.wgs + dxtlt::kBatchIndexWgs - 1) / dxtlt::kBatchIndexWgs;
         const size_t entry_bytes = (n * sizeof(BatchEntry) + 15) & ~(size_t)15;
-        const size_t bytes = (entry_bytes + index_n * sizeof(dxtlt::BatchIndex) + 15) & ~(size_t)15;
+        const size_t bytes = entry_bytes + dxtlt::batch_index_bytes(g.wgs);
         TableSlot* slot = nullptr;
         hipError_t e = g_ring.acquire(bytes, &slot);
         if (e != hipSuccess)
             return fail(kDevice, "batch table staging", e);
         std::memcpy(slot->host, g.entries.data(), n * sizeof(BatchEntry));
-        dxtlt::build_batch_index(g.entries.data(), n, g.wgs, reinterpret_cast<dxtlt::BatchIndex*>(static_cast<uint8_t*>(slot->host) + entry_bytes));
+        dxtlt::build_batch_index(g.entries.data(), n, g.wgs, static_cast<uint8_t*>(slot->host) + entry_bytes);
         const bool uniform = g.uniform && !no_uniform;
         // a regular array of buffers: one size and tile form, pointers a constant stride apart
         bool strided = uniform && !no_strided;   // (one buffer is a regular array too)
@@ -286,7 +285,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         if (e == hipSuccess)
             e = dxtlt::launch_batch((dxtlt::Format)((gi >> 5) + 1), ((gi >> 4) & 1) != 0, group_settings(gi),
                                     static_cast<const BatchEntry*>(slot->dev),
-                                    reinterpret_cast<const dxtlt::BatchIndex*>(static_cast<const uint8_t*>(slot->dev) + entry_bytes),
+                                    static_cast<const uint8_t*>(slot->dev) + entry_bytes,
                                     (uint32_t)n, g.wgs, uniform ? g.uniform_wgs : 0, user,
                                     strided ? &g.entries[0] : nullptr, src_stride, dst_stride);
         // the event marks both the copy and the kernel that reads the device table

@@ -15,6 +15,7 @@
 //     one kernel per settings combination present in the batch; a corpus usually has one) and the entry carries the
 //     per-stream bases (Shifts::gbase) ready-made instead of six 64-bit products per workgroup.
 #include <cstdlib>
+#include <cstring>
 
 #include "bcn_device.h"
 
@@ -88,8 +89,8 @@ struct StridedBatch {
 
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
 __global__ void __launch_bounds__(256)
-batch_kernel(const BatchEntry* __restrict__ entries_arg, const BatchIndex* __restrict__ index_arg, uint32_t uniform_wgs, uint32_t magic,
-             StridedBatch strided)
+batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restrict__ index_arg, uint32_t n_base, uint32_t uniform_wgs,
+             uint32_t magic, StridedBatch strided)
 {
     constexpr int kLds = INVERSE ? kShiftLdsBytes : halo_lds_bytes<FMT>();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
@@ -98,9 +99,9 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const BatchIndex* __res
     // both table pointers in the FIRST scalar round trip (the compiler otherwise fetches `index` on the path that uses it, behind
     // the first wait); through integers: see fetched_now
     uint64_t entries_at = reinterpret_cast<uintptr_t>(entries_arg), index_at = reinterpret_cast<uintptr_t>(index_arg);
-    asm("" : "+s"(entries_at), "+s"(index_at), "+s"(uniform_wgs), "+s"(magic));
+    asm("" : "+s"(entries_at), "+s"(index_at), "+s"(n_base), "+s"(uniform_wgs), "+s"(magic));
     const BatchEntry* entries = (const BatchEntry*)(const __attribute__((address_space(1))) BatchEntry*)entries_at;
-    const BatchIndex* index = (const BatchIndex*)(const __attribute__((address_space(1))) BatchIndex*)index_at;
+    const uint8_t* index = (const uint8_t*)(global_cptr)index_at;
     if (uniform_wgs != 0) {
         uint32_t e = __umulhi(wg, magic);
         if ((e + 1) * uniform_wgs <= wg)
@@ -124,15 +125,19 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const BatchIndex* __res
             en = load_batch_entry(entries + e);
         }
     } else {
-        // index[wg / 64] = the entry that owns workgroup 64 * (wg / 64); an entry carries its own end, so a workgroup of a buffer
-        // of 64 workgroups or more is two dependent table loads away from its tile (three scalar round trips with the kernel
-        // arguments).  What was measured on the way here (profiles/r04_batch_edge_tiles.txt; one 2 GiB odd-count buffer or the
-        // corpus, forward): no table load 0.80, ONE load of an entry that thousands of workgroups share 0.80 -- a scalar-cache
-        // hit costs next to nothing -- but an index record that every workgroup of a CU sees for the first time 0.72-0.76
-        // whatever it saves in round trips (a 144-byte record per 256 workgroups with the entry inline: 0.72; a 16-byte bit
-        // mask per 64: 0.76).  So the index is as small as it can be -- 4 bytes per 64 workgroups, a cache line per 1024 -- and
-        // the entry, shared by all workgroups of its buffer, is what is fetched behind it.
-        uint32_t e = index[wg >> 6];
+        // base[wg / 4096] + delta[wg / 64] = the entry that owns workgroup 64 * (wg / 64) (bcn_launch.h); an entry carries its own
+        // end, so a workgroup of a buffer of 64 workgroups or more is two dependent table loads away from its tile (three scalar
+        // round trips with the kernel arguments).  What was measured on the way here (profiles/r04_batch_edge_tiles.txt; one
+        // 2 GiB odd-count buffer or the corpus, forward): no table load 0.80, ONE load of an entry that thousands of workgroups
+        // share 0.80 -- a scalar-cache hit costs next to nothing -- but an index record that every workgroup of a CU sees for the
+        // first time 0.72-0.76 whatever it saves in round trips (a 144-byte record per 256 workgroups with the entry inline:
+        // 0.72; a 16-byte bit mask per 64: 0.76; 4 bytes per 64: 0.77).  So the index is as small as it can be -- one byte per 64
+        // workgroups, a cache line per 4096 -- and the entry, shared by all workgroups of its buffer, is what is fetched behind it.
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(index);
+        const uint8_t* delta = index + n_base * 4;
+        uint32_t e = base[wg >> 12];
+        const uint32_t dword = reinterpret_cast<const uint32_t*>(delta)[wg >> 8];   // (a scalar load is a dword load)
+        e += (dword >> (8u * ((wg >> 6) & 3u))) & 0xFFu;
         en = load_batch_entry(entries + e);
         // every field is needed HERE (empty non-volatile asm: the value becomes opaque, memory is untouched, the loads stay
         // scalar): left alone the compiler fetches end_wg, runs the loop and only then asks for the rest of the entry
@@ -225,21 +230,27 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
     return wgs;
 }
 
-void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, BatchIndex* index)
+void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, uint8_t* index)
 {
-    const size_t n = ((size_t)total_wgs + kBatchIndexWgs - 1) / kBatchIndexWgs;
+    const size_t n_base = batch_index_base_count(total_wgs), n_delta = batch_index_delta_count(total_wgs);
+    uint32_t* base = reinterpret_cast<uint32_t*>(index);
+    uint8_t* delta = index + n_base * 4;
+    std::memset(index, 0, batch_index_bytes(total_wgs));
     size_t cur = 0;
-    for (size_t k = 0; k < n; ++k) {
-        const uint32_t wg = (uint32_t)(k * kBatchIndexWgs);
+    for (size_t j = 0; j < n_delta; ++j) {
+        const uint32_t wg = (uint32_t)(j * kBatchIndexWgs);
         while (cur + 1 < n_entries && entries[cur].end_wg <= wg)
             ++cur;
-        index[k] = (BatchIndex)cur;
+        if (wg % kBatchBaseWgs == 0)
+            base[wg / kBatchBaseWgs] = (uint32_t)cur;
+        const size_t d = cur - base[wg / kBatchBaseWgs];
+        delta[j] = (uint8_t)(d > 255 ? 255 : d);   // saturated: the kernel walks on from there
     }
 }
 
 namespace {
 
-using BatchFn = void (*)(const BatchEntry*, const BatchIndex*, uint32_t, uint32_t, StridedBatch);
+using BatchFn = void (*)(const BatchEntry*, const uint8_t*, uint32_t, uint32_t, uint32_t, StridedBatch);
 
 template <int FMT, int VARIANT, bool SA, bool SC>
 BatchFn batch_fn(bool inverse) { return inverse ? batch_kernel<FMT, VARIANT, SA, SC, true> : batch_kernel<FMT, VARIANT, SA, SC, false>; }
@@ -267,7 +278,7 @@ BatchFn batch_variant(int variant, bool sa, bool sc, bool inverse)
 
 }  // namespace
 
-hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const BatchIndex* d_index,
+hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint8_t* d_index,
                         uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
                         const BatchEntry* strided_first, int64_t src_stride, int64_t dst_stride)
 {
@@ -302,7 +313,8 @@ hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const Batch
     case kBc3: k = batch_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_index, uniform_wgs, magic, strided);
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_index, (uint32_t)batch_index_base_count(total_wgs), uniform_wgs, magic,
+                       strided);
     return hipGetLastError();
 }
 

@@ -45,6 +45,42 @@ def test_batch_equals_oracle_item_by_item(pkg, oracle):
 
 
 @pytest.mark.gpu
+def test_batch_index_with_hundreds_of_tiny_buffers_between_large_ones(pkg, oracle):
+    """The workgroup -> buffer index is one byte per 64 workgroups on top of a base per 4096 (bcn_launch.h) and SATURATES when
+    more than 255 buffers begin inside one 4096-workgroup span; the kernel then walks the entries from where the index leaves
+    it.  A large buffer, 700 buffers of one to three tiles of different sizes (no two neighbours alike: no equal-size
+    shortcut), another large one, 300 more tiny ones: every buffer against the oracle, guard bytes intact, both directions."""
+    from dxt_lossless_transform_amd import batch
+
+    dev = torch.device("cuda:0")
+    fmt, B = "bc3", 16
+    st = settings_for(pkg, fmt, 1, 1, 1)
+    rng = np.random.default_rng(0x1DE7)
+    counts = [300_000] + [int(rng.integers(1, 770)) for _ in range(700)] + [1_398_103] + [int(rng.integers(1, 300)) for _ in range(300)]
+    for inverse in (False, True):
+        xs = [oracle.fill_splitmix64(n * B, 0x1DE7 + 7 * k) for k, n in enumerate(counts)]
+        if inverse:
+            xs = [oracle.transform(fmt, x, 1, True, True) for x in xs]
+        offs, at = [], 0
+        for n in counts:
+            offs.append(at)
+            at += (n * B + 64 + 255) // 256 * 256
+        xd = torch.zeros(at, dtype=torch.uint8, device=dev)
+        yd = torch.full((at,), 0x5A, dtype=torch.uint8, device=dev)
+        hx = np.zeros(at, dtype=np.uint8)
+        for x, o in zip(xs, offs):
+            hx[o:o + x.size] = x
+        xd.copy_(torch.from_numpy(hx))
+        batch.transform_batch([(fmt, inverse, xd[o:o + n * B], yd[o:o + n * B], st) for n, o in zip(counts, offs)])
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy()
+        for k, (n, o, x) in enumerate(zip(counts, offs, xs)):
+            want = oracle.transform(fmt, x, 1, True, True, inverse=inverse)
+            assert np.array_equal(got[o:o + n * B], want), (inverse, k, n)
+            assert (got[o + n * B:o + n * B + 64] == 0x5A).all(), (inverse, k, n)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_batch_runs_every_tile_form(pkg, oracle, fmt):
     """The batch kernel picks a tile form per buffer (plan_batch_entry): aligned tiles when every stream base sits on a
