@@ -766,6 +766,21 @@ def cpu_baseline_corpus_bc1(sample) -> dict:
     return out
 
 
+def attach_corpus_traffic(legs: dict) -> None:
+    """HBM bytes per launch of the corpus legs' batch kernels from the committed PMC passes, when the leg ran the profiled corpus."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return
+    note = (f"{rec.get('source', 'profiles/pmc_traffic.json')}: committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 rule, "
+            "WRITE_SIZE); NOT measured by this run")
+    for name in ("corpus", "corpus_bc3"):
+        r = (rec.get("legs") or {}).get(name) or {}
+        if name in legs and r.get("bytes") == legs[name]["bytes"] and r.get("fwd"):
+            legs[name]["roofline"].update({"traffic": r["fwd"], "inverse_traffic": r["inv"], "traffic_source": note})
+
+
 def bc7_main(args) -> None:
     """BASELINE.json configs[3]: BC7 forward (+ inverse) on a synthetic mode-mixed buffer.  Same JSON contract; the
     transform is this build's own format (docs/BC7_FORMAT.md, version 2; the reference has none), so parity is a round
@@ -1372,6 +1387,7 @@ def main() -> None:
         scale = 1.0 if nbytes >= (4 << 30) else 0.01
         out["legs"]["corpus"] = run_corpus_leg(pkg, torch, dev, "bc1", args.leg_steps, 2, scale, cpu=not args.no_cpu_baseline)
         out["legs"]["corpus_bc3"] = run_corpus_leg(pkg, torch, dev, "bc3", args.leg_steps, 2, scale, cpu=not args.no_cpu_baseline)
+        attach_corpus_traffic(out["legs"])
         x = y = z = None
     host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
     if host_gib > 0 and not args.drop_blocks:

@@ -160,7 +160,7 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
     Shifts sh;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 63u);
+        sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 127u);
         sh.gbase[i] = en.gbase[i];
     }
     sh.xcd_remap = 0;
@@ -199,7 +199,7 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
     const uint64_t tiles = e.blocks / T, rest = e.blocks % T;
     // The tile forms of launch_transform: aligned tiles when every stream base is on a 128-byte line; otherwise forward halo
     // tiles (windows moved back to a 64-byte boundary) and inverse shifted tiles (slices displaced by the base modulo 16).
-    const uint64_t mask = inverse ? 15 : 63;
+    const uint64_t mask = inverse ? 15 : (uint64_t)(kHaloAlign - 1);
     bool on_lines = true, stream_tails = false;
     int d[6] = {0, 0, 0, 0, 0, 0}, halo_blocks = 0;
     for (int i = 0; i < S.n; ++i) {

@@ -804,8 +804,12 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
 // read-modify-write -- with 16-byte boundaries such lines had to meet in one L2 (XCD-contiguous tile order, itself worth
 // -0.04) or cost 0.08 (profiles/r02_b_shift_probe.txt).  The halo grows to at most 63 bytes per stream = at most 63
 // blocks for a 1-byte stream; only as many vectors as some stream needs are fetched (Shifts::halo_vecs).
-constexpr int kHaloBlocks = 64;
-constexpr int kHaloPad = 64;   // bytes between the stream regions of the LDS image: room for d_s
+#ifndef DXTLT_HALO_ALIGN
+#define DXTLT_HALO_ALIGN 64   // experiment: 128 = windows on 128-byte lines (no line shared between tiles, halo up to 127 bytes per stream)
+#endif
+constexpr int kHaloAlign = DXTLT_HALO_ALIGN;
+constexpr int kHaloBlocks = kHaloAlign;
+constexpr int kHaloPad = kHaloAlign;   // bytes between the stream regions of the LDS image: room for d_s
 template <int FMT>
 constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, 256) + kHaloBlocks) + kHaloPad * 6; }
 
@@ -937,7 +941,7 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
         const u32x4 qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
         scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
     }
-    static_assert(HV <= 64, "the halo is loaded by lanes of wave 0");
+    static_assert(HV <= 256, "the halo is loaded by the first lanes of the workgroup");
     scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
     __syncthreads();
 
@@ -1074,8 +1078,9 @@ __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ a
     case 2: halo_copy_out_wave<FMT, SA, SC, 2, true>(soa, lds, t, gb, sh, vlo, vhi); break;
     default: halo_copy_out_wave<FMT, SA, SC, 3, true>(soa, lds, t, gb, sh, vlo, vhi); break;
     }
-    if (t < 4 * S.n) {   // up to 63 bytes of a stream lie behind its window: four more segments per stream
-        const EdgeSlot e = edge_slot_behind_window<FMT, SA, SC, T, T + H, kHaloPad, H>(t >> 2, t & 3, sh, gb);
+    constexpr int XS = kHaloAlign / 16;   // up to kHaloAlign - 1 bytes of a stream lie behind its window: XS more segments per stream
+    if (t < XS * S.n) {
+        const EdgeSlot e = edge_slot_behind_window<FMT, SA, SC, T, T + H, kHaloPad, H>(t / XS, t % XS, sh, gb);
         int hi_s = 0;
 #pragma unroll
         for (int s = 0; s < 6; ++s)

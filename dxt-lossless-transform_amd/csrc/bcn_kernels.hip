@@ -264,7 +264,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         for (int i = 0; i < S.n; ++i) {
             const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
                                   (uint64_t)S.width[i] * r.first_block;
-            shh.d[i] = (int)(base & 63);
+            shh.d[i] = (int)(base & (uint64_t)(kHaloAlign - 1));
             halo_blocks = std::max(halo_blocks, (shh.d[i] + S.width[i] - 1) / S.width[i]);
         }
         fill_gbase(shh, S, r.total_blocks, r.first_block);
@@ -294,7 +294,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         if (count == 0)
             return hipSuccess;
         Shifts e{};
-        const int mask = inverse ? 15 : 63;
+        const int mask = inverse ? 15 : kHaloAlign - 1;
         for (int i = 0; i < S.n; ++i) {
             const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
                                   (uint64_t)S.width[i] * (r.first_block + local_first);

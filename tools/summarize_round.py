@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/<round>_final (tools/r03_measure.sh) into profiles/<tag>_*:
+"""Condenses gpurun_out/<round>_final (tools/r03_measure.sh, ROUND=r04 for round 4) into profiles/<tag>_*:
 
     python tools/summarize_round.py r03_z [r03_final]
 
@@ -34,9 +34,30 @@ def one(pattern):
     return hits[-1]
 
 
+def corpus_bytes():
+    """block bytes of the corpus legs of the profiled bench line (the batch kernel's grid holds edge tiles: its bytes are the leg's)"""
+    try:
+        with open(os.path.join(src, "prof_kt.json")) as f:
+            legs = json.loads([l for l in f if l.startswith('{"metric"')][0]).get("legs", {})
+        return {1: legs.get("corpus", {}).get("bytes"), 3: legs.get("corpus_bc3", {}).get("bytes")}
+    except (OSError, ValueError, IndexError):
+        return {}
+
+
+CORPUS = None
+
+
 def launch_bytes(name, grid_threads, wg):
     """algorithmic bytes of one launch: read + write of the blocks its grid covers; None for kernels that are not a leg"""
+    global CORPUS
     wgs = grid_threads // wg
+    m = re.search(r"batch_kernel<(\d),", name)
+    if m:
+        if CORPUS is None:
+            CORPUS = corpus_bytes()
+        b = CORPUS.get(int(m.group(1)))
+        # the corpus legs' launches: one 4 KiB tile per workgroup but for a buffer's last one
+        return 2 * b if b and abs(wgs * 4096 - b) < b // 100 else None
     if re.search(r"(fwd|inv)_tiled<", name):
         return 2 * wgs * wg * 16            # one 16-byte vector per lane
     if re.search(r"bc7_(forward|inverse)<", name):
@@ -105,9 +126,15 @@ def find(pattern, alg):
 
 
 # per-launch HBM bytes of the legs' kernels (bench.py attaches them to `legs.*.roofline.traffic`, labelled as a committed pass)
+CB = CORPUS or corpus_bytes()
 leg_traffic = {
     "bc3": {"bytes": 8 << 30, "fwd": find("fwd_tiled<3, 1, true, true", 2 * (8 << 30)), "inv": find("inv_tiled<3, 1, true, true", 2 * (8 << 30))},
+    "bc2": {"bytes": 8 << 30, "fwd": find("fwd_tiled<2, 1, false, true", 2 * (8 << 30)), "inv": find("inv_tiled<2, 1, false, true", 2 * (8 << 30))},
     "bc7": {"bytes": 4 << 30, "fwd": find("bc7_forward<", 2 * (4 << 30)), "inv": find("bc7_inverse<", 2 * (4 << 30))},
+    "corpus": {"bytes": CB.get(1), "fwd": find("batch_kernel<1, 1, false, true, false>", 2 * (CB.get(1) or 0)),
+               "inv": find("batch_kernel<1, 1, false, true, true>", 2 * (CB.get(1) or 0))},
+    "corpus_bc3": {"bytes": CB.get(3), "fwd": find("batch_kernel<3, 1, true, true, false>", 2 * (CB.get(3) or 0)),
+                   "inv": find("batch_kernel<3, 1, true, true, true>", 2 * (CB.get(3) or 0))},
     "archive_texture": {"bytes": 256 << 20,
                         "bc1_fwd": find("fwd_tiled<1, 1, false, true", 2 * (256 << 20)), "bc1_inv": find("inv_tiled<1, 1, false, true", 2 * (256 << 20)),
                         "bc3_fwd": find("fwd_tiled<3, 1, true, true", 2 * (256 << 20)), "bc3_inv": find("inv_tiled<3, 1, true, true", 2 * (256 << 20))},
