@@ -1,0 +1,74 @@
+"""Two properties of the gfx950 code that cost 0.03-0.08 of peak when the compiler drops them -- and it did, silently, when the
+code AROUND the hot path changed (profiles/r04_batch_edge_tiles.txt).  Checked on the device assembly hipcc emits (cross-compiled
+here, no GPU needed), for the default-settings kernels of the batch path:
+
+  * wave 0 of an inverse shifted tile issues its main load and its tail load back to back: no `s_waitcnt vmcnt` between them
+    (with one, every workgroup waits out a memory round trip before asking for its tail segments: BC3 inverse 0.77 -> 0.70);
+  * the batch kernel's table lookup fetches every field of its entry in ONE group of scalar loads (no scalar load between the
+    entry's first wait and the tile's first vector load except inside the rare walk loop)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "dxt-lossless-transform_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def batch_asm():
+    src = os.path.join(CSRC, "batch_kernels.hip")
+    out = os.path.join(ROOT, "build", "isa", "batch_kernels.s")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            pytest.skip("no hipcc")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "--cuda-device-only", "-S", src,
+                               "-o", out + ".tmp", "-Wno-unused-command-line-argument"], cwd="/tmp")
+        os.replace(out + ".tmp", out)
+    return open(out).read()
+
+
+def kernel_body(asm: str, mangled_fragment: str) -> list:
+    m = re.search(r"^(_ZN5dxtlt12batch_kernel" + re.escape(mangled_fragment) + r"\w*):\s*(?:;.*)?$", asm, re.M)
+    assert m, mangled_fragment
+    body = asm[m.end():]
+    body = body[:body.index(".Lfunc_end")]
+    return [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
+
+
+@pytest.mark.parametrize("kernel", ["ILi3ELi1ELb1ELb1ELb1E", "ILi1ELi1ELb0ELb1ELb1E"])   # BC3 / BC1 default settings, inverse
+def test_wave0_of_the_inverse_shifted_tile_issues_both_loads_before_it_waits(batch_asm, kernel):
+    lines = kernel_body(batch_asm, kernel)
+    nt_loads = [i for i, l in enumerate(lines) if l.startswith("global_load_dwordx4") and l.endswith(" nt")]
+    assert len(nt_loads) >= 2
+    back_to_back = 0
+    for a, b in zip(nt_loads, nt_loads[1:]):
+        between = lines[a + 1:b]
+        if not any(l.startswith("s_waitcnt vmcnt") or l.startswith("s_barrier") or l.startswith("s_endpgm") for l in between):
+            back_to_back += 1
+    assert back_to_back >= 1, "no two nt loads without a vmcnt wait between them: wave 0's main and tail loads are serialised"
+
+
+@pytest.mark.parametrize("kernel", ["ILi3ELi1ELb1ELb1ELb0E", "ILi3ELi1ELb1ELb1ELb1E", "ILi1ELi1ELb0ELb1ELb0E"])
+def test_batch_lookup_fetches_the_whole_entry_at_once(batch_asm, kernel):
+    """Behind the index loads (the only scalar loads with a register offset) the entry arrives as one group of loads followed by
+    one wait; the next scalar load may only be the walk loop's."""
+    lines = kernel_body(batch_asm, kernel)
+    idx = [i for i, l in enumerate(lines) if l.startswith("s_load_dword ") and re.search(r", s\d+ offset:", l)]
+    assert len(idx) == 2, idx                       # base[wg / 4096] and the dword of delta[wg / 64], issued together
+    assert not any(l.startswith("s_waitcnt") for l in lines[idx[0] + 1:idx[1]])
+    wait = next(i for i in range(idx[1], len(lines)) if lines[i].startswith("s_waitcnt lgkmcnt(0)"))
+    group = []
+    i = wait + 1
+    while not lines[i].startswith("s_waitcnt lgkmcnt(0)"):
+        if lines[i].startswith("s_load"):
+            group.append(lines[i])
+        i += 1
+    bytes_loaded = sum(4 * int(re.match(r"s_load_dword(x(\d+))?", l).group(2) or 1) for l in group)
+    # sizeof(BatchEntry) = 96, of which a format with three streams needs 72 (the bases of streams it does not have are dead):
+    # nothing the tile needs is left for a later round trip
+    assert 72 <= bytes_loaded <= 96, (bytes_loaded, group)
