@@ -50,7 +50,8 @@ extern "C" {
 #define DXTLT_E_NO_DEVICE 3        /* no usable HIP device */
 #define DXTLT_E_DEVICE 4           /* HIP runtime error (allocation, copy, launch) */
 #define DXTLT_E_ESTIMATOR 5        /* a size-estimator callback returned non-zero (auto transform) */
-#define DXTLT_E_ALLOCATION 6       /* host allocation of the estimator scratch buffer failed */
+#define DXTLT_E_ALLOCATION 6       /* a host resource ran out: the estimator's scratch buffer, or a worker thread the call could not
+                                      start (batch_host, the sharded calls: everything already started is joined first) */
 
 /* YCoCgVariant, core numbering */
 #define DXTLT_YCOCG_NONE 0
@@ -200,7 +201,9 @@ int32_t dxtlt_sharded_last_stats(DxtltShardStat *out, int32_t cap);
 /* ---- NUMA placement of the library's own host threads -------------------------------------------
  * Every worker thread dxtlt_transform_sharded (and the BC7 sharded calls) starts for a device binds itself to the CPUs
  * the kernel lists as local to that device's PCI function, intersected with the CPUs the process may use; the threads of
- * the caller are never touched.  DXTLT_NUMA_BIND=0 switches it off.  The three helpers are exported so that a host
+ * the caller are never touched.  DXTLT_NUMA_BIND=0 switches it off.  A sharded call brings the HIP runtime up for the
+ * devices it uses on the CALLER's thread before it starts a worker: threads the runtime creates lazily would otherwise be
+ * born from a worker and keep its narrowed mask for the life of the process.  The three helpers are exported so that a host
  * program can place its own feeder threads -- and its first touch of the arrays -- the same way.
  * dxtlt_pci_local_cpulist: pure host code; reads <sysfs>/bus/pci/devices/<bdf>/local_cpulist (or numa_node -> node
  * cpulist), <sysfs> = $DXTLT_SYSFS_ROOT or /sys; writes e.g. "0-63,128-191" and returns its length, 0 when unknown.
