@@ -1092,7 +1092,7 @@ def pcie_pair_ceiling(torch, dev, nbytes: int = 1 << 30, reps: int = 3) -> dict:
             "what": "one pinned H2D and one pinned D2H hipMemcpyAsync of 1 GiB each on two streams of the same device, best of 3"}
 
 
-def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, want_devices: int) -> dict:
+def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, want_devices: int, ceiling=None) -> dict:
     """north_star's multi-GPU statement as ONE call: a host-resident block array is split by contiguous block range over
     every visible device and each shard's slice of every stream lands at its final host offset (dxtlt_transform_sharded;
     the reference side of the contract is one call over the whole array, transform_with_settings.rs:31-72).  Host
@@ -1187,7 +1187,8 @@ def sharded_host_array(pkg, torch, fmt, settings, nbytes: int, seed: int, dev, w
     assert ok, "sharded host array: result differs from the oracle / round trip failed"
     # the link's own ceiling, same run, same device: a sharded call moves every byte up and every byte down, both directions busy
     try:
-        ceiling = pcie_pair_ceiling(torch, dev, min(1 << 30, max(nbytes, 1 << 20)))
+        if ceiling is None:
+            ceiling = pcie_pair_ceiling(torch, dev, min(1 << 30, max(nbytes, 1 << 20)))
         peak = ceiling["concurrent_GiBps_per_direction"]
         for row in per_device:
             row["roofline"] = {"bound": "pcie", "unit": "GiB/s per direction", "peak": peak,
@@ -1253,6 +1254,18 @@ def main() -> None:
         blocks = size_bytes // block
         total_blocks, first = blocks * world, rank * blocks
     nbytes = blocks * block
+
+    # The link's ceiling for the host-array leg is taken FIRST, while the host is as the process found it: measured at the end
+    # of a full run -- 24 GiB of host arrays first-touched next to the device, the legs' CPU baselines behind it -- the same
+    # pinned pair lands on far memory and reads 27 instead of 45 GiB/s per direction (profiles/r04_channel_map.txt, item 4).
+    host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
+    ceiling = None
+    if rank == 0 and host_gib > 0 and not args.drop_blocks:
+        try:
+            ceiling = pcie_pair_ceiling(torch, dev, min(1 << 30, max(int(host_gib * (1 << 30)), 1 << 20)))
+            ceiling["when"] = "first thing in the run"
+        except Exception as e:  # noqa: BLE001
+            ceiling = {"error": f"{type(e).__name__}: {e}"}
 
     x = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     z = torch.empty_like(x)
@@ -1407,13 +1420,13 @@ def main() -> None:
         out["legs"]["corpus_bc3"] = run_corpus_leg(pkg, torch, dev, "bc3", args.leg_steps, 2, scale, cpu=not args.no_cpu_baseline)
         attach_corpus_traffic(out["legs"])
         x = y = z = None
-    host_gib = args.host_array_gib if args.host_array_gib is not None else min(args.size_gib, 8.0)
     if host_gib > 0 and not args.drop_blocks:
         del y, z
         torch.cuda.empty_cache()
         # an extra leg beside `value`: if it cannot run (a device this rank may not open, host memory), say so and keep the line
         try:
-            out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev, world)
+            out["sharded_host_array"] = sharded_host_array(pkg, torch, fmt, settings, int(host_gib * (1 << 30)), seed, dev, world,
+                                                           ceiling if ceiling and "error" not in ceiling else None)
         except Exception as e:  # noqa: BLE001
             out["sharded_host_array"] = {"error": f"{type(e).__name__}: {e}"}
     R.cpu_barrier()
