@@ -206,3 +206,22 @@ def test_eight_rank_rendezvous_the_driver_shape():
     # real N > 1 line carries so that the first SCALE record shows stragglers and proves the group saw N ranks
     assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 8, "max_over_ranks": 8.0, "backend": "gloo",
                                     "world_size_seen": 8, "per_rank": [[float(r + 1), float(10 * r)] for r in range(8)]}
+
+
+def test_corpus_leg_has_the_shape_of_the_references_published_benchmark():
+    """legs.corpus rebuilds the reference's own benchmark shape (api/dxt-lossless-transform-bc1-api/README.MD:286-311: "2130
+    real files (8692.9 MiB)" of BC1 DDS textures): 2130 textures with full mip chains whose block bytes add up to 8692.9 MiB,
+    every block count odd (the 4 + 1 + 1 + 1 blocks of the 8x8 .. 1x1 levels), laid out at 256-byte boundaries."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.mip_chain_blocks(4, 4) == 1 + 1 + 1                      # 4x4, 2x2, 1x1: a block each
+    assert bench.mip_chain_blocks(256, 256) == (4 ** 7 - 1) // 3 + 2      # 64^2 + 32^2 + ... + 1, + the 2x2 and 1x1 levels
+    assert bench.mip_chain_blocks(4096, 2048) == 699053
+    texs = bench.corpus_textures()
+    assert len(texs) == 2130 and all(n % 2 == 1 for _, _, n in texs)
+    assert round(sum(n for _, _, n in texs) * 8 / 2**20, 1) == 8692.9
+    assert texs != sorted(texs, key=lambda t: t[2])                       # a directory walk, not a size-sorted list
+    offs, arena = bench.corpus_layout(texs, 8)
+    assert all(o % 256 == 0 for o in offs) and arena >= sum(n for _, _, n in texs) * 8
+    assert all(b - a >= n * 8 for (a, b), (_, _, n) in zip(zip(offs, offs[1:] + [arena]), texs))
