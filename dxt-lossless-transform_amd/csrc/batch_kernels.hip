@@ -56,6 +56,10 @@ __device__ __forceinline__ BatchView load_batch_entry(const BatchEntry* entry)
 }
 __device__ __forceinline__ void pin_batch_view(BatchView& v)
 {
+#ifdef DXTLT_WG_TIMING
+    (void)v;   // (the experiment build's stores to its timing array make the table loads vector loads: nothing to pin)
+    return;
+#endif
     uint64_t s = reinterpret_cast<uintptr_t>(v.src), d = reinterpret_cast<uintptr_t>(v.dst);
     asm("" : "+s"(s), "+s"(d), "+s"(v.blocks));
     v.src = (const uint8_t*)(global_cptr)s;
@@ -87,6 +91,33 @@ struct StridedBatch {
     uint32_t on;
 };
 
+#ifdef DXTLT_WG_TIMING
+// EXPERIMENT build only (tools/wg_timing_probe.py): per workgroup {100 MHz ticks from its first instruction to the acknowledgement of
+// its last store, kind of tile, start tick (low 32 bits), XCC id}
+__device__ uint32_t g_wg_timing[4 << 20];
+extern "C" int dxtlt_debug_read_wg_timing(uint32_t* out, size_t count)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timing), count * 4);
+}
+#define WG_TIMING_BEGIN const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
+#define WG_TIMING_END(kind)                                                                         \
+    do {                                                                                            \
+        __builtin_amdgcn_s_waitcnt(0);                                                              \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+        if (threadIdx.x == 0 && blockIdx.x < (1u << 20)) {                                          \
+            uint32_t xcc;                                                                           \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                       \
+            g_wg_timing[4 * blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);   \
+            g_wg_timing[4 * blockIdx.x + 1] = (kind);                                               \
+            g_wg_timing[4 * blockIdx.x + 2] = (uint32_t)t_begin;                                    \
+            g_wg_timing[4 * blockIdx.x + 3] = xcc & 0xF;                                            \
+        }                                                                                           \
+    } while (0)
+#else
+#define WG_TIMING_BEGIN
+#define WG_TIMING_END(kind)
+#endif
+
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
 __global__ void __launch_bounds__(256)
 batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restrict__ index_arg, uint32_t n_base, uint32_t uniform_wgs,
@@ -95,15 +126,19 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
     constexpr int kLds = INVERSE ? kShiftLdsBytes : halo_lds_bytes<FMT>();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
     const uint32_t wg = blockIdx.x;
+    WG_TIMING_BEGIN
     BatchView en;
+    uint32_t e;   // index of the buffer in its launch
     // both table pointers in the FIRST scalar round trip (the compiler otherwise fetches `index` on the path that uses it, behind
     // the first wait); through integers: see fetched_now
     uint64_t entries_at = reinterpret_cast<uintptr_t>(entries_arg), index_at = reinterpret_cast<uintptr_t>(index_arg);
+#ifndef DXTLT_WG_TIMING
     asm("" : "+s"(entries_at), "+s"(index_at), "+s"(n_base), "+s"(uniform_wgs), "+s"(magic));
+#endif
     const BatchEntry* entries = (const BatchEntry*)(const __attribute__((address_space(1))) BatchEntry*)entries_at;
     const uint8_t* index = (const uint8_t*)(global_cptr)index_at;
     if (uniform_wgs != 0) {
-        uint32_t e = __umulhi(wg, magic);
+        e = __umulhi(wg, magic);
         if ((e + 1) * uniform_wgs <= wg)
             ++e;
         if (strided.on != 0) {
@@ -135,7 +170,7 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
         // workgroups, a cache line per 4096 -- and the entry, shared by all workgroups of its buffer, is what is fetched behind it.
         const uint32_t* base = reinterpret_cast<const uint32_t*>(index);
         const uint8_t* delta = index + n_base * 4;
-        uint32_t e = base[wg >> 12];
+        e = base[wg >> 12];
         const uint32_t dword = reinterpret_cast<const uint32_t*>(delta)[wg >> 8];   // (a scalar load is a dword load)
         e += (dword >> (8u * ((wg >> 6) & 3u))) & 0xFFu;
         en = load_batch_entry(entries + e);
@@ -147,7 +182,18 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
             en = load_batch_entry(entries + e);
         }
     }
-    const uint32_t local = wg - en.first_wg;
+    // Which of the buffer's tiles this workgroup takes.  Workgroups go to the eight XCDs round robin (wg % 8), and an edge tile
+    // takes 1.2-1.9 x a whole tile's time (tools/wg_timing_probe.py): with buffers of 8 k workgroups each, launch order would put
+    // EVERY buffer's last tile on one and the same XCD, which then runs 10 % behind the other seven -- the tail that made 4096
+    // x (256 KiB - 1 block) run at 0.60 where 4096 x 16407 blocks (65 workgroups per buffer) ran at 0.71, and that round 3
+    // built in by padding every buffer to a multiple of 8 workgroups (profiles/r04_batch_edge_tiles.txt section 7).  So the
+    // buffer's tiles are rotated by r, chosen so that buffer e's last tile runs on XCD e % 8 (and its tile 0 on (e + 1) % 8).
+    const uint32_t n_wgs = en.end_wg - en.first_wg;
+    uint32_t local = wg - en.first_wg;
+    if (n_wgs >= 8) {
+        local += (en.first_wg + n_wgs - 1u - e) & 7u;
+        local = local >= n_wgs ? local - n_wgs : local;
+    }
     const bool aligned = (en.flags & 0xFF) == kBatchAligned;
     if (aligned && local < en.full_tiles) {
         // every stream base on a 128-byte line: the aligned tile, tiles in launch order (as the single-buffer call runs it)
@@ -155,6 +201,7 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
             inv_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
         else
             fwd_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+        WG_TIMING_END(1);
         return;
     }
     Shifts sh;
@@ -173,17 +220,23 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
     if constexpr (INVERSE) {
         if (local >= en.full_tiles) {
             inv_shift_edge_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, sh, en.full_tiles, lds);
+            WG_TIMING_END(4);
         } else {
             // Neighbouring tiles share 128-byte lines: consecutive tiles stay on one XCD (xcd_contiguous_tile).  Workgroup
-            // residues mod 8 are XCDs whatever the buffer's first workgroup is: equal residues of `local` meet on one XCD.
+            // residues mod 8 are XCDs whatever the buffer's first workgroup and rotation are: equal residues of `local` meet on
+            // one XCD (but for the few workgroups the rotation wraps around).
             const uint64_t tile = xcd_contiguous_tile(local, en.full_tiles);
             inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
+            WG_TIMING_END(2);
         }
     } else {
-        if (local == 0 || local >= en.full_tiles)
+        if (local == 0 || local >= en.full_tiles) {
             fwd_halo_edge_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, sh, local, lds);
-        else
+            WG_TIMING_END(local == 0 ? 3 : 4);
+        } else {
             fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+            WG_TIMING_END(2);
+        }
     }
 }
 
