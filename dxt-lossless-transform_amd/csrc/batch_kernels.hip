@@ -99,6 +99,10 @@ extern "C" int dxtlt_debug_read_wg_timing(uint32_t* out, size_t count)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_timing), count * 4);
 }
+extern "C" int dxtlt_debug_read_wg_marks(uint32_t* out, size_t count)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dxtlt::g_wg_marks), count * 4);
+}
 #define WG_TIMING_BEGIN const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
 #define WG_TIMING_END(kind)                                                                         \
     do {                                                                                            \

@@ -35,6 +35,27 @@ constexpr int default_tile_threads(int fmt, bool inverse)
 #define DXTLT_NONTEMPORAL 1
 #endif
 
+#ifdef DXTLT_WG_TIMING
+// EXPERIMENT build only (tools/wg_timing_probe.py, tools/wg_phase_single.py; built by DXTLT_EXTRA_HIPCC_FLAGS=-DDXTLT_WG_TIMING
+// tools/ab_build_rev.sh WORKTREE timing): phase marks of lane 0 of every workgroup, 100 MHz ticks (low 32 bits).  Slot 0: kernel
+// start (single-buffer aligned kernels), 1: the tile begins, 2: its loads have arrived, 3: behind the barrier, 4: stores issued.
+__device__ uint32_t g_wg_marks[8 << 20];
+__device__ __forceinline__ void wg_mark(int i)
+{
+    if (threadIdx.x == 0 && blockIdx.x < (1u << 20))
+        g_wg_marks[8 * blockIdx.x + i] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+}
+#define WG_MARK(i) wg_mark(i)
+#define WG_MARK_LOADS_DONE(i)                                  \
+    do {                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
+        wg_mark(i);                                            \
+    } while (0)
+#else
+#define WG_MARK(i)
+#define WG_MARK_LOADS_DONE(i)
+#endif
+
 __device__ __forceinline__ u32x4 gload16(const void* p)
 {
 #if DXTLT_NONTEMPORAL
@@ -259,12 +280,16 @@ __device__ __forceinline__ void fwd_aligned_tile(const uint8_t* __restrict__ aos
 {
     constexpr int T = tile_blocks(FMT, THREADS);
     const int t = threadIdx.x;
+    WG_MARK(1);
     const u32x4 q = normalize_vector<FMT, NORM>(gload16(aos + tile * (THREADS * 16) + t * 16));
+    WG_MARK_LOADS_DONE(2);
     scatter_to_image<FMT, VARIANT, SA, SC, T>(lds, t, q);
     __syncthreads();
+    WG_MARK(3);
     const u32x4 v = lds_at<u32x4>(lds, t * 16);
     const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
     gstore16(soa + o, v);
+    WG_MARK(4);
 }
 
 template <int FMT, int VARIANT, bool SA, bool SC, int THREADS>
@@ -286,6 +311,7 @@ fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t t
           int xcd_remap, int64_t aos_stride, int64_t soa_stride)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[THREADS * 16];
+    WG_MARK(0);
     if (xcd_remap & kTiledArray) {   // a regular array of buffers: blockIdx.y is the buffer (launch_batch)
         aos += (int64_t)blockIdx.y * aos_stride;
         soa += (int64_t)blockIdx.y * soa_stride;
@@ -930,6 +956,7 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     // a 63-block halo), a line fetched temporally is still in the memory-side cache.  Found by accident -- the compiler
     // merged an experiment's two loads and dropped the hint -- and worth 0.05-0.07 of peak on large halos
     // (profiles/r02_b_shift_probe.txt); on small halos it costs nothing.
+    WG_MARK(1);
     const u32x4 q = *reinterpret_cast<const u32x4*>(tile_aos + t * 16);
     // Only the blocks that have bytes inside a window are fetched: max over the streams of ceil(d_s / w_s) blocks, at
     // most 16 (the whole halo costs 0.02 of peak on BC3 -- 6 % more bytes read -- profiles/r02_b_shift_probe.txt).
@@ -942,8 +969,10 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
         scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
     }
     static_assert(HV <= 256, "the halo is loaded by the first lanes of the workgroup");
+    WG_MARK_LOADS_DONE(2);
     scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
     __syncthreads();
+    WG_MARK(3);
 
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
@@ -954,6 +983,7 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, none, none); break;
     default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, none, none); break;
     }
+    WG_MARK(4);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -405,6 +405,13 @@ hipError_t launch_tiled_array(Format fmt, bool inverse, const Settings& s, const
     return hipGetLastError();
 }
 
+#ifdef DXTLT_WG_TIMING
+extern "C" int dxtlt_debug_read_wg_marks_single(uint32_t* out, size_t count)   // experiment build: bcn_device.h, WG_MARK
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_marks), count * 4);
+}
+#endif
+
 // Table upload by a kernel: the lanes read the pinned host table over PCIe and write the device twin.  A copy engine
 // transfer in front of the batch kernel costs the stream two queue hand-overs (20-90 us measured per call, more than a
 // quarter of a 1 GiB batch's kernel time); kernel after kernel on one queue is a barrier bit.

@@ -6,21 +6,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import dxt_lossless_transform_amd as pkg
 from dxt_lossless_transform_amd import batch, _lib
-fmt, count, blocks, stride = os.environ.get("PROBE_CASE", "bc3:4096:16383:262144").split(":")
-count, blocks, stride = int(count), int(blocks), int(stride)
+case = os.environ.get("PROBE_CASE", "bc3:4096:16383:262144").split(":")
 inverse = os.environ.get("PROBE_INVERSE", "0") == "1"
-B = 8 if fmt == "bc1" else 16
-st = pkg.Bc1TransformSettings() if fmt == "bc1" else pkg.Bc3TransformSettings()
-n = blocks * B
 dev = torch.device("cuda:0")
-big = torch.empty(count * stride, dtype=torch.uint8, device=dev); pkg.fill_splitmix64(big, 5)
-outb = torch.empty_like(big)
-prep = batch.prepare_batch([(fmt, inverse, big[i * stride:i * stride + n], outb[i * stride:i * stride + n], st) for i in range(count)])
+if case[0] == "corpus":          # corpus:<fmt>:<scale>: bench.py's corpus textures (a fraction of them: the timing array holds 2^20 workgroups)
+    import bench
+    fmt, scale = case[1], float(case[2])
+    B = 8 if fmt == "bc1" else 16
+    st = pkg.Bc1TransformSettings() if fmt == "bc1" else pkg.Bc3TransformSettings()
+    texs = bench.corpus_textures(scale)
+    if fmt != "bc1":
+        texs = texs[::2]
+    offs, arena = bench.corpus_layout(texs, B)
+    big = torch.empty(arena, dtype=torch.uint8, device=dev); pkg.fill_splitmix64(big, 5)
+    outb = torch.empty_like(big)
+    prep = batch.prepare_batch([(fmt, inverse, big[o:o + n * B], outb[o:o + n * B], st) for (_, _, n), o in zip(texs, offs)])
+    wgs = min(1 << 20, sum((n * B + 4095) // 4096 + 1 for _, _, n in texs))
+else:
+    fmt, count, blocks, stride = case[0], int(case[1]), int(case[2]), int(case[3])
+    B = 8 if fmt == "bc1" else 16
+    st = pkg.Bc1TransformSettings() if fmt == "bc1" else pkg.Bc3TransformSettings()
+    n = blocks * B
+    big = torch.empty(count * stride, dtype=torch.uint8, device=dev); pkg.fill_splitmix64(big, 5)
+    outb = torch.empty_like(big)
+    prep = batch.prepare_batch([(fmt, inverse, big[i * stride:i * stride + n], outb[i * stride:i * stride + n], st) for i in range(count)])
+    wgs = min(1 << 20, count * ((blocks + (4096 // B) - 1) // (4096 // B) + 1))
 for _ in range(20):
     batch.run_prepared_batch(prep)
 torch.cuda.synchronize()
 lib = _lib.load()
-wgs = min(1 << 20, count * ((blocks + (4096 // B) - 1) // (4096 // B) + 1))
 buf = np.zeros(4 * wgs, dtype=np.uint32)
 lib.dxtlt_debug_read_wg_timing.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert lib.dxtlt_debug_read_wg_timing(buf.ctypes.data, buf.size) == 0
@@ -50,3 +64,19 @@ if k4.size:
     nxt = k4[k4 + 1 < starts_us.size] + 1
     print(f"  gap in front of the workgroup that follows an end edge tile: mean {np.mean(starts_us[nxt] - starts_us[nxt - 1]) * 1000:.1f} ns")
 print("  workgroups per XCC:", np.bincount(xcc[live]).tolist())
+print("  sum of workgroup durations per XCC (ms):", [round(float(t[live][xcc[live] == x].sum()) / 1000, 2) for x in range(8)])
+
+# phase marks of lane 0 (experiment build): 1 = lookup done / tile starts, 2 = loads arrived, 3 = behind the barrier, 4 = stores issued
+marks = np.zeros(8 * wgs, dtype=np.uint32)
+if hasattr(lib, "dxtlt_debug_read_wg_marks"):
+    lib.dxtlt_debug_read_wg_marks.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    if lib.dxtlt_debug_read_wg_marks(marks.ctypes.data, marks.size) == 0:
+        m = marks.reshape(-1, 8).astype(np.int64)
+        for k in (1, 2):
+            sel = (kind == k) & (m[:, 1] != 0)
+            if not sel.any():
+                continue
+            st0 = start[sel]
+            ph = [((m[sel, i] - st0) & 0xFFFFFFFF) * 0.01 for i in (1, 2, 3, 4)]
+            total = t[sel]
+            print(f"  {names[k]}: start -> tile begins {ph[0].mean():.2f} us -> loads arrived {ph[1].mean():.2f} -> behind the barrier {ph[2].mean():.2f} -> stores issued {ph[3].mean():.2f} -> all acknowledged {total.mean():.2f}")
