@@ -1135,6 +1135,7 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos_arg, uint8_t* __restrict__ soa_ar
                Shifts sh_arg)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
+    WG_MARK(0);
     const uint32_t wg = blockIdx.x;
     const Shifts sh = shifts_fetched_at_once(sh_arg);
     const uint8_t* __restrict__ aos = fetched_now(aos_arg);
