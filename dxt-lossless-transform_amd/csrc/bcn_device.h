@@ -400,13 +400,10 @@ __device__ __forceinline__ uint8_t* fetched_now(uint8_t* p)
 __device__ __forceinline__ Shifts shifts_fetched_at_once(const Shifts& in)
 {
     Shifts s = in;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        asm("" : "+s"(s.d[i]));
-        asm("" : "+s"(s.gbase[i]));
-    }
-    asm("" : "+s"(s.xcd_remap), "+s"(s.line_policy), "+s"(s.skip_partial), "+s"(s.natural), "+s"(s.halo_vecs), "+s"(s.full_tiles));
-    asm("" : "+s"(s.range_blocks));
+    // ONE statement: with several, the compiler fetches what the first one needs, waits, and only then asks for the next one's
+    asm("" : "+s"(s.d[0]), "+s"(s.d[1]), "+s"(s.d[2]), "+s"(s.d[3]), "+s"(s.d[4]), "+s"(s.d[5]), "+s"(s.gbase[0]), "+s"(s.gbase[1]),
+             "+s"(s.gbase[2]), "+s"(s.gbase[3]), "+s"(s.gbase[4]), "+s"(s.gbase[5]), "+s"(s.xcd_remap), "+s"(s.line_policy),
+             "+s"(s.skip_partial), "+s"(s.natural), "+s"(s.halo_vecs), "+s"(s.full_tiles), "+s"(s.range_blocks));
     return s;
 }
 
