@@ -970,7 +970,11 @@ void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
 {
     g_tile_threads.store(tile_threads);
     // bits 8..9 of force_path carry the XCD-remap experiment switch: 0x100 = off, 0x200 = on, 0 = default
-    g_force_generic.store(force_generic & 0x1CFF);  // 0x400: first form of the forward shifted tiles (no halo)
+    // 0x10 leaves the partial segments / the halo out -- a TIMING experiment with wrong output: only honoured when the process
+    // asked for it in its environment, so that no caller of a shipped library can switch correctness off by an argument
+    static const bool timing_experiments = std::getenv("DXTLT_TIMING_EXPERIMENTS") != nullptr;
+    const int32_t allowed = timing_experiments ? 0x1CFF : (0x1CFF & ~0x10);
+    g_force_generic.store(force_generic & allowed);  // 0x400: first form of the forward shifted tiles (no halo)
     g_xcd_remap.store((force_generic & 0x100) ? 0 : (force_generic & 0x200) ? 1 : -1);
 }
 

@@ -232,7 +232,9 @@ int32_t dxtlt_device_count(void);
 size_t dxtlt_host_route_threshold_bytes(void);
 void dxtlt_set_host_route_threshold_bytes(size_t bytes);
 /* Knobs for experiments and tests.  tile_threads: 64/128/256/512 (0 = per-format default).
- * force_path: 0 = automatic, 1 = always the element-granular kernel, 2 = always the shifted-tile kernel.
+ * force_path: 0 = automatic, 1 = always the element-granular kernel, 2 = always the shifted-tile kernel; higher bits are
+ * the experiment switches that csrc/bcn_kernels.hip documents where it reads them (every one of them leaves the results
+ * exact, except 0x10 -- a timing experiment -- which is ignored unless DXTLT_TIMING_EXPERIMENTS is set in the environment).
  * Process-wide. */
 void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path);
 /* "dxtlt-gfx950 <version>" */

@@ -225,6 +225,25 @@ def test_forward_shifted_tiles_both_forms(pkg, oracle, dev, fmt):
             pkg.set_tuning(0, 0)
 
 
+def test_timing_experiment_switch_is_inert_without_its_environment_variable(pkg, oracle, dev):
+    """Bit 0x10 of dxtlt_set_tuning's force_path leaves the halo / the partial segments out (a timing experiment with wrong
+    output).  A library call must not be able to switch correctness off: the bit is honoured only when
+    DXTLT_TIMING_EXPERIMENTS was in the environment when the library first read it."""
+    import os
+    if os.environ.get("DXTLT_TIMING_EXPERIMENTS") is not None:
+        pytest.skip("the timing experiments are switched on in this environment")
+    for fmt in FORMATS:
+        n = 9 * TILE[fmt] + 7
+        x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x71E + n)
+        s = next(iter(all_settings(fmt)))
+        try:
+            for force in (0x10, 0x10 | 0x400, 0x10 | 2):
+                pkg.set_tuning(0, force)
+                assert np.array_equal(run_device(pkg, fmt, x, s, dev), fwd_oracle(oracle, fmt, x, s)), (fmt, hex(force))
+        finally:
+            pkg.set_tuning(0, 0)
+
+
 def test_no_write_past_the_end(pkg, oracle, dev):
     """Stream sections are adjacent in one buffer: a wide store of one stream must never spill into the next
     (SURVEY.md 2, AVX-512 crib) nor past the end of the output."""

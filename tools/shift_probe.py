@@ -3,6 +3,7 @@ odd-block-count cost is the kernel's own structure and which is misalignment.  f
 aligned, 0x20 = generic (switch per access) LDS scatter/gather, 0x40 = no write-through on whole lines, 0x10 = partial segments left out (timing only), 0x100 / 0x200 = XCD-contiguous
 tile order off / on.  PROBE_ONLY=<substring> selects cases."""
 import json, sys, os
+os.environ.setdefault("DXTLT_TIMING_EXPERIMENTS", "1")   # the 0x10 cases (wrong output, timing only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dxt_lossless_transform_amd as pkg
