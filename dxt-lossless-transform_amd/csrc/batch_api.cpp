@@ -312,6 +312,54 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
     return kOk;
 }
 
+// Test hook (no device needed, nothing is dereferenced): plans buffers of one format, direction and settings exactly as
+// dxtlt_transform_batch_device does for one launch -- plan_batch_entry per buffer, then build_batch_index -- and hands back the
+// planned entries and the workgroup -> entry index, so that the host logic can be checked on a machine without a GPU
+// (tests/test_batch_plan.py).  Returns the launch's workgroups; 0xFFFFFFFF when `index_capacity` is too small or a buffer is
+// one the batch kernel does not take (dxtlt_transform_batch_device launches those alone).
+extern "C" uint32_t dxtlt_debug_plan_batch(int32_t format, int32_t inverse, int32_t variant, int32_t split_alpha, int32_t split_colour,
+                                           const uint64_t* src_addresses, const uint64_t* dst_addresses, const uint64_t* blocks, size_t count,
+                                           DxtltDebugPlannedEntry* entries_out, uint8_t* index_out, size_t index_capacity)
+{
+    if (format < 1 || format > 3 || (count != 0 && (!src_addresses || !dst_addresses || !blocks || !entries_out)))
+        return 0xFFFFFFFFu;
+    dxtlt::Settings s{};
+    s.variant = variant;
+    s.split_alpha = format == 3 && split_alpha != 0;
+    s.split_colour = split_colour != 0;
+    std::vector<BatchEntry> entries;
+    uint32_t total = 0;
+    for (size_t i = 0; i < count; ++i) {
+        BatchEntry e{};
+        e.src = reinterpret_cast<const uint8_t*>(static_cast<uintptr_t>(src_addresses[i]));
+        e.dst = reinterpret_cast<uint8_t*>(static_cast<uintptr_t>(dst_addresses[i]));
+        e.blocks = blocks[i];
+        e.first_wg = total;
+        const uint32_t wgs = dxtlt::plan_batch_entry((dxtlt::Format)format, inverse != 0, s, e);
+        if (wgs == 0xFFFFFFFFu || (uint64_t)total + wgs > 0xFFFFFFull)
+            return 0xFFFFFFFFu;
+        if (wgs == 0)
+            e.end_wg = e.first_wg;
+        total += wgs;
+        DxtltDebugPlannedEntry& o = entries_out[i];
+        o.first_wg = e.first_wg;
+        o.end_wg = e.end_wg;
+        o.full_tiles = e.full_tiles;
+        o.form = e.form;
+        o.halo_vecs = e.halo_vecs;
+        std::memcpy(o.shift, e.shift, sizeof o.shift);
+        std::memcpy(o.gbase, e.gbase, sizeof o.gbase);
+        if (wgs != 0)
+            entries.push_back(e);
+    }
+    if (total != 0) {
+        if (index_out == nullptr || index_capacity < dxtlt::batch_index_bytes(total))
+            return 0xFFFFFFFFu;
+        dxtlt::build_batch_index(entries.data(), entries.size(), total, index_out);
+    }
+    return total;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // dxtlt_transform_batch_host: the same, for HOST buffers -- the reference's actual call pattern: one call per file,
 // host pointers, textures of 0.1-20 MiB (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:154-199).

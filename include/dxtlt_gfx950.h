@@ -168,6 +168,24 @@ typedef struct DxtltBatchItem {
     uint8_t reserved[3];
 } DxtltBatchItem;
 int32_t dxtlt_transform_batch_device(const DxtltBatchItem *items, size_t count, void *hip_stream);
+/* Test hook, no device needed: plans `count` buffers of one format, direction and settings the way
+ * dxtlt_transform_batch_device plans one launch (addresses are numbers here, nothing is dereferenced) and returns the
+ * launch's workgroups; entries_out[i] describes buffer i (an empty buffer owns no workgroup), index_out receives the
+ * workgroup -> entry index: uint32 base[ceil(wgs / 4096)], then uint8 delta[ceil(wgs / 64)] -- the owner of workgroup w is
+ * the first entry at or behind base[w / 4096] + delta[w / 64] (counting buffers that own workgroups) whose end_wg > w.
+ * 0xFFFFFFFF: index_capacity too small, or a buffer the batch kernel does not take (stream bases off their element
+ * width: launched alone by the batch call). */
+typedef struct DxtltDebugPlannedEntry {
+    uint32_t first_wg, end_wg;   /* workgroups [first_wg, end_wg): whole tiles first, then the edge tile if there is one */
+    uint32_t full_tiles;
+    uint8_t form;                /* 1 = aligned tiles, 0 = halo tiles (forward) / shifted tiles (inverse) */
+    uint8_t halo_vecs;
+    uint8_t shift[6];            /* stream base modulo 64 (forward) or 16 (inverse) */
+    uint64_t gbase[6];
+} DxtltDebugPlannedEntry;
+uint32_t dxtlt_debug_plan_batch(int32_t format, int32_t inverse, int32_t variant, int32_t split_alpha, int32_t split_colour,
+                                const uint64_t *src_addresses, const uint64_t *dst_addresses, const uint64_t *blocks, size_t count,
+                                DxtltDebugPlannedEntry *entries_out, uint8_t *index_out, size_t index_capacity);
 
 /* The same for HOST buffers (d_input / d_output of every item are host pointers here) -- the reference's own call
  * pattern: one call per file, host pointers, textures of 0.1-20 MiB (tools/dxt-lossless-transform-cli/src/commands/
