@@ -301,6 +301,52 @@ int32_t dxtlt_transform_header_unpack(uint32_t header, int32_t* transform_format
     return DXTLT_FF_OK;
 }
 
+uint32_t dxtlt_transform_header_new(int32_t transform_format, uint32_t format_data)
+{
+    return ((uint32_t)transform_format & 0xFu) | (format_data << 4);
+}
+
+int32_t dxtlt_transform_header_format(uint32_t header)
+{
+    const uint32_t code = header & 0xFu;
+    return code <= DXTLT_TF_BC5 ? (int32_t)code : -1;
+}
+
+uint32_t dxtlt_transform_header_format_data(uint32_t header) { return header >> 4; }
+
+void dxtlt_transform_header_write(uint32_t header, uint8_t* ptr)
+{
+    if (ptr != nullptr)
+        wr32(ptr, header);
+}
+
+uint32_t dxtlt_transform_header_read(const uint8_t* ptr) { return ptr != nullptr ? rd32(ptr) : 0; }
+
+namespace {
+bool is_reserved_flag_format(uint32_t code)
+{
+    return code == DXTLT_TF_RGBA8888 || code == DXTLT_TF_BGRA8888 || code == DXTLT_TF_BGR888 || code == DXTLT_TF_BC4 ||
+           code == DXTLT_TF_BC5;
+}
+}  // namespace
+
+uint32_t dxtlt_transform_header_pack_reserved_format(int32_t transform_format, bool flag)
+{
+    return dxtlt_transform_header_new(transform_format, (flag ? 1u : 0u) << 2);   // version 0, reserved 0
+}
+
+int32_t dxtlt_transform_header_unpack_reserved_format(uint32_t header, int32_t* transform_format, bool* flag)
+{
+    const uint32_t code = header & 0xFu, data = header >> 4;
+    if (!is_reserved_flag_format(code))
+        return DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT;
+    if ((data & 3u) != 0 || (data >> 3) != 0)
+        return DXTLT_FF_CORRUPTED_EMBEDDED_DATA;
+    if (transform_format) *transform_format = (int32_t)code;
+    if (flag) *flag = ((data >> 2) & 1u) != 0;
+    return DXTLT_FF_OK;
+}
+
 void dxtlt_file_formats_enable_bc7(bool enabled) { g_bc7_enabled.store(enabled, std::memory_order_relaxed); }
 
 bool is_dds(const uint8_t* ptr, size_t len)

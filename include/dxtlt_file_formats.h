@@ -37,6 +37,17 @@ extern "C" {
 #define DXTLT_TF_BC2 1
 #define DXTLT_TF_BC3 2
 #define DXTLT_TF_BC7 3
+/* codes upstream has reserved header layouts for, without a transform behind them yet */
+#define DXTLT_TF_BC6H 4
+#define DXTLT_TF_RGBA8888 5
+#define DXTLT_TF_BGRA8888 6
+#define DXTLT_TF_BGR888 7
+#define DXTLT_TF_BC4 8
+#define DXTLT_TF_BC5 9
+
+/* embed/mod.rs:96-103: bytes a file format must reserve beyond the 4-byte header for these two */
+#define DXTLT_BC7_ADDITIONAL_SPACE 48
+#define DXTLT_BC6H_ADDITIONAL_SPACE 80
 
 /* status codes of this header's functions */
 #define DXTLT_FF_OK 0
@@ -55,6 +66,23 @@ uint32_t dxtlt_transform_header_pack(int32_t transform_format, uint8_t decorrela
                                      bool split_alpha_endpoints, bool split_colour_endpoints);
 int32_t dxtlt_transform_header_unpack(uint32_t header, int32_t *transform_format, uint8_t *decorrelation_mode,
                                       bool *split_alpha_endpoints, bool *split_colour_endpoints);
+
+/* TransformHeader itself (embed/mod.rs:105-140): format code in bits 0-3, format-specific data in bits 4-31, stored as a
+ * little-endian u32.  _new masks `format_data` to 28 bits; _format returns the code, or -1 for one this version does not know
+ * (TransformFormat::from_u8 -> None: 10 ... 15), so that files written by later versions are refused, not misread. */
+uint32_t dxtlt_transform_header_new(int32_t transform_format, uint32_t format_data);
+int32_t dxtlt_transform_header_format(uint32_t header);
+uint32_t dxtlt_transform_header_format_data(uint32_t header);
+void dxtlt_transform_header_write(uint32_t header, uint8_t *ptr);   /* 4 bytes, little endian */
+uint32_t dxtlt_transform_header_read(const uint8_t *ptr);
+
+/* Header data of the formats upstream keeps placeholders for (embed/formats/bc4.rs, bc5.rs: `split_endpoints`; rgba8888.rs,
+ * bgra8888.rs, bgr888.rs: `decorrelation`): version:2 (only 0 valid) | flag:1 | reserved:25 (must be zero).  No transform
+ * exists for them upstream or here -- the DDS calls answer DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT -- but a tool that walks
+ * headers can name them.  _unpack: DXTLT_FF_UNKNOWN_TRANSFORM_FORMAT for any other format code,
+ * DXTLT_FF_CORRUPTED_EMBEDDED_DATA for another version or non-zero reserved bits. */
+uint32_t dxtlt_transform_header_pack_reserved_format(int32_t transform_format, bool flag);
+int32_t dxtlt_transform_header_unpack_reserved_format(uint32_t header, int32_t *transform_format, bool *flag);
 
 /* DdsFormat (parse_dds.rs:6-20), #[repr(u8)] */
 enum DdsFormat

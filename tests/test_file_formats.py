@@ -84,6 +84,74 @@ def test_header_rejects_bad_version_and_format(lib):
     assert lib.dxtlt_transform_header_unpack(0xF, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 4
 
 
+def _header_api(lib):
+    lib.dxtlt_transform_header_new.argtypes = [C.c_int32, C.c_uint32]
+    lib.dxtlt_transform_header_new.restype = C.c_uint32
+    lib.dxtlt_transform_header_format.argtypes = [C.c_uint32]
+    lib.dxtlt_transform_header_format.restype = C.c_int32
+    lib.dxtlt_transform_header_format_data.argtypes = [C.c_uint32]
+    lib.dxtlt_transform_header_format_data.restype = C.c_uint32
+    lib.dxtlt_transform_header_write.argtypes = [C.c_uint32, C.c_void_p]
+    lib.dxtlt_transform_header_write.restype = None
+    lib.dxtlt_transform_header_read.argtypes = [C.c_void_p]
+    lib.dxtlt_transform_header_read.restype = C.c_uint32
+    lib.dxtlt_transform_header_pack_reserved_format.argtypes = [C.c_int32, C.c_bool]
+    lib.dxtlt_transform_header_pack_reserved_format.restype = C.c_uint32
+    lib.dxtlt_transform_header_unpack_reserved_format.argtypes = [C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_bool)]
+    lib.dxtlt_transform_header_unpack_reserved_format.restype = C.c_int32
+    return lib
+
+
+def test_transform_format_codes_and_header_bitfield(lib):
+    """embed/mod.rs tests test_transform_format_conversion, test_transform_header_bitfield, test_header_read_write,
+    test_little_endian_byte_order, replayed on the C surface"""
+    l = _header_api(lib)
+    # Bc1 Bc2 Bc3 Bc7 Bc6H Rgba8888 Bgra8888 Bgr888 Bc4 Bc5 = 0 .. 9; 0x0F is no format
+    for code in range(10):
+        assert l.dxtlt_transform_header_format(l.dxtlt_transform_header_new(code, 0)) == code
+    for code in range(10, 16):
+        assert l.dxtlt_transform_header_format(code) == -1
+    h = l.dxtlt_transform_header_new(0, 0x0ABCDEF0)
+    assert l.dxtlt_transform_header_format(h) == 0 and l.dxtlt_transform_header_format_data(h) == 0x0ABCDEF0
+    h2 = l.dxtlt_transform_header_new(2, 0xFFFFFFFF)   # data masked to 28 bits
+    assert l.dxtlt_transform_header_format(h2) == 2 and l.dxtlt_transform_header_format_data(h2) == 0x0FFFFFFF
+    buf = np.zeros(4, dtype=np.uint8)
+    h3 = l.dxtlt_transform_header_new(3, 0x1234567)   # BC7
+    assert h3 == 0x12345673
+    l.dxtlt_transform_header_write(h3, buf.ctypes.data)
+    assert bytes(buf) == bytes([0x73, 0x56, 0x34, 0x12])
+    assert l.dxtlt_transform_header_read(buf.ctypes.data) == h3
+
+
+@pytest.mark.parametrize("code", [8, 9, 5, 6, 7])   # Bc4, Bc5 (split_endpoints); Rgba8888, Bgra8888, Bgr888 (decorrelation)
+def test_reserved_format_headers(lib, code):
+    """embed/formats/{bc4,bc5,rgba8888,bgra8888,bgr888}.rs: version:2 | flag:1 | reserved:25 -- their tests
+    test_*_pack_unpack_roundtrip, test_roundtrip_all_possible_transform_details, test_header_version_and_reserved_fields,
+    test_invalid_header_version, test_invalid_reserved_bits, test_format_association"""
+    l = _header_api(lib)
+    f, flag = C.c_int32(), C.c_bool()
+    seen = set()
+    for want in (False, True):
+        h = l.dxtlt_transform_header_pack_reserved_format(code, want)
+        seen.add(h)
+        assert l.dxtlt_transform_header_format(h) == code
+        data = l.dxtlt_transform_header_format_data(h)
+        assert data & 3 == 0 and data >> 3 == 0 and (data >> 2) & 1 == int(want)
+        assert l.dxtlt_transform_header_unpack_reserved_format(h, C.byref(f), C.byref(flag)) == 0
+        assert (f.value, flag.value) == (code, want)
+    assert len(seen) == 2
+    bad_version = l.dxtlt_transform_header_new(code, 3)         # only version 0 is valid
+    assert l.dxtlt_transform_header_unpack_reserved_format(bad_version, C.byref(f), C.byref(flag)) == 5
+    bad_reserved = l.dxtlt_transform_header_new(code, 1 << 3)   # reserved = 1
+    assert l.dxtlt_transform_header_unpack_reserved_format(bad_reserved, C.byref(f), C.byref(flag)) == 5
+    assert l.dxtlt_transform_header_unpack_reserved_format(l.dxtlt_transform_header_new(code, 1 << 27), C.byref(f), C.byref(flag)) == 5
+    # the transform formats proper are not this family's, and no DDS call accepts a reserved format
+    assert l.dxtlt_transform_header_unpack_reserved_format(l.dxtlt_transform_header_new(0, 0), C.byref(f), C.byref(flag)) == 4
+    m, a, c = C.c_uint8(), C.c_bool(), C.c_bool()
+    h = l.dxtlt_transform_header_pack_reserved_format(code, True)
+    assert lib.dxtlt_transform_header_unpack(h, C.byref(f), C.byref(m), C.byref(a), C.byref(c)) == 4
+
+
 # ---- DDS parsing -------------------------------------------------------------------------------------------
 def test_is_dds(lib):
     # likely_dds.rs tests: magic + at least 128 bytes
