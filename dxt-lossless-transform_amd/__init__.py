@@ -129,9 +129,14 @@ def load():
 
 
 def set_tuning(tile_threads: int = 0, force_path: int = 0) -> None:
-    """Experiments/tests: tile workgroup size (0 = per-format default) and kernel path (0 = automatic,
-    1 = element-granular kernel, 2 = shifted-tile kernel)."""
+    """Tests/tuning: workgroup size of the aligned tiles (0 = per-format default) and kernel path (0 = automatic, 2 = halo /
+    shifted tiles always, 0x20 = their generic LDS accesses).  Bits outside tuning_mask() are ignored."""
     load().dxtlt_set_tuning(int(tile_threads), int(force_path))
+
+
+def tuning_mask() -> int:
+    """The force_path bits this build honours: 0x22 for the shipped library (the experiments side build knows more)."""
+    return int(load().dxtlt_tuning_mask())
 
 
 def set_auto_estimator_threads(threads: int) -> None:

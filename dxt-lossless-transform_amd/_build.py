@@ -4,6 +4,7 @@ One object per source under build/obj (compiled in parallel, rebuilt only when t
 link step.  The shared library is the only artefact that matters; build/ is scratch."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -12,15 +13,32 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdxtlt_gfx950.so")
-OBJ_DIR = os.path.join(os.path.dirname(_HERE), "build", "obj")
+_BUILD_DIR = os.path.join(os.path.dirname(_HERE), "build")
 
 SOURCES = ["bcn_kernels.hip", "batch_kernels.hip", "dxtlt_api.cpp", "c_api_core.cpp", "c_api_stable.cpp", "auto_transform.cpp", "file_format.cpp",
            "bc7_kernels.hip", "bc7_api.cpp", "bc7_sharded.cpp", "bc1_normalize.hip", "normalize_api.cpp", "batch_api.cpp", "bc23_normalize.hip",
            "normalize23_api.cpp", "color565_ops.hip", "color565_api.cpp", "bcn_decode.hip", "decode_api.cpp",
            "auto_kernels.hip", "numa_affinity.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-command-line-argument"]
-# A/B experiments (tools/ab_build_rev.sh): extra compiler flags for a side build, never set for the shipped library
-FLAGS += os.environ.get("DXTLT_EXTRA_HIPCC_FLAGS", "").split()
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-command-line-argument"]
+
+
+def _extra_flags(extra_flags=None) -> list:
+    """Extra compiler flags of a SIDE build (A/B experiments: tools/ab_build_rev.sh; -DDXTLT_EXPERIMENTS, -DDXTLT_WG_TIMING):
+    the argument, else $DXTLT_EXTRA_HIPCC_FLAGS.  A build with extra flags never touches the shipped library or its objects:
+    it goes to build/side-<hash of the flags>/ (objects and library), so a variable left set in a shell cannot put experiment
+    code into libdxtlt_gfx950.so, and objects of one flag set are never linked into another."""
+    if extra_flags is None:
+        extra_flags = os.environ.get("DXTLT_EXTRA_HIPCC_FLAGS", "").split()
+    return list(extra_flags)
+
+
+def _dirs(extra: list):
+    """(object directory, library path) of a build with the extra flags `extra`"""
+    if not extra:
+        return os.path.join(_BUILD_DIR, "obj"), LIB_PATH
+    tag = hashlib.sha256(" ".join(extra).encode()).hexdigest()[:12]
+    side = os.path.join(_BUILD_DIR, "side-" + tag)
+    return os.path.join(side, "obj"), os.path.join(side, "libdxtlt_gfx950.so")
 
 
 def _hipcc() -> str:
@@ -43,44 +61,51 @@ def _headers():
 
 
 def is_stale() -> bool:
+    """The SHIPPED library against its sources (side builds are always asked for explicitly)."""
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(f) > t for f in _sources() + _headers())
 
 
-def _obj(src: str) -> str:
-    return os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-
-
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP/C++ source of the package into one shared library for gfx950."""
-    if not force and not is_stale():
+def build(force: bool = False, verbose: bool = False, extra_flags=None) -> str:
+    """Compile every HIP/C++ source of the package into one shared library for gfx950 and return its path: the shipped
+    library, or -- with extra flags -- a side build under build/side-*/ (see _extra_flags)."""
+    extra = _extra_flags(extra_flags)
+    obj_dir, lib_path = _dirs(extra)
+    if not extra and not force and not is_stale():
         return LIB_PATH
     hipcc = _hipcc()
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = BASE_FLAGS + extra
     newest_header = max((os.path.getmtime(h) for h in _headers()), default=0.0)
+
+    def obj(src: str) -> str:
+        return os.path.join(obj_dir, os.path.basename(src) + ".o")
+
     todo = []
     for src in _sources():
-        o = _obj(src)
+        o = obj(src)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(src), newest_header):
             todo.append(src)
 
     def compile_one(src: str) -> None:
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", _obj(src) + ".tmp"]
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj(src) + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        os.replace(_obj(src) + ".tmp", _obj(src))
+        os.replace(obj(src) + ".tmp", obj(src))
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         list(pool.map(compile_one, todo))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-o", LIB_PATH + ".tmp", "-lpthread"]
+    if not todo and os.path.exists(lib_path) and all(os.path.getmtime(obj(s)) <= os.path.getmtime(lib_path) for s in _sources()):
+        return lib_path
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj(s) for s in _sources()] + ["-o", lib_path + ".tmp", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -214,9 +214,11 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
         sh.d[i] = (int)((en.shifts[i >> 2] >> (8 * (i & 3))) & 127u);
         sh.gbase[i] = en.gbase[i];
     }
+#ifdef DXTLT_EXPERIMENTS
     sh.xcd_remap = 0;
     sh.line_policy = INVERSE ? 1 : 3;
     sh.skip_partial = 0;
+#endif
     sh.natural = 1;             // plan_batch_entry hands buffers with other shifts back to the host
     sh.halo_vecs = (int)(en.flags >> 8) & 0xFF;
     sh.full_tiles = en.full_tiles;

@@ -1,6 +1,12 @@
-// bcn_device.h -- device code of the BCn block-transform kernels (gfx950): the LDS image, the aligned / halo / shifted / edge
-// tiles and the element-granular block, shared by the single-buffer kernels (bcn_kernels.hip) and the batch kernels
-// (batch_kernels.hip).  The design notes are at the top of bcn_kernels.hip.
+// bcn_device.h -- device code of the BCn block-transform kernels (gfx950): the LDS image and the aligned / halo / shifted / edge
+// tiles, shared by the single-buffer kernels (bcn_kernels.hip) and the batch kernels (batch_kernels.hip).  The design notes
+// are at the top of bcn_kernels.hip.
+//
+// -DDXTLT_EXPERIMENTS (a SIDE build, never the shipped library: `DXTLT_EXTRA_HIPCC_FLAGS=-DDXTLT_EXPERIMENTS tools/ab_build_rev.sh
+// WORKTREE exp`, run through DXTLT_LIB_PATH) adds what the measurements in profiles/ were taken with and the product does not
+// need: the element-granular kernel, the first form of the forward shifted tiles, run-time store policies and tile orders, and
+// a wrong-output timing switch (Shifts::skip_partial).  Without the flag none of that is compiled: the kernels carry no switch
+// that is not a property of the data.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -268,7 +274,7 @@ __device__ __forceinline__ u32x4 normalize_vector(u32x4 q)
     return q;
 }
 
-// bit 1 of the tiled kernels' `xcd_remap` argument: the launch is two-dimensional, blockIdx.y numbers the buffers of a regular
+// bit 1 of the tiled kernels' `xcd_remap` argument (bit 0, experiments build only: XCD-contiguous tile order): the launch is two-dimensional, blockIdx.y numbers the buffers of a regular
 // array whose sources / destinations lie `*_stride` bytes apart (first pointer argument, second pointer argument)
 constexpr int kTiledArray = 2;
 
@@ -316,7 +322,11 @@ fwd_tiled(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint64_t t
         aos += (int64_t)blockIdx.y * aos_stride;
         soa += (int64_t)blockIdx.y * soa_stride;
     }
+#ifdef DXTLT_EXPERIMENTS
     const uint64_t tile = (xcd_remap & 1) ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+#else
+    const uint64_t tile = blockIdx.x;   // identity order: the XCD-contiguous one costs aligned tiles 0.01-0.03 (profiles/r01_i_*)
+#endif
     fwd_aligned_tile<FMT, VARIANT, SA, SC, THREADS, NORM>(aos, soa, total_blocks, first_block, tile, lds);
 }
 
@@ -330,7 +340,11 @@ inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t t
         soa += (int64_t)blockIdx.y * soa_stride;
         aos += (int64_t)blockIdx.y * aos_stride;
     }
+#ifdef DXTLT_EXPERIMENTS
     const uint64_t tile = (xcd_remap & 1) ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
+#else
+    const uint64_t tile = blockIdx.x;
+#endif
     inv_aligned_tile<FMT, VARIANT, SA, SC, THREADS>(soa, aos, total_blocks, first_block, tile, lds);
 }
 
@@ -348,9 +362,6 @@ inv_tiled(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos, uint64_t t
 // ------------------------------------------------------------------------------------------------
 struct Shifts {
     int d[6];
-    int xcd_remap;    // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile)
-    int line_policy;  // 1: forward stores of lines written whole by one wave instruction are write-through (sc1 nt)
-    int skip_partial; // timing experiment only (wrong output): 1 = leave out the partial head / tail segments
     int natural;      // 1: every d[s] is a multiple of stream s's element width (always so when the SoA pointer is 8-byte aligned)
     int halo_vecs;    // halo tiles: 16-byte vectors in front of a tile whose blocks have bytes in the tile's windows
     // offset from the SoA pointer of the aligned segment that holds the first byte of stream s of the RANGE:
@@ -364,7 +375,45 @@ struct Shifts {
     // behind them (the rest, and forward the last bytes of every stream that the whole tiles' moved-back windows leave out).
     uint32_t full_tiles;
     uint64_t range_blocks;
+#ifdef DXTLT_EXPERIMENTS
+    int xcd_remap;    // 1: consecutive tiles stay on one XCD (see xcd_contiguous_tile); the product fixes it per kernel
+    int line_policy;  // forward store policy (first form: 1 = write-through for lines one wave instruction writes whole, 2 = plain
+                      // stores on shared lines; halo tiles: 3 = write-through, else plain nt); the product always runs 3
+    int skip_partial; // TIMING experiment, WRONG OUTPUT: 1 = leave out the partial head / tail segments and the halo load
+#endif
 };
+
+// The tile order of the halo (forward) and shifted (inverse) kernels, and the halo tiles' store policy: fixed in the product
+// (identity order + write-through forward -- every window starts on a 64-byte sector, nothing is shared; XCD-contiguous order
+// inverse -- neighbouring tiles share lines), run-time values in the experiments build.
+__device__ __forceinline__ bool shifts_xcd_contiguous(const Shifts& sh, bool product_default)
+{
+#ifdef DXTLT_EXPERIMENTS
+    (void)product_default;
+    return sh.xcd_remap != 0;
+#else
+    (void)sh;
+    return product_default;
+#endif
+}
+__device__ __forceinline__ bool shifts_halo_write_through(const Shifts& sh)
+{
+#ifdef DXTLT_EXPERIMENTS
+    return sh.line_policy == 3;
+#else
+    (void)sh;
+    return true;
+#endif
+}
+__device__ __forceinline__ bool shifts_skip_partial(const Shifts& sh)
+{
+#ifdef DXTLT_EXPERIMENTS
+    return sh.skip_partial != 0;
+#else
+    (void)sh;
+    return false;
+#endif
+}
 
 template <typename STREAMS>
 __host__ __device__ inline void fill_gbase(Shifts& sh, const STREAMS& S, uint64_t total_blocks, uint64_t first_block)
@@ -401,9 +450,15 @@ __device__ __forceinline__ Shifts shifts_fetched_at_once(const Shifts& in)
 {
     Shifts s = in;
     // ONE statement: with several, the compiler fetches what the first one needs, waits, and only then asks for the next one's
+#ifdef DXTLT_EXPERIMENTS
     asm("" : "+s"(s.d[0]), "+s"(s.d[1]), "+s"(s.d[2]), "+s"(s.d[3]), "+s"(s.d[4]), "+s"(s.d[5]), "+s"(s.gbase[0]), "+s"(s.gbase[1]),
              "+s"(s.gbase[2]), "+s"(s.gbase[3]), "+s"(s.gbase[4]), "+s"(s.gbase[5]), "+s"(s.xcd_remap), "+s"(s.line_policy),
              "+s"(s.skip_partial), "+s"(s.natural), "+s"(s.halo_vecs), "+s"(s.full_tiles), "+s"(s.range_blocks));
+#else
+    asm("" : "+s"(s.d[0]), "+s"(s.d[1]), "+s"(s.d[2]), "+s"(s.d[3]), "+s"(s.d[4]), "+s"(s.d[5]), "+s"(s.gbase[0]), "+s"(s.gbase[1]),
+             "+s"(s.gbase[2]), "+s"(s.gbase[3]), "+s"(s.gbase[4]), "+s"(s.gbase[5]), "+s"(s.natural), "+s"(s.halo_vecs),
+             "+s"(s.full_tiles), "+s"(s.range_blocks));
+#endif
     return s;
 }
 
@@ -727,6 +782,9 @@ constexpr int kShiftLdsBytes = shift_lds_bytes(1);
 // 0.702 / 0.797, BC1 0.755 / 0.777 against 0.775 / 0.818; profiles/r01_z/shift_probe_with_big_tiles.txt).  L2 merges the
 // shared lines either way: HBM traffic is 1.003 x the algorithmic bytes on odd counts (PMC).
 
+#ifdef DXTLT_EXPERIMENTS
+// EXPERIMENTS build only: the FIRST form of the forward shifted tiles (typed partial segments), kept for the measurements that
+// led to the halo tiles below (tools/shift_probe.py, switch 0x400).
 // one shifted tile, forward; `lds` is the workgroup's shift_lds_bytes(R) scratch (R = 1: shared with the batch kernel)
 template <int FMT, int VARIANT, bool SA, bool SC, int NORM = kNormNone, int R = 1>
 __device__ __forceinline__ void fwd_shift_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
@@ -805,6 +863,7 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
     const uint64_t tile = sh.xcd_remap ? xcd_contiguous_tile(blockIdx.x, gridDim.x) : (uint64_t)blockIdx.x;
     fwd_shift_tile<FMT, VARIANT, SA, SC, NORM, R>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
+#endif  // DXTLT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Forward shifted tiles, second form ("halo tiles").  What the counters said about the form above on odd block counts
@@ -921,9 +980,9 @@ __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, co
             __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
         return;
     }
-    // line_policy 3 (launch_transform: every window starts on a 64-byte sector, so no sector is shared between tiles):
-    // write-through streaming stores as in the aligned tiles; otherwise plain nt, which lets L2 merge the parts of a shared line
-    if (sh.line_policy == 3)
+    // Every window starts on a 64-byte sector, so no sector is shared between tiles: write-through streaming stores as in the
+    // aligned tiles (the experiments build can ask for plain nt, which lets L2 merge the parts of a shared line)
+    if (shifts_halo_write_through(sh))
         gstore16(soa + g, lds_at<u32x4>(const_cast<uint8_t*>(lds), la));
     else
         __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
@@ -957,9 +1016,8 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     const u32x4 q = *reinterpret_cast<const u32x4*>(tile_aos + t * 16);
     // Only the blocks that have bytes inside a window are fetched: max over the streams of ceil(d_s / w_s) blocks, at
     // most 16 (the whole halo costs 0.02 of peak on BC3 -- 6 % more bytes read -- profiles/r02_b_shift_probe.txt).
-    // skip_partial: timing experiment (wrong output)
     const int hv = sh.halo_vecs;
-    const bool has_halo = tile > 0 && t < hv && !sh.skip_partial;
+    const bool has_halo = tile > 0 && t < hv && !shifts_skip_partial(sh);
     if (has_halo) {
         // plain load: the previous tile has just fetched these lines
         const u32x4 qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
@@ -1138,7 +1196,8 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos_arg, uint8_t* __restrict__ soa_ar
     const uint8_t* __restrict__ aos = fetched_now(aos_arg);
     uint8_t* __restrict__ soa = fetched_now(soa_arg);
     const bool whole = wg < sh.full_tiles;
-    const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : sh.xcd_remap ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
+    // identity tile order: the halo is read again by the next tile, on another XCD, out of the memory-side cache (temporal loads)
+    const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : shifts_xcd_contiguous(sh, false) ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
     const bool edge = !whole || tile == 0;
     if (edge)
         fwd_halo_edge_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, sh, tile, lds);
@@ -1335,7 +1394,8 @@ inv_tiled_shift(const uint8_t* __restrict__ soa_arg, uint8_t* __restrict__ aos_a
     uint8_t* __restrict__ aos = fetched_now(aos_arg);
     asm("" : "+s"(total_blocks));
     const bool whole = wg < sh.full_tiles;
-    const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : sh.xcd_remap ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
+    // XCD-contiguous tile order: neighbouring tiles share their first and last line
+    const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : shifts_xcd_contiguous(sh, true) ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
     const bool edge = !whole;
     if (edge)
         inv_shift_edge_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, sh, tile, lds);
@@ -1344,8 +1404,7 @@ inv_tiled_shift(const uint8_t* __restrict__ soa_arg, uint8_t* __restrict__ aos_a
 }
 
 // ------------------------------------------------------------------------------------------------
-// Element-granular kernels: one lane per block, any alignment, any block count.  Used for the tail of a
-// tiled range and for buffers whose pointers / stream bases are not 16-byte aligned.
+// Byte-granular accessors (the synthetic-data fill kernel; the element-granular kernel of the experiments build).
 // ------------------------------------------------------------------------------------------------
 template <int W>
 __device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, bool natural)
@@ -1381,7 +1440,12 @@ __device__ __forceinline__ uint64_t load_bytes(const uint8_t* p, bool natural)
 
 __device__ __forceinline__ bool aligned_to(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// block i (0 <= i < count) of the element-granular range; shared by generic_kernel and the batch kernel
+#ifdef DXTLT_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENTS build only -- the element-granular kernel: one lane per block, natural-width or byte accesses, any alignment, any
+// block count.  Rounds 1-3 sent ragged tails and misaligned buffers here (0.4-0.7 of peak); the edge tiles replaced it in round 4.
+// ------------------------------------------------------------------------------------------------
+// block i (0 <= i < count) of the element-granular range
 template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int NORM = kNormNone>
 __device__ __forceinline__ void generic_block(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                               uint64_t total_blocks, uint64_t first_block, uint64_t local_first,
@@ -1522,5 +1586,6 @@ generic_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint6
     generic_block<FMT, VARIANT, SA, SC, INVERSE, NORM>(src, dst, total_blocks, first_block, local_first, count,
                                                        (uint64_t)blockIdx.x * kThreads + threadIdx.x);
 }
+#endif  // DXTLT_EXPERIMENTS
 
 }  // namespace dxtlt

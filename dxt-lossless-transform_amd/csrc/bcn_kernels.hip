@@ -9,31 +9,39 @@
 // split, optional YCoCg-R of the two RGB565 endpoints; and the inverse.  Output length == input length.
 //
 // How it is mapped to the machine (this is NOT how the reference does it; the reference is x86 SIMD):
-//   * HBM-bound byte shuffling: 2 bytes of traffic per byte of input, ~20 integer ops per colour pair.
-//     No MFMA.  What matters is that every HBM access is a full-width, fully coalesced 16 B/lane vector
-//     access and that the memory system always has many independent workgroups to pull from.
-//   * One workgroup owns ONE contiguous tile of blocks: THREADS x 16 bytes (256 threads: 4 KiB = 512 BC1 or
-//     256 BC2/BC3 blocks).  Forward: one global_load_dwordx4 per lane (1 KiB contiguous per wave
-//     instruction) -> YCoCg-R in registers -> each field is written to its place in an LDS image that is
-//     laid out exactly like the output (stream after stream) -> barrier -> the image is read back linearly
-//     with ds_read_b128 and leaves with one global_store_dwordx4 per lane; every stream slice of the tile
-//     is a contiguous run of >= 256 bytes.  Inverse: the mirror (linear 16-B stream loads -> LDS image ->
-//     per-block gather + inverse YCoCg-R -> AoS dwordx4 store).
-//   * One tile per workgroup, grid = number of tiles (2^21 workgroups for 8 GiB).  Measured on MI355X
-//     (profiles/r01_b_*, r01_c_*): a persistent grid-stride loop with 4 vectors per lane and software
-//     prefetch reached 0.58-0.60 of the 8 TB/s peak, the same structure as one small tile per workgroup
-//     0.79-0.80, against 0.81-0.83 for a plain dwordx4 copy launched the same way.  The hardware
-//     dispatcher is the better scheduler for a pure stream: short-lived workgroups de-synchronise reads
-//     and writes and keep every channel busy.
-//   * Non-temporal loads (every byte is touched exactly once): +2-3 % over default policy.  Stores of aligned tiles
-//     are write-through streaming stores (`sc1 nt`): another +1-3 % (profiles/r01_p, r01_q).  Shifted tiles share
-//     128-B lines with their neighbours and keep plain `nt` stores, so L2 can merge the two halves of a line.
-//   * 64-bit block indices and byte offsets everywhere (8 GiB of BC1 = 2^30 blocks).
-//   * Stream bases that are not 16-byte aligned (odd block counts, ranges starting at odd blocks) take the
-//     "shifted tile" kernels further down: same structure, each stream's LDS slice displaced by its
-//     misalignment so the body still moves as aligned 16-byte vectors (0.72-0.79 of peak).
-//   * What no tile path can take (the < 1 tile tail, an AoS pointer that is itself misaligned) goes to an
-//     element-granular kernel: one lane per block, natural-width or byte accesses.
+//   * HBM-bound byte shuffling: 2 bytes of traffic per byte of input, ~20 integer ops per colour pair.  No MFMA.  What matters
+//     is that every HBM access is a full-width, fully coalesced 16 B/lane vector access and that the memory system always has
+//     thousands of independent, short-lived workgroups to pull from.
+//   * One workgroup owns ONE contiguous tile of blocks: THREADS x 16 bytes (BC1 128 lanes = 256 blocks, BC2 / BC3 256 lanes = 256
+//     blocks; profiles/r01_q_*).  Forward: one global_load_dwordx4 per lane -> YCoCg-R on packed colour pairs -> each field goes
+//     to its place in an LDS image laid out exactly like the output (stream after stream) -> barrier -> the image is read back
+//     linearly (ds_read_b128) and leaves with one global_store_dwordx4 per lane; every stream slice of a tile is one contiguous
+//     run.  Inverse: the mirror.  One tile per workgroup, no loop: 2^21-2^23 workgroups for 8 GiB.  A persistent grid-stride
+//     loop reached 0.58-0.60 of the 8 TB/s peak where this reaches 0.84-0.86 and a plain copy 0.82-0.85 (profiles/r01_b_*,
+//     r01_c_*, r04_pipelined_tiles.txt): the hardware dispatcher is the better scheduler for a pure stream.
+//   * `nt` loads for bytes touched once; write-through streaming stores (`sc1 nt`, streaming_store.h) for 128-byte lines a
+//     workgroup writes whole; plain `nt` stores where a line is shared with another workgroup (profiles/r01_p, r01_q).
+//   * 64-bit block indices and byte offsets everywhere (8 GiB of BC1 = 2^30 blocks); launches of at most 2^31 blocks.
+//
+// Which tile a range gets (launch_transform; the batch kernel picks the same per buffer) -- a property of the addresses only:
+//   * ALIGNED tiles (fwd_tiled / inv_tiled): every stream base soa + off_s * N + w_s * first_block on a 128-byte line.
+//   * Stream bases anywhere (odd block counts -- every DDS payload with a mip chain -- or ranges starting at odd blocks):
+//       forward HALO tiles (fwd_tiled_halo): each stream's window is moved back to a 64-byte boundary; the up-to-63 bytes in
+//         front are records of blocks before the tile, which the workgroup loads too (temporal loads: the next tile re-reads
+//         them out of the memory-side cache), and what leaves is one whole aligned 16-byte store per lane;
+//       inverse SHIFTED tiles (inv_tiled_shift): each slice of the LDS image sits `base & 15` bytes further in, so LDS and global
+//         addresses agree modulo 16 and whole aligned segments are loaded; XCD-contiguous tile order, because neighbouring
+//         tiles share their first and last line (profiles/r03_inv_shift_pmc.txt).
+//     The AoS side may sit at any byte address (a DDS file resident in HBM has its payload at byte 128 or 148): 16-byte vector
+//     accesses at unaligned addresses are exact on gfx950 and cost 0.02-0.06 (tools/unaligned_lab.hip).
+//   * EDGE tiles (fwd_halo_edge_tile / inv_shift_edge_tile): the first tile of a halo range and the ragged last tile of any
+//     range are the same tiles with masks -- whole 16-byte vectors wherever a segment lies inside the stream, a few narrow
+//     pieces where a stream begins or ends inside one, nothing outside.  They run as one more workgroup of the same launch
+//     (halo / shifted) or as one more launch of one workgroup (behind aligned tiles).  There is no element-granular path.
+//
+// Experiments (the element-granular kernel, the first form of the forward shifted tiles, run-time store policies / tile orders
+// and the wrong-output timing switch the measurements in profiles/ were taken with) are compiled only with -DDXTLT_EXPERIMENTS,
+// a side build (bcn_device.h); this file then also honours the `force_path` bits documented at launch_transform.
 #include "bcn_device.h"
 
 namespace dxtlt {
@@ -71,14 +79,18 @@ fill_splitmix64_kernel(uint8_t* __restrict__ dst, uint64_t len_bytes, uint64_t s
 namespace {
 
 using TiledFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int, int64_t, int64_t);
-using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
 using ShiftFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, Shifts);
+#ifdef DXTLT_EXPERIMENTS
+using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t);
+#endif
 
 struct KernelSet {
-    TiledFn tiled[4];  // 64, 128, 256, 512 threads
-    ShiftFn shifted;   // 256 threads, misaligned stream bases
+    TiledFn tiled[4];  // aligned tiles of 64, 128, 256, 512 threads
+    ShiftFn shifted;   // inverse: shifted tiles + edge tile (256 threads); forward: nullptr (experiments build: the first form)
+    ShiftFn halo[2];   // forward: halo tiles + edge tiles ([1]: natural shifts); inverse: nullptr
+#ifdef DXTLT_EXPERIMENTS
     GenericFn generic;
-    ShiftFn halo[2];   // forward only: shifted tiles with a halo, whole segments only ([1]: natural shifts); nullptr for the inverse
+#endif
 };
 
 inline int threads_slot(int threads) { return threads == 64 ? 0 : threads == 128 ? 1 : threads == 512 ? 3 : 2; }
@@ -86,14 +98,30 @@ inline int threads_slot(int threads) { return threads == 64 ? 0 : threads == 128
 template <int FMT, int VARIANT, bool SA, bool SC>
 KernelSet kernels_for(bool inverse)
 {
-    if (inverse)
-        return {{inv_tiled<FMT, VARIANT, SA, SC, 64>, inv_tiled<FMT, VARIANT, SA, SC, 128>,
-                 inv_tiled<FMT, VARIANT, SA, SC, 256>, inv_tiled<FMT, VARIANT, SA, SC, 512>},
-                inv_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, true>, {nullptr, nullptr}};
-    return {{fwd_tiled<FMT, VARIANT, SA, SC, 64>, fwd_tiled<FMT, VARIANT, SA, SC, 128>,
-             fwd_tiled<FMT, VARIANT, SA, SC, 256>, fwd_tiled<FMT, VARIANT, SA, SC, 512>},
-            fwd_tiled_shift<FMT, VARIANT, SA, SC>, generic_kernel<FMT, VARIANT, SA, SC, false>,
-            {fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false>, fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true>}};
+    KernelSet ks{};
+    if (inverse) {
+        ks.tiled[0] = inv_tiled<FMT, VARIANT, SA, SC, 64>;
+        ks.tiled[1] = inv_tiled<FMT, VARIANT, SA, SC, 128>;
+        ks.tiled[2] = inv_tiled<FMT, VARIANT, SA, SC, 256>;
+        ks.tiled[3] = inv_tiled<FMT, VARIANT, SA, SC, 512>;
+        ks.shifted = inv_tiled_shift<FMT, VARIANT, SA, SC>;
+    } else {
+        ks.tiled[0] = fwd_tiled<FMT, VARIANT, SA, SC, 64>;
+        ks.tiled[1] = fwd_tiled<FMT, VARIANT, SA, SC, 128>;
+        ks.tiled[2] = fwd_tiled<FMT, VARIANT, SA, SC, 256>;
+        ks.tiled[3] = fwd_tiled<FMT, VARIANT, SA, SC, 512>;
+        ks.halo[0] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false>;
+        ks.halo[1] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true>;
+    }
+#ifdef DXTLT_EXPERIMENTS
+    if (inverse) {
+        ks.generic = generic_kernel<FMT, VARIANT, SA, SC, true>;
+    } else {
+        ks.shifted = fwd_tiled_shift<FMT, VARIANT, SA, SC>;
+        ks.generic = generic_kernel<FMT, VARIANT, SA, SC, false>;
+    }
+#endif
+    return ks;
 }
 
 template <int FMT, int VARIANT>
@@ -119,15 +147,21 @@ KernelSet pick_variant(int variant, bool sa, bool sc, bool inverse)
     }
 }
 
-// BC1 forward with block normalisation fused in: one tile size (the BC1 default), shifted tiles, element kernel
+// BC1 forward with block normalisation fused in: one tile size (the BC1 default), halo / edge tiles
 template <int VARIANT, bool SC, int NORM>
 KernelSet bc1_norm_kernels()
 {
     constexpr int TH = default_tile_threads(kBc1, false);
     TiledFn tiled = fwd_tiled<kBc1, VARIANT, false, SC, TH, NORM>;
-    return {{tiled, tiled, tiled, tiled}, fwd_tiled_shift<kBc1, VARIANT, false, SC, NORM>,
-            generic_kernel<kBc1, VARIANT, false, SC, false, NORM>,
-            {fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, false>, fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, true>}};
+    KernelSet ks{};
+    ks.tiled[0] = ks.tiled[1] = ks.tiled[2] = ks.tiled[3] = tiled;
+    ks.halo[0] = fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, false>;
+    ks.halo[1] = fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, true>;
+#ifdef DXTLT_EXPERIMENTS
+    ks.shifted = fwd_tiled_shift<kBc1, VARIANT, false, SC, NORM>;
+    ks.generic = generic_kernel<kBc1, VARIANT, false, SC, false, NORM>;
+#endif
+    return ks;
 }
 
 template <int NORM>
@@ -158,7 +192,21 @@ int cached_cu_count()
 
 }  // namespace
 
-static inline int force_bits_early(const LaunchTuning* tuning) { return tuning ? tuning->force_generic : 0; }
+// force_path bits of dxtlt_set_tuning as this build honours them (include/dxtlt_gfx950.h, dxtlt_tuning_mask()).
+//   product:      2 = halo / shifted tiles even for aligned stream bases; 0x20 = the generic (switch per access) LDS scatter /
+//                 gather of the halo / shifted tiles even for natural shifts.  Both are test levers: every path they select is
+//                 a path some address pattern selects by itself, and the results are exact.
+//   experiments:  1 = element-granular kernel; 0x10 = leave out partial segments / the halo load (TIMING ONLY, WRONG OUTPUT; also
+//                 needs DXTLT_TIMING_EXPERIMENTS in the environment); 0x40 / 0x80 = store policies of the first-form shifted
+//                 tiles; 0x100 / 0x200 = XCD-contiguous tile order off / on; 0x400 = first form of the forward shifted tiles;
+//                 0x800 = plain nt stores in the halo tiles; 0x1000 = round-1 rule (tiles only for a 16-byte aligned AoS
+//                 pointer); 0x2000 = round-3 routing (heads and tails through the element kernel).
+#ifdef DXTLT_EXPERIMENTS
+constexpr int kForceMask = 0x3CFF;
+#else
+constexpr int kForceMask = 2 | 0x20;
+#endif
+int launch_force_mask() { return kForceMask; }
 
 hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const void* src, void* dst,
                             const Range& r, hipStream_t stream, const LaunchTuning* tuning)
@@ -206,79 +254,52 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
 
     const uint8_t* src8 = static_cast<const uint8_t*>(src);
     uint8_t* dst8 = static_cast<uint8_t*>(dst);
-    const void* aos = inverse ? (const void*)dst : src;
     const void* soa = inverse ? src : (const void*)dst;
+    const int force_bits = (tuning ? tuning->force_generic : 0) & kForceMask;
 
-    // Which path can take the range?
-    //   aligned tiles: both pointers and every stream base 16-byte aligned
-    //   shifted tiles: AoS pointer 16-byte aligned, stream bases anywhere
-    //   element kernel: everything else, and the tail that does not fill a tile
+    // Which tiles take the range?  (the table at the top of this file)  The AoS side may sit at any byte address: 16-byte vector
+    // loads / stores at unaligned addresses are exact on gfx950 under ROCm's default memory mode and cost little
+    // (tools/unaligned_lab.hip: a streaming copy at 0.845 of peak drops to 0.81-0.83 with misaligned loads, 0.78-0.79 with
+    // misaligned stores).
     const Streams S = make_streams(fmt, sa, sc);
-    // The AoS side may sit at any byte address: 16-byte vector loads / stores at unaligned addresses are exact on gfx950
-    // under ROCm's default memory mode and cost little (tools/unaligned_lab.hip: a streaming copy at 0.845 of peak drops
-    // to 0.81-0.83 with misaligned loads, 0.78-0.79 with misaligned stores) -- far less than the element kernel, which
-    // round 1 sent such buffers to (0.4-0.7).  A DDS file that lies whole in HBM has its payload at byte 128 or 148.
-    // Experiment switch 0x1000 restores the round-1 rule (tiles only for a 16-byte aligned AoS pointer).
-    const bool aos_ok = (reinterpret_cast<uintptr_t>(aos) & 15) == 0 || !(force_bits_early(tuning) & 0x1000);
-    Shifts sh{};
+    auto stream_base = [&](int i, uint64_t first_block) {
+        return reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks + (uint64_t)S.width[i] * first_block;
+    };
+    // The aligned tiles need 16-byte aligned stream bases to be correct and 128-byte aligned ones to be fast: with bases that
+    // are only 16-byte aligned every slice shares its first and last line with the neighbouring tiles, which the halo / shifted
+    // tiles handle and the aligned ones do not -- BC3 forward 0.65 against 0.77 of peak (profiles/r01_z/shift_probe.txt).
     bool any_shift = false;
-    for (int i = 0; i < S.n; ++i) {
-        const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
-                              (uint64_t)S.width[i] * r.first_block;
-        sh.d[i] = (int)(base & 15);
-        // The aligned tiles need 16-byte aligned stream bases to be correct and 128-byte aligned ones to be fast: with
-        // bases that are only 16-byte aligned every slice shares its first and last line with the neighbouring tiles,
-        // which the shifted tiles handle (XCD-contiguous tile order, no write-through on shared lines) and the aligned
-        // ones do not -- BC3 forward 0.65 against 0.77 of peak (tools/shift_probe.py, profiles/r01_z/shift_probe.txt).
-        any_shift = any_shift || (base & 127) != 0;
-    }
-    fill_gbase(sh, S, r.total_blocks, r.first_block);
-    sh.natural = (force_bits_early(tuning) & 0x20) ? 0 : shifts_are_natural(S, sh.d);   // experiment switch 0x20: generic LDS accesses
-    // XCD-contiguous tile order: measured +2..+9 % on shifted tiles (neighbouring tiles share 128-byte lines), -1..-3 %
-    // on aligned tiles (profiles/r01_i_*) -- so on for the former, off for the latter unless an experiment says so
-    const int remap_override = tuning ? tuning->xcd_remap : -1;
-    sh.xcd_remap = remap_override >= 0 ? remap_override : 1;
-    const int aligned_remap = remap_override >= 0 ? remap_override : 0;
-    const int force_bits = tuning ? tuning->force_generic : 0;
-    const int force = force_bits & 3;  // 1 = element kernel, 2 = shifted tiles
-    sh.skip_partial = (force_bits & 0x10) ? 1 : 0;
-    sh.line_policy = (force_bits & 0x40) ? 0 : (force_bits & 0x80) ? 2 : 1;  // 0x80: shared lines with plain (temporal) stores  // experiment switch: 0x40 = plain nt stores on every shifted line
-    const bool use_tiles = aos_ok && force != 1;
-    const bool use_shift = use_tiles && (any_shift || force == 2);
+    for (int i = 0; i < S.n; ++i)
+        any_shift = any_shift || (stream_base(i, r.first_block) & 127) != 0;
+    const bool use_shift = any_shift || (force_bits & 3) == 2;
 
+    // Shifts of the range [first_block + local_first, ...) for the halo tiles (stream base mod 64) or the shifted tiles (mod 16)
+    auto shifts_of = [&](uint64_t local_first, bool halo) {
+        Shifts sh{};
+        const uint64_t mask = halo ? (uint64_t)(kHaloAlign - 1) : 15;
+        int halo_blocks = 0;
+        for (int i = 0; i < S.n; ++i) {
+            sh.d[i] = (int)(stream_base(i, r.first_block + local_first) & mask);
+            halo_blocks = std::max(halo_blocks, (sh.d[i] + S.width[i] - 1) / S.width[i]);
+        }
+        fill_gbase(sh, S, r.total_blocks, r.first_block + local_first);
+        sh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, sh.d);
+        // only the blocks that have bytes inside a window are fetched as halo: max over the streams of ceil(d_s / w_s) blocks
+        const int per_vec = 16 / fmt_block(fmt);
+        sh.halo_vecs = halo ? (halo_blocks + per_vec - 1) / per_vec : 0;
+        return sh;
+    };
     int threads = default_tile_threads(fmt, inverse);
-    if (tuning && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
-                   tuning->tile_threads == 512))
-        threads = tuning->tile_threads;
-    if (normalizing)
-        threads = default_tile_threads(fmt, inverse);  // the only tile size instantiated with normalisation
+    if (tuning && !normalizing && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
+                                   tuning->tile_threads == 512))
+        threads = tuning->tile_threads;   // (normalisation: the default is the only tile size instantiated)
     if (use_shift)
         threads = 256;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
-    const uint64_t num_tiles = use_tiles ? r.num_blocks / T : 0;
-    // forward shifted tiles take the halo form (whole segments only) unless experiment switch 0x400 asks for the first form
-    const bool use_halo = use_shift && !inverse && ks.halo[0] != nullptr && !(force_bits & 0x400);
-    Shifts shh = sh;   // the halo tiles' own shifts: stream base mod 64
-    if (use_halo) {
-        int halo_blocks = 0;
-        for (int i = 0; i < S.n; ++i) {
-            const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
-                                  (uint64_t)S.width[i] * r.first_block;
-            shh.d[i] = (int)(base & (uint64_t)(kHaloAlign - 1));
-            halo_blocks = std::max(halo_blocks, (shh.d[i] + S.width[i] - 1) / S.width[i]);
-        }
-        fill_gbase(shh, S, r.total_blocks, r.first_block);
-        shh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, shh.d);
-        // every window starts on a 64-byte sector: no line needs to meet its other half in one L2 -- identity tile order
-        // and, unless experiment switch 0x800 asks for plain nt, the write-through streaming stores of the aligned tiles
-        shh.line_policy = (force_bits & 0x800) ? 1 : 3;
-        const int per_vec = 16 / fmt_block(fmt);
-        shh.halo_vecs = (halo_blocks + per_vec - 1) / per_vec;
-        // The halo is read again by the next tile, which runs on another XCD in the identity order: the kernel's temporal
-        // loads keep those lines in the memory-side cache for it, so the identity order (0.035 faster by itself than the
-        // XCD-contiguous one) is right for every halo size.
-        shh.xcd_remap = remap_override >= 0 ? remap_override : 0;
-    }
+
+#ifdef DXTLT_EXPERIMENTS
+    // ---- experiments build: the routes of earlier rounds ------------------------------------------------------------------
+    const int remap_override = tuning ? tuning->xcd_remap : -1;
     auto element_range = [&](uint64_t local_first, uint64_t count) -> hipError_t {
         if (count == 0)
             return hipSuccess;
@@ -287,48 +308,82 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
                            r.first_block, local_first, count);
         return hipGetLastError();
     };
-    // Shifts of the sub-range [local_first, local_first + count) of the range as ONE edge tile (count < T): what is left
-    // behind the aligned tiles, or a range smaller than a tile.  Forward: a halo tile 0 (no halo, writes every stream from its
-    // first byte to its last); inverse: a shifted tile 0.
-    auto edge_tile_of = [&](uint64_t local_first, uint64_t count) -> hipError_t {
-        if (count == 0)
-            return hipSuccess;
-        Shifts e{};
-        const int mask = inverse ? 15 : kHaloAlign - 1;
-        for (int i = 0; i < S.n; ++i) {
-            const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
-                                  (uint64_t)S.width[i] * (r.first_block + local_first);
-            e.d[i] = (int)(base & (uint64_t)mask);
+    {
+        const void* aos = inverse ? (const void*)dst : src;
+        const bool aos_ok = (reinterpret_cast<uintptr_t>(aos) & 15) == 0 || !(force_bits & 0x1000);
+        if (!aos_ok || (force_bits & 3) == 1)
+            return element_range(0, r.num_blocks);
+        const bool first_form = use_shift && !inverse && (force_bits & 0x400);
+        const bool old_routing = (force_bits & 0x2000) != 0;
+        if (first_form || (old_routing && use_shift)) {
+            const uint64_t tiles = r.num_blocks / T;
+            Shifts sh = shifts_of(0, !inverse && !first_form);
+            sh.xcd_remap = remap_override >= 0 ? remap_override : (!inverse && !first_form) ? 0 : 1;
+            sh.skip_partial = (force_bits & 0x10) ? 1 : 0;
+            sh.line_policy = !first_form ? ((force_bits & 0x800) ? 1 : 3) : (force_bits & 0x40) ? 0 : (force_bits & 0x80) ? 2 : 1;
+            sh.full_tiles = (uint32_t)tiles;
+            sh.range_blocks = tiles * T;
+            if (tiles > 0) {
+                hipLaunchKernelGGL(first_form || inverse ? ks.shifted : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)tiles), dim3(256), 0,
+                                   stream, src8, dst8, r.total_blocks, r.first_block, sh);
+                if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                    return e;
+            }
+            uint64_t done = tiles * T;
+            if (!inverse && !first_form && tiles > 0) {
+                // what the halo tiles' windows leave out: the head of every stream of the range (records of its first 64 blocks)
+                // and everything behind the last window
+                if (hipError_t e = element_range(0, kHaloBlocks); e != hipSuccess)
+                    return e;
+                done -= kHaloBlocks;
+            }
+            return element_range(done, r.num_blocks - done);
         }
-        fill_gbase(e, S, r.total_blocks, r.first_block + local_first);
-        e.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, e.d);
-        e.line_policy = 1;
-        e.full_tiles = 0;
-        e.range_blocks = count;
-        const uint64_t aos_off = local_first * (uint64_t)fmt_block(fmt);
-        if (inverse)
-            hipLaunchKernelGGL(ks.shifted, dim3(1), dim3(256), 0, stream, src8, dst8 + aos_off, r.total_blocks, r.first_block, e);
-        else
-            hipLaunchKernelGGL(ks.halo[e.natural ? 1 : 0], dim3(1), dim3(256), 0, stream, src8 + aos_off, dst8, r.total_blocks,
-                               r.first_block, e);
-        return hipGetLastError();
-    };
+        if (old_routing) {
+            const uint64_t tiles = r.num_blocks / T;
+            if (tiles > 0) {
+                hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)tiles), dim3(threads), 0, stream, src8, dst8,
+                                   r.total_blocks, r.first_block, remap_override >= 0 ? remap_override : 0, (int64_t)0, (int64_t)0);
+                if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                    return e;
+            }
+            return element_range(tiles * T, r.num_blocks - tiles * T);
+        }
+    }
+#define DXTLT_SET_EXPERIMENT_FIELDS(sh, halo)                                              \
+    do {                                                                                   \
+        (sh).xcd_remap = remap_override >= 0 ? remap_override : (halo) ? 0 : 1;            \
+        (sh).skip_partial = (force_bits & 0x10) ? 1 : 0;                                   \
+        (sh).line_policy = (halo) ? ((force_bits & 0x800) ? 1 : 3) : 1;                    \
+    } while (0)
+    const int aligned_flags = remap_override >= 0 ? remap_override : 0;
+#else
+#define DXTLT_SET_EXPERIMENT_FIELDS(sh, halo) (void)0
+    const int aligned_flags = 0;
+#endif
+
+    const uint64_t num_tiles = r.num_blocks / T;
     const uint64_t rest = r.num_blocks - num_tiles * T;
-    // experiment switch 0x2000: the round-3 routing (heads and tails through the element kernel)
-    const bool edge_tiles = use_tiles && !(force_bits & 0x2000) && (inverse || ks.halo[0] != nullptr);
-    if (use_halo && edge_tiles) {
+    if (use_shift && !inverse) {
         // halo tiles + edge tiles in ONE launch: tile 0 writes the head of every stream itself, and one more workgroup takes the
-        // blocks behind the last whole tile and the last d_s bytes of every stream
+        // blocks behind the last whole tile and the last d_s bytes of every stream.  Identity tile order, write-through stores:
+        // every window starts on a 64-byte sector, and the halo -- re-read by the next tile, on another XCD -- comes out of the
+        // memory-side cache (temporal loads; bcn_device.h).
+        Shifts sh = shifts_of(0, true);
+        DXTLT_SET_EXPERIMENT_FIELDS(sh, true);
         bool tail = rest > 0;
         for (int i = 0; i < S.n; ++i)
-            tail = tail || shh.d[i] > 0;
-        shh.full_tiles = (uint32_t)num_tiles;
-        shh.range_blocks = r.num_blocks;
-        hipLaunchKernelGGL(ks.halo[shh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
-                           r.total_blocks, r.first_block, shh);
+            tail = tail || sh.d[i] > 0;
+        sh.full_tiles = (uint32_t)num_tiles;
+        sh.range_blocks = r.num_blocks;
+        hipLaunchKernelGGL(ks.halo[sh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
+                           r.total_blocks, r.first_block, sh);
         return hipGetLastError();
     }
-    if (use_shift && inverse && edge_tiles) {
+    if (use_shift) {
+        // shifted tiles + the edge tile in one launch; XCD-contiguous tile order (neighbouring tiles share lines)
+        Shifts sh = shifts_of(0, false);
+        DXTLT_SET_EXPERIMENT_FIELDS(sh, false);
         sh.full_tiles = (uint32_t)num_tiles;
         sh.range_blocks = r.num_blocks;
         hipLaunchKernelGGL(ks.shifted, dim3((unsigned)(num_tiles + (rest > 0 ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
@@ -336,46 +391,32 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         return hipGetLastError();
     }
     if (num_tiles > 0) {
-        if (use_halo) {   // (switch 0x2000)
-            shh.full_tiles = (uint32_t)num_tiles;
-            shh.range_blocks = num_tiles * T;
-            shh.skip_partial = 0;
-            hipLaunchKernelGGL(ks.halo[shh.natural ? 1 : 0], dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8,
-                               r.total_blocks, r.first_block, shh);
-        } else if (use_shift) {
-            sh.full_tiles = (uint32_t)num_tiles;
-            sh.range_blocks = num_tiles * T;
-            hipLaunchKernelGGL(ks.shifted, dim3((unsigned)num_tiles), dim3(256), 0, stream, src8, dst8, r.total_blocks,
-                               r.first_block, sh);
-        } else {
-            hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream,
-                               src8, dst8, r.total_blocks, r.first_block, aligned_remap, (int64_t)0, (int64_t)0);
-        }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess)
+        hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream, src8, dst8,
+                           r.total_blocks, r.first_block, aligned_flags, (int64_t)0, (int64_t)0);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess)
             return e;
     }
-    uint64_t done = num_tiles * T;
-    if (use_halo && num_tiles > 0) {
-        // (switch 0x2000) what the halo tiles' windows leave out: the head of every stream of the range (records of its first 64
-        // blocks) and everything behind the last window (records of the last 64 blocks of the tiles, and the rest)
-        if (hipError_t e = element_range(0, kHaloBlocks); e != hipSuccess)
-            return e;
-        done -= kHaloBlocks;
-        return element_range(done, r.num_blocks - done);
+    // Behind aligned tiles (or a range smaller than a tile): the rest as ONE edge tile -- a halo tile 0 forward (no halo; writes
+    // every stream from its first byte to its last), a shifted tile 0 inverse -- of up to 256 lanes' worth of blocks (512-thread
+    // BC1 tiles, a tuning size, can leave two).
+    const uint64_t T256 = (uint64_t)tile_blocks(fmt, 256);
+    for (uint64_t at = num_tiles * T; at < r.num_blocks; at += T256) {
+        Shifts e = shifts_of(at, !inverse);
+        DXTLT_SET_EXPERIMENT_FIELDS(e, !inverse);
+        e.full_tiles = 0;
+        e.range_blocks = std::min(T256, r.num_blocks - at);
+        const uint64_t aos_off = at * (uint64_t)fmt_block(fmt);
+        if (inverse)
+            hipLaunchKernelGGL(ks.shifted, dim3(1), dim3(256), 0, stream, src8, dst8 + aos_off, r.total_blocks, r.first_block, e);
+        else
+            hipLaunchKernelGGL(ks.halo[e.natural ? 1 : 0], dim3(1), dim3(256), 0, stream, src8 + aos_off, dst8, r.total_blocks,
+                               r.first_block, e);
+        if (hipError_t err = hipGetLastError(); err != hipSuccess)
+            return err;
     }
-    // behind aligned tiles (or a range smaller than a tile): one edge tile -- 256 threads' worth of blocks at most
-    if (edge_tiles && rest <= (uint64_t)tile_blocks(fmt, 256))
-        return edge_tile_of(done, rest);
-    if (edge_tiles) {   // BC1 with 512-thread tiles (an experiment size): up to 1023 blocks left
-        const uint64_t T256 = (uint64_t)tile_blocks(fmt, 256);
-        for (uint64_t at = done; at < r.num_blocks; at += T256)
-            if (hipError_t e = edge_tile_of(at, std::min(T256, r.num_blocks - at)); e != hipSuccess)
-                return e;
-        return hipSuccess;
-    }
-    return element_range(done, r.num_blocks - done);
+    return hipSuccess;
 }
+#undef DXTLT_SET_EXPERIMENT_FIELDS
 
 // A regular array of buffers whose stream bases all sit on 128-byte lines and whose block count is a whole number of tiles IS
 // the single-buffer aligned kernel with one more grid dimension: no table, no lookup (the batch kernel's lookup and entry

@@ -25,10 +25,13 @@ struct Range {
 };
 
 struct LaunchTuning {
-    int tile_threads;   // 0 = per-direction default; 64, 128, 256, 512 = experiment
-    int force_generic;  // testing: 1 = always the element-granular kernel, 2 = always the shifted-tile kernel
-    int xcd_remap;      // shifted tiles: -1 = default, 0 = off, 1 = XCD-contiguous tile order
+    int tile_threads;   // aligned tiles: 0 = per-format default; 64, 128, 256, 512
+    int force_generic;  // force_path bits of dxtlt_set_tuning, see launch_transform (bcn_kernels.hip); 2 = halo / shifted tiles always
+    int xcd_remap;      // experiments build only: -1 = default, 0 = off, 1 = XCD-contiguous tile order
 };
+
+// the force_path bits this build of the kernels honours (2 | 0x20 in the shipped library)
+int launch_force_mask();
 
 // Forward: aos (input) -> soa (output).  Inverse: soa (input) -> aos (output).
 // Enqueues on `stream`; returns the first HIP error.

@@ -966,16 +966,24 @@ size_t dxtlt_host_route_threshold_bytes(void)
 
 void dxtlt_set_host_route_threshold_bytes(size_t bytes) { g_host_route_threshold.store(bytes); }
 
-void dxtlt_set_tuning(int32_t tile_threads, int32_t force_generic)
+int32_t dxtlt_tuning_mask(void) { return dxtlt::launch_force_mask(); }
+
+void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path)
 {
     g_tile_threads.store(tile_threads);
-    // bits 8..9 of force_path carry the XCD-remap experiment switch: 0x100 = off, 0x200 = on, 0 = default
-    // 0x10 leaves the partial segments / the halo out -- a TIMING experiment with wrong output: only honoured when the process
-    // asked for it in its environment, so that no caller of a shipped library can switch correctness off by an argument
+    // Only the bits this build knows (bcn_kernels.hip, kForceMask): the shipped library honours 2 and 0x20 -- test levers that
+    // select paths some address pattern selects by itself, results exact -- and nothing else; in particular it contains no switch
+    // that changes results.  The experiments side build (-DDXTLT_EXPERIMENTS) adds the rest; its 0x10, a timing experiment with
+    // WRONG output, additionally needs DXTLT_TIMING_EXPERIMENTS in the environment.
+    int32_t allowed = dxtlt::launch_force_mask();
+#ifdef DXTLT_EXPERIMENTS
     static const bool timing_experiments = std::getenv("DXTLT_TIMING_EXPERIMENTS") != nullptr;
-    const int32_t allowed = timing_experiments ? 0x1CFF : (0x1CFF & ~0x10);
-    g_force_generic.store(force_generic & allowed);  // 0x400: first form of the forward shifted tiles (no halo)
-    g_xcd_remap.store((force_generic & 0x100) ? 0 : (force_generic & 0x200) ? 1 : -1);
+    if (!timing_experiments)
+        allowed &= ~0x10;
+#endif
+    const int32_t bits = force_path & allowed;
+    g_force_generic.store(bits);
+    g_xcd_remap.store((bits & 0x100) ? 0 : (bits & 0x200) ? 1 : -1);   // (experiments build: XCD-contiguous tile order off / on)
 }
 
 const char* dxtlt_version(void) { return "dxtlt-gfx950 0.2.0"; }

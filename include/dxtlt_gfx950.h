@@ -249,12 +249,15 @@ int32_t dxtlt_device_count(void);
  * implementation, and every entry point does what its name says on the device. */
 size_t dxtlt_host_route_threshold_bytes(void);
 void dxtlt_set_host_route_threshold_bytes(size_t bytes);
-/* Knobs for experiments and tests.  tile_threads: 64/128/256/512 (0 = per-format default).
- * force_path: 0 = automatic, 1 = always the element-granular kernel, 2 = always the shifted-tile kernel; higher bits are
- * the experiment switches that csrc/bcn_kernels.hip documents where it reads them (every one of them leaves the results
- * exact, except 0x10 -- a timing experiment -- which is ignored unless DXTLT_TIMING_EXPERIMENTS is set in the environment).
- * Process-wide. */
+/* Knobs for tests and tuning; process-wide.  tile_threads: workgroup size of the aligned tiles, 64/128/256/512 (0 = per-format
+ * default).  force_path: 0 = automatic; 2 = the halo (forward) / shifted (inverse) tiles even when every stream base is on a
+ * 128-byte line; 0x20 = their generic LDS accesses even for naturally aligned shifts.  Both select kernels that some address
+ * pattern selects by itself and leave every result exact.  Bits outside dxtlt_tuning_mask() are ignored: the shipped library
+ * has no other switch -- the experiment switches earlier rounds measured with (element-granular kernel, store policies, a
+ * wrong-output timing switch) exist only in a side build made with -DDXTLT_EXPERIMENTS (csrc/bcn_device.h). */
 void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path);
+/* The force_path bits this build honours: 0x22 for the shipped library. */
+int32_t dxtlt_tuning_mask(void);
 /* "dxtlt-gfx950 <version>" */
 const char *dxtlt_version(void);
 /* The host-pointer entry points keep, per calling thread and device, one stream and a grow-only pair of staging

@@ -48,8 +48,9 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec == {"rendezvous": "ok", "n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo", "world_size_seen": 2,
-                   "per_rank": [[1.0, 0.0], [2.0, 10.0]]}
+    assert {k: rec[k] for k in ("rendezvous", "n_gpus", "max_over_ranks", "backend", "world_size_seen", "per_rank")} == {
+        "rendezvous": "ok", "n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo", "world_size_seen": 2, "per_rank": [[1.0, 0.0], [2.0, 10.0]]}
+    assert rec["config"]["total_blocks"] == 2 << 30 and rec["ranges"] == [[0, 0, 1 << 30], [1, 1 << 30, 1 << 30]]
 
 
 def test_stdout_of_a_launcher_run_is_one_json_line():
@@ -72,8 +73,10 @@ def test_stdout_of_a_launcher_run_is_one_json_line():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
-    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 3, "max_over_ranks": 3.0, "backend": "gloo",
-                                    "world_size_seen": 3, "per_rank": [[1.0, 0.0], [2.0, 10.0], [3.0, 20.0]]}
+    rec = json.loads(lines[0])
+    assert {k: rec[k] for k in ("rendezvous", "n_gpus", "max_over_ranks", "backend", "world_size_seen", "per_rank")} == {
+        "rendezvous": "ok", "n_gpus": 3, "max_over_ranks": 3.0, "backend": "gloo", "world_size_seen": 3,
+        "per_rank": [[1.0, 0.0], [2.0, 10.0], [3.0, 20.0]]}
 
 
 def test_bench_self_launch_returns_the_childs_exit_code():
@@ -148,6 +151,15 @@ def test_default_line_carries_the_other_single_gpu_configs_as_legs():
         assert legs[name]["largest_blocks"] == 1398103 and legs[name]["smallest_blocks"] % 2 == 1   # 4096 x 4096 with mips; odd counts
     assert legs["bc7_uniform"]["oracle_prefix_exact"] and legs["bc7_skewed"]["oracle_prefix_exact"]
     assert legs["bc7_skewed"]["mode_counts"][6] > 2 * legs["bc7_uniform"]["mode_counts"][6]
+    # the driver's record keeps `config` and drops `legs`: every leg rides there in short, nested and as flat scalars
+    cfg = d["config"]
+    assert set(cfg["legs_summary"]) == set(legs) and cfg["legs_all_exact"] is True
+    assert 0 < cfg["inv_frac"] < 1 and cfg["inv_frac"] == d["roofline"]["inv_frac"] == d["roofline"]["inverse_kernel"]["frac"]
+    for name, leg in legs.items():
+        f, i, ok = cfg["legs_summary"][name]
+        assert f == leg["roofline"]["frac"] == cfg[f"leg_{name}_fwd_frac"], name
+        assert i == leg["roofline"]["inverse_kernel"]["frac"] == cfg[f"leg_{name}_inv_frac"], name
+        assert ok is True and cfg[f"leg_{name}_exact"] is True, name
     # without the switch a small buffer has no legs (they are defined on the BASELINE sizes)
     assert "legs" not in _run_bench(["--host-array-gib", "0"])
 
@@ -204,8 +216,36 @@ def test_eight_rank_rendezvous_the_driver_shape():
     assert len(lines) == 1
     # world_size_seen is the process group's own count; per_rank = every rank's figures in rank order (all_gather): the keys a
     # real N > 1 line carries so that the first SCALE record shows stragglers and proves the group saw N ranks
-    assert json.loads(lines[0]) == {"rendezvous": "ok", "n_gpus": 8, "max_over_ranks": 8.0, "backend": "gloo",
-                                    "world_size_seen": 8, "per_rank": [[float(r + 1), float(10 * r)] for r in range(8)]}
+    rec = json.loads(lines[0])
+    assert {k: rec[k] for k in ("rendezvous", "n_gpus", "max_over_ranks", "backend", "world_size_seen", "per_rank")} == {
+        "rendezvous": "ok", "n_gpus": 8, "max_over_ranks": 8.0, "backend": "gloo", "world_size_seen": 8,
+        "per_rank": [[float(r + 1), float(10 * r)] for r in range(8)]}
+    # the numbers the first real SCALE record must carry at N = 8 (weak scaling, BC1, 8 GiB per GPU): eight per_rank rows, the
+    # process group's own count, 8 x 2^30 blocks in all, rank r on blocks [r * 2^30, (r + 1) * 2^30) -- job_shape() is the
+    # function the real run takes its ranges from
+    assert rec["world_size_seen"] == 8 and len(rec["per_rank"]) == 8 and rec["scaling"] == "weak"
+    assert rec["config"] == {"format": "bc1", "total_blocks": 8 * 2**30, "blocks_per_gpu": 2**30}
+    assert rec["ranges"] == [[r, r * 2**30, 2**30] for r in range(8)]
+
+
+def test_strong_scaling_ranges_partition_the_array():
+    """--scaling strong over eight ranks: the block ranges of job_shape() tile [0, total) without gap or overlap."""
+    import argparse
+
+    sys.path.insert(0, ROOT)
+    import bench
+    import dxt_lossless_transform_amd as pkg
+
+    for size_gib, drop in ((8.0, 0), (8.0, 1), (0.25, 3)):
+        a = argparse.Namespace(size_gib=size_gib, drop_blocks=drop, scaling="strong")
+        shapes = [bench.job_shape(a, 8, 8, r, pkg.plan_shards) for r in range(8)]
+        total = shapes[0][0]
+        assert all(s[0] == total for s in shapes) and total == int(size_gib * 2**30) // 8 - drop
+        at = 0
+        for _, first, blocks in shapes:
+            assert first == at and blocks > 0
+            at += blocks
+        assert at == total
 
 
 def test_corpus_leg_has_the_shape_of_the_references_published_benchmark():

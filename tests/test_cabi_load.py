@@ -134,27 +134,149 @@ def test_new_entry_points_validate_without_a_device(pkg):
     assert l.dxtlt_transform_bc7_sharded(p, p, 0, 2) == 0
 
 
-def test_rust_sys_crate_declares_only_exported_symbols(pkg):
-    """rust/dxt-lossless-transform-gfx950-sys/src/lib.rs (source only: no Rust toolchain here) must not drift from the
-    library: every `pub fn` of its extern block is an exported symbol, and every argument list has the C prototype's
-    number of parameters."""
-    import ctypes
-    import os
-    import re
+def _strip_c_comments(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "rust", "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read()
-    header = open(os.path.join(root, "include", "dxtlt_gfx950.h")).read()
+
+_C_SCALARS = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "int64_t": "i64",
+              "size_t": "usize", "bool": "bool", "double": "f64", "float": "f32", "char": "c_char", "void": "c_void"}
+
+
+def c_type_to_rust(decl: str, named: bool = True) -> str:
+    """The Rust spelling a C parameter / field / return declaration must have in an `extern "C"` block: fixed-width integers by
+    width, size_t -> usize, `const T *` -> `*const T`, `T *` -> `*mut T`, `T name[N]` -> `[T; N]`, struct names unchanged."""
+    decl = " ".join(decl.replace("*", " * ").split())
+    arr = re.search(r"\[(\d+)\]$", decl)
+    if arr:
+        decl = decl[:arr.start()].strip()
+    toks = decl.split()
+    if named and len(toks) > 1 and toks[-1] != "*":
+        toks = toks[:-1]                      # the parameter / field name
+    const = "const" in toks
+    toks = [t for t in toks if t not in ("const", "struct")]
+    stars = toks.count("*")
+    base = [t for t in toks if t != "*"]
+    assert len(base) == 1, decl
+    ty = _C_SCALARS.get(base[0], base[0])
+    for k in range(stars):
+        ty = ("*const " if const and k == 0 else "*mut ") + ty
+    if arr:
+        ty = f"[{ty}; {arr.group(1)}]"
+    return ty
+
+
+def rust_type(t: str) -> str:
+    return " ".join(t.split()).replace("core::ffi::", "")
+
+
+def _split_args(args: str):
+    return [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]
+
+
+def test_c_type_to_rust_mapping():
+    assert c_type_to_rust("const uint8_t *input_ptr") == "*const u8"
+    assert c_type_to_rust("uint8_t *output_ptr") == "*mut u8"
+    assert c_type_to_rust("size_t len") == "usize"
+    assert c_type_to_rust("const DltSizeEstimator *estimator") == "*const DltSizeEstimator"
+    assert c_type_to_rust("void *hip_stream") == "*mut c_void"
+    assert c_type_to_rust("const void *d_input") == "*const c_void"
+    assert c_type_to_rust("bool *out_split") == "*mut bool"
+    assert c_type_to_rust("uint8_t reserved[3]") == "[u8; 3]"
+    assert c_type_to_rust("const char *", named=False) == "*const c_char"
+    assert c_type_to_rust("int32_t", named=False) == "i32"
+
+
+def test_rust_sys_crate_matches_the_c_prototypes_by_type(pkg):
+    """rust/dxt-lossless-transform-gfx950-sys/src/lib.rs has never been through rustc (no toolchain in this image), and a wrong
+    width in an `extern "C"` declaration is undefined behaviour that compiles.  So every `pub fn` of its extern block is checked
+    against the prototype in include/dxtlt_gfx950.h: exported by the library, the same parameters IN ORDER with the same names and
+    the types a fixed C -> Rust mapping gives (const uint8_t * <-> *const u8, size_t <-> usize, bool, uint8_t <-> u8,
+    const DltSizeEstimator * <-> *const DltSizeEstimator, ...), and the same return type (int32_t <-> i32) -- the shape of the
+    reference's own C entry points (bc1 c_api/transform_with_settings.rs:73,119).  The #[repr(C)] structs are checked field by
+    field against the header's typedefs."""
+    import ctypes
+
+    src = open(os.path.join(ROOT, "rust", "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read()
+    src_nc = re.sub(r"//[^\n]*", "", src)
+    header = _strip_c_comments(open(os.path.join(ROOT, "include", "dxtlt_gfx950.h")).read())
+    est = _strip_c_comments(open(os.path.join(ROOT, "include", "dlt_size_estimator.h")).read())
     lib = ctypes.CDLL(pkg._lib.lib_path())
-    decls = re.findall(r"pub fn (dxtlt_\w+)\(([^)]*)\)", src)
-    assert len(decls) >= 20
-    for name, args in decls:
+    block = src_nc[src_nc.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    decls = re.findall(r"pub fn (dxtlt_\w+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block)
+    assert len(decls) >= 30
+    for name, args, ret in decls:
         assert hasattr(lib, name), name
-        m = re.search(r"\b" + name + r"\(([^)]*)\)", header)
-        assert m, name
-        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
-        rust_args = [a for a in args.split(",") if a.strip()]
-        assert len(c_args) == len(rust_args), (name, len(c_args), len(rust_args))
+        m = re.search(r"([\w ]+?[\s\*]+)\b" + name + r"\s*\(([^)]*)\)\s*;", header)
+        assert m, f"{name}: no prototype in include/dxtlt_gfx950.h"
+        c_ret = c_type_to_rust(m.group(1), named=False)
+        assert (rust_type(ret) if ret else "c_void") == c_ret, (name, "return", ret, m.group(1))
+        c_args, rust_args = _split_args(m.group(2)), _split_args(args)
+        assert len(c_args) == len(rust_args), (name, c_args, rust_args)
+        for ca, ra in zip(c_args, rust_args):
+            rname, rty = [x.strip() for x in ra.split(":", 1)]
+            assert rust_type(rty) == c_type_to_rust(ca), (name, ca, ra)
+            assert rname == ca.replace("*", " ").split()[-1], (name, "parameter name", ca, ra)
+
+    def c_struct(text, name):
+        body = re.search(r"typedef struct " + name + r"\s*\{(.*?)\}\s*" + name + r"\s*;", text, re.S).group(1)
+        return [f.strip() for f in body.split(";") if f.strip()]
+
+    def rust_struct(name):
+        body = re.search(r"pub struct " + name + r"\s*\{(.*?)\n\}", src_nc, re.S).group(1)
+        fields, depth, cur = [], 0, ""
+        for ch in body:                       # split at top-level commas (fn pointer types hold commas of their own)
+            depth += ch == "("
+            depth -= ch == ")"
+            if ch == "," and depth == 0:
+                fields.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        fields.append(cur)
+        return [" ".join(f.split()) for f in fields if f.strip()]
+
+    for name in ("DxtltBatchItem", "DxtltShardStat"):
+        cf, rf = c_struct(header, name), rust_struct(name)
+        assert len(cf) == len(rf), (name, cf, rf)
+        for c, r in zip(cf, rf):
+            rname, rty = [x.strip() for x in r.replace("pub ", "", 1).split(":", 1)]
+            cname = re.sub(r"\[\d+\]$", "", c.replace("*", " ").split()[-1])
+            assert rname == cname and rust_type(rty) == c_type_to_rust(c), (name, c, r)
+    # DltSizeEstimator: a context pointer and two callbacks whose signatures are the header's function-pointer typedefs
+    fn_types = {n: (c_type_to_rust(r, named=False), [c_type_to_rust(a) for a in _split_args(a_)])
+                for r, n, a_ in re.findall(r"typedef\s+([\w ]+?)\s*\(\*(\w+)\)\(([^)]*)\);", est)}
+    cf, rf = c_struct(est, "DltSizeEstimator"), rust_struct("DltSizeEstimator")
+    assert len(cf) == len(rf) == 3
+    assert rf[0] == "pub context: *mut c_void" and c_type_to_rust(cf[0]) == "*mut c_void"
+    for c, r in zip(cf[1:], rf[1:]):
+        want_ret, want_args = fn_types[c.split()[0]]
+        m = re.match(r"pub \w+: unsafe extern \"C\" fn\((.*)\) -> (\w+)$", r)
+        assert m, r
+        got_args = [rust_type(a.split(":", 1)[1]) for a in _split_args(m.group(1))]
+        assert got_args == want_args and m.group(2) == want_ret, (c, r)
+    # status codes
+    for cname, value in re.findall(r"#define (DXTLT_(?:OK|E_\w+))\s+(\d+)", header):
+        assert re.search(r"pub const " + cname + r": i32 = " + value + ";", src), cname
+
+
+def test_shipped_library_contains_no_experiment_code(pkg):
+    """The experiment switches of rounds 1-4 (element-granular kernel, first-form shifted tiles, a wrong-output timing switch, the
+    per-workgroup timing arrays) are compiled only with -DDXTLT_EXPERIMENTS / -DDXTLT_WG_TIMING, into side builds under
+    build/side-*/ that never replace the shipped library (_build.py).  Checked on the shipped file itself: the tuning mask, the
+    kernel names in its device code object, the debug exports."""
+    if os.environ.get("DXTLT_LIB_PATH"):
+        pytest.skip("another build of the library is under test")
+    l = pkg.load()
+    assert l.dxtlt_tuning_mask() == 0x22
+    blob = open(pkg._lib.lib_path(), "rb").read()
+    for needle in (b"generic_kernel", b"fwd_tiled_shift", b"g_wg_marks", b"g_wg_timing", b"dxtlt_debug_read_wg"):
+        assert needle not in blob, needle
+    assert b"fwd_tiled_halo" in blob and b"inv_tiled_shift" in blob      # (the check can see kernel names)
+    from dxt_lossless_transform_amd import _build
+    assert _build._dirs([])[1] == _build.LIB_PATH
+    assert _build._dirs(["-DDXTLT_EXPERIMENTS"])[1] != _build.LIB_PATH and "side-" in _build._dirs(["-DDXTLT_EXPERIMENTS"])[0]
 
 
 def test_host_route_threshold_default_setter_and_environment(pkg):

@@ -126,6 +126,8 @@ def test_misaligned_device_pointers(pkg, oracle, dev, fmt, shift):
 
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_element_kernel_equals_tiled_kernel(pkg, oracle, dev, fmt):
+    if not pkg.tuning_mask() & 1:
+        pytest.skip("the element-granular kernel exists in the experiments side build only (-DDXTLT_EXPERIMENTS)")
     n = 4 * TILE[fmt]
     x = oracle.fill_splitmix64(n * BLOCK[fmt], 0xE1E)
     for s in all_settings(fmt):
@@ -194,12 +196,12 @@ def test_shifted_tiles(pkg, oracle, dev, fmt):
 
 @pytest.mark.parametrize("fmt", FORMATS)
 def test_forward_shifted_tiles_both_forms(pkg, oracle, dev, fmt):
-    """The forward shifted tiles exist in two forms: halo tiles (whole 16-byte segments only; the default) and the first
-    form with typed partial segments (experiment switch 0x400).  Both must equal the oracle on odd counts, on ranges
-    that start at odd blocks and on an SoA pointer that is itself misaligned."""
+    """The forward halo tiles (whole 16-byte segments only) -- and, in the experiments side build, the first form with typed
+    partial segments (switch 0x400) -- must equal the oracle on odd counts, on ranges that start at odd blocks and on an SoA
+    pointer that is itself misaligned."""
     t = TILE[fmt]
     B = BLOCK[fmt]
-    for force in (0, 0x400):
+    for force in ((0, 0x400) if pkg.tuning_mask() & 0x400 else (0,)):
         try:
             pkg.set_tuning(0, force)
             for n in (t + 1, 2 * t + 15, 9 * t + 7, 40 * t + 16 + 3):
@@ -225,19 +227,20 @@ def test_forward_shifted_tiles_both_forms(pkg, oracle, dev, fmt):
             pkg.set_tuning(0, 0)
 
 
-def test_timing_experiment_switch_is_inert_without_its_environment_variable(pkg, oracle, dev):
-    """Bit 0x10 of dxtlt_set_tuning's force_path leaves the halo / the partial segments out (a timing experiment with wrong
-    output).  A library call must not be able to switch correctness off: the bit is honoured only when
-    DXTLT_TIMING_EXPERIMENTS was in the environment when the library first read it."""
+def test_shipped_library_has_no_experiment_switch(pkg, oracle, dev):
+    """The shipped library honours two force_path bits (2: halo / shifted tiles always; 0x20: generic LDS accesses), both exact.
+    Everything else -- the element kernel (1), the wrong-output timing switch (0x10), store policies, tile orders, old routings --
+    lives in the -DDXTLT_EXPERIMENTS side build: here those bits must be absent from the mask and inert."""
     import os
-    if os.environ.get("DXTLT_TIMING_EXPERIMENTS") is not None:
-        pytest.skip("the timing experiments are switched on in this environment")
+    if os.environ.get("DXTLT_LIB_PATH"):
+        pytest.skip("another build of the library is under test")
+    assert pkg.tuning_mask() == 0x22
     for fmt in FORMATS:
         n = 9 * TILE[fmt] + 7
         x = oracle.fill_splitmix64(n * BLOCK[fmt], 0x71E + n)
         s = next(iter(all_settings(fmt)))
         try:
-            for force in (0x10, 0x10 | 0x400, 0x10 | 2):
+            for force in (1, 0x10, 0x10 | 0x400, 0x10 | 2, 0x40, 0x80, 0x100, 0x200, 0x800, 0x1000, 0x2000, 0x7FFFFFFF):
                 pkg.set_tuning(0, force)
                 assert np.array_equal(run_device(pkg, fmt, x, s, dev), fwd_oracle(oracle, fmt, x, s)), (fmt, hex(force))
         finally:

@@ -99,3 +99,19 @@ def test_single_call_halo_and_shifted_kernels_fetch_their_arguments_in_one_round
     late = [l for l in lines[wait:vmem] if l.startswith("s_load_dword") and f", {karg}, " in l]
     assert not late, late
     assert not any(l.startswith("flat_") for l in lines), "a pinned pointer lost its address space: flat accesses in the tile"
+
+
+@pytest.mark.parametrize("prefix, kernel, round4_scalars", [
+    ("_ZN5dxtlt14fwd_tiled_halo", "ILi3ELi1ELb1ELb1ELi0ELb1E", 535), ("_ZN5dxtlt14fwd_tiled_halo", "ILi1ELi1ELb0ELb1ELi0ELb1E", 474),
+    ("_ZN5dxtlt15inv_tiled_shift", "ILi3ELi1ELb1ELb1E", 728), ("_ZN5dxtlt15inv_tiled_shift", "ILi1ELi1ELb0ELb1E", 828)])
+def test_product_kernels_carry_no_experiment_scalars(single_asm, prefix, kernel, round4_scalars):
+    """Round 4's halo / shifted kernels pinned 19 Shifts fields into SGPRs, three of them experiment switches (tile order, store
+    policy, a wrong-output timing switch) that every workgroup fetched and branched on.  Those now exist only with
+    -DDXTLT_EXPERIMENTS: the product kernels' static scalar-instruction counts must stay below the round-4 figures (halo tiles:
+    535 -> 486 and 474 -> 427; shifted tiles, which only lost the tile-order switch: 728 -> 721 and 828 -> 822)."""
+    lines = kernel_body(single_asm, kernel, prefix)
+    scalars = sum(1 for l in lines if l.startswith("s_") and not l.endswith(":"))
+    assert scalars < round4_scalars, (scalars, round4_scalars)
+    if "halo" in prefix:
+        assert scalars <= round4_scalars - 40, (scalars, round4_scalars)
+    assert not any("generic_kernel" in l or "fwd_tiled_shift" in l for l in single_asm.splitlines() if l.startswith("_ZN"))

@@ -2,6 +2,7 @@
 # Same-box A/B of whole library versions: builds the library as of git revision REV (all sources) into ab/libdxtlt_NAME.so,
 # to be run beside the current one through DXTLT_LIB_PATH on ONE gpurun box (box-to-box spread is +-0.02 of peak).
 #     tools/ab_build_rev.sh HEAD~3 r3
+#     DXTLT_EXTRA_HIPCC_FLAGS=-DDXTLT_EXPERIMENTS tools/ab_build_rev.sh WORKTREE exp     (the experiments side build)
 #     gpurun -- 'for lib in ab/libdxtlt_r3.so dxt-lossless-transform_amd/libdxtlt_gfx950.so; do
 #                  DXTLT_LIB_PATH=$GRAFT_REPO_ROOT/$lib python tools/batch_shape_probe.py; done'
 # ab/ is git-ignored; remove it afterwards (it travels with every gpurun push).
@@ -15,12 +16,14 @@ if [ "$REV" = WORKTREE ]; then      # the working tree as it is (with DXTLT_EXTR
 else
   git -C $R archive $REV dxt-lossless-transform_amd include | tar -x -C $W
 fi
-python3 - <<PY
+BUILT=$(python3 - <<PY
 import importlib.util, sys
 spec = importlib.util.spec_from_file_location("_build", "$W/dxt-lossless-transform_amd/_build.py")
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-print(m.build(force=True))
+print(m.build(force=True))     # the shipped path, or build/side-<hash>/ when DXTLT_EXTRA_HIPCC_FLAGS is set (a side build)
 PY
-cp $W/dxt-lossless-transform_amd/libdxtlt_gfx950.so $R/ab/libdxtlt_$NAME.so
+)
+BUILT=$(echo "$BUILT" | tail -1)
+cp "$BUILT" $R/ab/libdxtlt_$NAME.so
 rm -rf $W
 echo "built $R/ab/libdxtlt_$NAME.so (as of $REV)"
