@@ -701,8 +701,8 @@ def corpus_layout(texs, block_bytes: int, align: int = 256):
 def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_scale: float = 1.0, cpu: bool = True,
                    align: int = 256) -> dict:
     """One corpus-shaped leg (see CORPUS_CLASSES): device-resident textures, one batch call per direction, HIP events per
-    direction, exact round trip over the whole arena, oracle equality on three whole textures (the smallest, a middle one,
-    one of the largest)."""
+    direction, exact round trip over the whole arena (gaps between textures included, in both outputs), oracle equality on
+    every 16th texture in size order plus the smallest, a middle one and the largest."""
     import numpy as np
 
     from dxt_lossless_transform_amd import batch
@@ -738,9 +738,17 @@ def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_sca
     order = sorted(range(len(texs)), key=lambda i: texs[i][2])
     ok = True
     mode, sa, sc = int(st.decorrelation_mode), getattr(st, "split_alpha_endpoints", True), st.split_colour_endpoints
-    for i in (order[0], order[len(order) // 2], order[-1]):
+    # against the oracle: every 16th texture in size order, and the smallest, a middle one, the largest (whole textures)
+    checked = sorted(set(order[::16]) | {order[0], order[len(order) // 2], order[-1]})
+    for i in checked:
         want = oracle_c.transform(fmt, views[i][0].cpu().numpy(), mode, sc, sa)
         ok = ok and bool(np.array_equal(views[i][1].cpu().numpy(), want))
+    # The 1-255 bytes between one texture's end and the next one's start must still be zero in BOTH outputs: the forward edge
+    # tiles write narrow pieces at every stream end and up to four extra segments past each window, and a store that strayed into
+    # a gap (or into a neighbour the inverse does not read back wrongly) would leave the round trip exact.  (z: torch.equal(z, x)
+    # below covers its gaps; y is checked here.)
+    gaps = [y[o + n * B:(o + n * B + align - 1) // align * align] for (_, _, n), o in zip(texs, offs)]
+    gaps_clean = not bool(torch.cat([g for g in gaps if g.numel()]).any()) if any(g.numel() for g in gaps) else True
     odd = sum(1 for _, _, n in texs if n % 2)
     leg = leg_record(
         f"{fmt.upper()} corpus shape of the reference's published benchmark (bc1-api README.MD:286-311: 2130 files, 8692.9 MiB): "
@@ -748,7 +756,8 @@ def run_corpus_leg(pkg, torch, dev, fmt: str, steps: int, warmup: int, count_sca
         f"{odd} of them with an odd block count, each at the next 256-byte boundary of one arena; default settings; ONE "
         "dxtlt_transform_batch_device call per direction", nbytes, f_ms, i_ms, wall, steps,
         f"batch tiles<{fmt}> forward (halo + edge tiles)", f"batch tiles<{fmt}> inverse (shifted + edge tiles)",
-        {"bit_exact_roundtrip": bool(torch.equal(z, x)), "oracle_textures_exact": ok, "textures": len(texs),
+        {"bit_exact_roundtrip": bool(torch.equal(z, x)), "oracle_textures_exact": ok, "oracle_textures_checked": len(checked),
+         "forward_gaps_exact": gaps_clean, "textures": len(texs),
          "smallest_blocks": texs[order[0]][2], "largest_blocks": texs[order[-1]][2]})
     if cpu:
         sample = views[order[-1]][0].cpu().numpy()

@@ -114,6 +114,10 @@ thread_local Arena g_arena;
 // the callbacks must be safe to call from several threads at once with the same Context.
 // ---------------------------------------------------------------------------------------------------------------
 std::atomic<int> g_estimator_threads{1};
+// per-thread cap on top of it (dxtlt_set_auto_estimator_threads_for_this_thread): 0 = none.  A binding whose estimator type
+// makes no thread-safety promise (the Rust glue: `T: SizeEstimationOperations` without `Sync`) sets 1 around its call, so that
+// its soundness does not rest on nobody in the process having called the process-wide setter.
+thread_local int t_estimator_threads_cap = 0;
 constexpr size_t kStageCapBytes = size_t(512) << 20;   // pinned staging per wave of sections (one section at least)
 
 struct HostStage {
@@ -238,6 +242,13 @@ extern "C" void dxtlt_set_auto_estimator_threads(int32_t threads)
 
 extern "C" int32_t dxtlt_get_auto_estimator_threads(void) { return g_estimator_threads.load(std::memory_order_relaxed); }
 
+extern "C" int32_t dxtlt_set_auto_estimator_threads_for_this_thread(int32_t cap)
+{
+    const int32_t before = t_estimator_threads_cap;
+    t_estimator_threads_cap = cap < 0 ? 0 : cap > 64 ? 64 : cap;
+    return before;
+}
+
 void dxtlt_host::release_auto_thread_arena()
 {
     g_arena.release();
@@ -292,7 +303,7 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
             return rc;
         }
         HIP_TRY_AUTO(hipMemcpyAsync(d_in, in, len, hipMemcpyHostToDevice, st), "H2D copy");
-        static const bool fused = [] { const char* v = std::getenv("DXTLT_AUTO_FUSED"); return !(v && v[0] == '0'); }();
+        static const bool fused = [] { const char* v = dxtlt::experiment_env("DXTLT_AUTO_FUSED"); return !(v && v[0] == '0'); }();
         if (fused)
             arena = static_cast<uint8_t*>(g_arena.get((size_t)dxtlt::auto_arena_bytes((dxtlt::Format)format, use_all, blocks)));
         if (arena != nullptr)
@@ -310,7 +321,9 @@ int32_t dxtlt_host::transform_auto(int32_t format, const uint8_t* in, uint8_t* o
         count = use_all ? 8 : 4;
     }
 
-    const int est_threads = g_estimator_threads.load(std::memory_order_relaxed);
+    int est_threads = g_estimator_threads.load(std::memory_order_relaxed);
+    if (t_estimator_threads_cap > 0 && est_threads > t_estimator_threads_cap)
+        est_threads = t_estimator_threads_cap;
     const bool parallel = est_threads > 1 && arena != nullptr && len > 0;
     if (parallel) {
         // distinct sections: colour (variant, split) pairs in the arena's order, then BC3's two alpha-endpoint sections

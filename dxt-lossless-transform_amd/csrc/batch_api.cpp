@@ -33,7 +33,8 @@ using namespace dxtlt_host;
 using dxtlt::BatchEntry;
 
 // Table staging: a ring of pinned host buffers with device twins.  A slot is reused only after the copy that last read
-// it has finished (its event), so the call never blocks unless more than kSlots batches are in flight.
+// it has finished (its event).  A call takes at most three slots (BC7 forward, BC7 inverse, one buffer for the tables of all its
+// BC1-3 groups), so it never waits for its own work, and blocks only when more than one earlier call is still in flight.
 constexpr int kSlots = 4;
 
 struct TableSlot {
@@ -111,7 +112,7 @@ thread_local TableRing g_ring;
 
 // DXTLT_BATCH_TABLE_COPY=1: the table travels by hipMemcpyAsync (the first version; kept for the comparison in
 // profiles/r02_m_batch_kernel.txt)
-const bool kTableByCopyEngine = std::getenv("DXTLT_BATCH_TABLE_COPY") != nullptr && std::getenv("DXTLT_BATCH_TABLE_COPY")[0] == '1';
+const bool kTableByCopyEngine = dxtlt::experiment_env("DXTLT_BATCH_TABLE_COPY") != nullptr && dxtlt::experiment_env("DXTLT_BATCH_TABLE_COPY")[0] == '1';
 
 hipError_t upload_table(TableSlot* slot, size_t bytes, hipStream_t stream)
 {
@@ -202,8 +203,8 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         else if (wgs != g.uniform_wgs)
             g.uniform = false;
     }
-    static const bool no_uniform = std::getenv("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switches (tools/batch_kernel_probe.py)
-    static const bool no_strided = std::getenv("DXTLT_BATCH_NO_STRIDED") != nullptr;
+    static const bool no_uniform = dxtlt::experiment_env("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switches of the experiments build (tools/batch_kernel_probe.py)
+    static const bool no_strided = dxtlt::experiment_env("DXTLT_BATCH_NO_STRIDED") != nullptr;
 
     // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one
     for (int inverse = 0; inverse < 2; ++inverse) {
@@ -257,38 +258,59 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             return fail(kDevice, "batch event", ev);
     }
 
+    // Every group's table (entries, then the workgroup index) goes into ONE staged buffer and ONE upload per call, at 16-byte
+    // aligned offsets.  (One ring slot per group made a call with many settings combinations -- rare in a corpus, routine in the
+    // fuzz: up to 96 groups -- wait in hipEventSynchronize for kernels this same call had enqueued: the "asynchronous" call then
+    // drained its own work, and would deadlock under a caller whose stream is gated on an event recorded after the call returns.)
+    // With the two BC7 tables above a call takes at most three of the ring's slots.
+    struct Placed {
+        int gi;
+        size_t at, entry_bytes;
+    };
+    std::vector<Placed> placed;
+    size_t table_bytes = 0;
     for (int gi = 0; gi < kGroups; ++gi) {
-        Group& g = groups[gi];
+        const Group& g = groups[gi];
         if (g.entries.empty())
             continue;
-        const size_t n = g.entries.size();
-        const size_t entry_bytes = (n * sizeof(BatchEntry) + 15) & ~(size_t)15;
-        const size_t bytes = entry_bytes + dxtlt::batch_index_bytes(g.wgs);
+        const size_t entry_bytes = (g.entries.size() * sizeof(BatchEntry) + 15) & ~(size_t)15;
+        placed.push_back({gi, table_bytes, entry_bytes});
+        table_bytes += entry_bytes + dxtlt::batch_index_bytes(g.wgs);
+    }
+    if (!placed.empty()) {
         TableSlot* slot = nullptr;
-        hipError_t e = g_ring.acquire(bytes, &slot);
+        hipError_t e = g_ring.acquire(table_bytes, &slot);
         if (e != hipSuccess)
             return fail(kDevice, "batch table staging", e);
-        std::memcpy(slot->host, g.entries.data(), n * sizeof(BatchEntry));
-        dxtlt::build_batch_index(g.entries.data(), n, g.wgs, static_cast<uint8_t*>(slot->host) + entry_bytes);
-        const bool uniform = g.uniform && !no_uniform;
-        // a regular array of buffers: one size and tile form, pointers a constant stride apart
-        bool strided = uniform && !no_strided;   // (one buffer is a regular array too)
-        const int64_t src_stride = n >= 2 ? (int64_t)(g.entries[1].src - g.entries[0].src) : 0;
-        const int64_t dst_stride = n >= 2 ? (int64_t)(g.entries[1].dst - g.entries[0].dst) : 0;
-        for (size_t i = 1; i < n && strided; ++i) {
-            const BatchEntry &a = g.entries[0], &b = g.entries[i];
-            strided = b.blocks == a.blocks && b.full_tiles == a.full_tiles && b.form == a.form && b.halo_vecs == a.halo_vecs &&
-                      std::memcmp(b.shift, a.shift, sizeof a.shift) == 0 && std::memcmp(b.gbase, a.gbase, sizeof a.gbase) == 0 &&
-                      b.src == a.src + (int64_t)i * src_stride && b.dst == a.dst + (int64_t)i * dst_stride;
+        std::vector<bool> wide(placed.size());
+        for (size_t k = 0; k < placed.size(); ++k) {
+            const Group& g = groups[placed[k].gi];
+            uint8_t* h = static_cast<uint8_t*>(slot->host) + placed[k].at;
+            std::memcpy(h, g.entries.data(), g.entries.size() * sizeof(BatchEntry));
+            wide[k] = dxtlt::build_batch_index(g.entries.data(), g.entries.size(), g.wgs, h + placed[k].entry_bytes);
         }
-        e = upload_table(slot, bytes, user);
-        if (e == hipSuccess)
+        e = upload_table(slot, table_bytes, user);
+        for (size_t k = 0; k < placed.size() && e == hipSuccess; ++k) {
+            const int gi = placed[k].gi;
+            Group& g = groups[gi];
+            const size_t n = g.entries.size();
+            const bool uniform = g.uniform && !no_uniform;
+            // a regular array of buffers: one size and tile form, pointers a constant stride apart
+            bool strided = uniform && !no_strided;   // (one buffer is a regular array too)
+            const int64_t src_stride = n >= 2 ? (int64_t)(g.entries[1].src - g.entries[0].src) : 0;
+            const int64_t dst_stride = n >= 2 ? (int64_t)(g.entries[1].dst - g.entries[0].dst) : 0;
+            for (size_t i = 1; i < n && strided; ++i) {
+                const BatchEntry &a = g.entries[0], &b = g.entries[i];
+                strided = b.blocks == a.blocks && b.full_tiles == a.full_tiles && b.form == a.form && b.halo_vecs == a.halo_vecs &&
+                          std::memcmp(b.shift, a.shift, sizeof a.shift) == 0 && std::memcmp(b.gbase, a.gbase, sizeof a.gbase) == 0 &&
+                          b.src == a.src + (int64_t)i * src_stride && b.dst == a.dst + (int64_t)i * dst_stride;
+            }
+            const uint8_t* d = static_cast<const uint8_t*>(slot->dev) + placed[k].at;
             e = dxtlt::launch_batch((dxtlt::Format)((gi >> 5) + 1), ((gi >> 4) & 1) != 0, group_settings(gi),
-                                    static_cast<const BatchEntry*>(slot->dev),
-                                    static_cast<const uint8_t*>(slot->dev) + entry_bytes,
-                                    (uint32_t)n, g.wgs, uniform ? g.uniform_wgs : 0, user,
-                                    strided ? &g.entries[0] : nullptr, src_stride, dst_stride);
-        // the event marks both the copy and the kernel that reads the device table
+                                    reinterpret_cast<const BatchEntry*>(d), d + placed[k].entry_bytes, (uint32_t)n, g.wgs,
+                                    uniform ? g.uniform_wgs : 0, wide[k], user, strided ? &g.entries[0] : nullptr, src_stride, dst_stride);
+        }
+        // the event marks both the copy and the kernels that read the device table
         hipError_t ev = hipEventRecord(slot->done, user);
         slot->pending = ev == hipSuccess;
         if (e != hipSuccess)
@@ -319,8 +341,11 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
 // one the batch kernel does not take (dxtlt_transform_batch_device launches those alone).
 extern "C" uint32_t dxtlt_debug_plan_batch(int32_t format, int32_t inverse, int32_t variant, int32_t split_alpha, int32_t split_colour,
                                            const uint64_t* src_addresses, const uint64_t* dst_addresses, const uint64_t* blocks, size_t count,
-                                           DxtltDebugPlannedEntry* entries_out, uint8_t* index_out, size_t index_capacity)
+                                           DxtltDebugPlannedEntry* entries_out, uint8_t* index_out, size_t index_capacity,
+                                           uint32_t* index_is_wide_out)
 {
+    if (index_is_wide_out)
+        *index_is_wide_out = 0;
     if (format < 1 || format > 3 || (count != 0 && (!src_addresses || !dst_addresses || !blocks || !entries_out)))
         return 0xFFFFFFFFu;
     dxtlt::Settings s{};
@@ -355,7 +380,9 @@ extern "C" uint32_t dxtlt_debug_plan_batch(int32_t format, int32_t inverse, int3
     if (total != 0) {
         if (index_out == nullptr || index_capacity < dxtlt::batch_index_bytes(total))
             return 0xFFFFFFFFu;
-        dxtlt::build_batch_index(entries.data(), entries.size(), total, index_out);
+        const bool wide = dxtlt::build_batch_index(entries.data(), entries.size(), total, index_out);
+        if (index_is_wide_out)
+            *index_is_wide_out = wide ? 1 : 0;
     }
     return total;
 }

@@ -16,6 +16,7 @@
 //     per-stream bases (Shifts::gbase) ready-made instead of six 64-bit products per workgroup.
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "bcn_device.h"
 
@@ -69,7 +70,7 @@ __device__ __forceinline__ void pin_batch_view(BatchView& v)
     for (int i = 0; i < 6; ++i)
         asm("" : "+s"(v.gbase[i]));
 }
-static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, full_tiles) == 32 && offsetof(BatchEntry, form) == 36 &&
+static_assert(offsetof(BatchEntry, first_wg) == 24 && offsetof(BatchEntry, end_wg) == 28 && offsetof(BatchEntry, full_tiles) == 32 && offsetof(BatchEntry, form) == 36 &&
                   offsetof(BatchEntry, shift) == 40 && offsetof(BatchEntry, gbase) == 48,
               "load_batch_entry reads BatchEntry by dword offsets");
 
@@ -172,17 +173,34 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
         // first time 0.72-0.76 whatever it saves in round trips (a 144-byte record per 256 workgroups with the entry inline:
         // 0.72; a 16-byte bit mask per 64: 0.76; 4 bytes per 64: 0.77).  So the index is as small as it can be -- one byte per 64
         // workgroups, a cache line per 4096 -- and the entry, shared by all workgroups of its buffer, is what is fetched behind it.
+        // Wide form (bit 31 of n_base; build_batch_index): 16-bit deltas, for launches in which more than 255 entries begin inside
+        // one 4096-workgroup span -- thousands of buffers of one to three tiles -- where a byte would saturate and leave a walk of
+        // up to ~3800 entries.  Branch-free on purpose: both forms issue the same two index loads.
         const uint32_t* base = reinterpret_cast<const uint32_t*>(index);
-        const uint8_t* delta = index + n_base * 4;
+        const uint32_t wide = n_base >> 31;
+        const uint8_t* delta = index + (n_base & 0x7FFFFFFFu) * 4;
         e = base[wg >> 12];
-        const uint32_t dword = reinterpret_cast<const uint32_t*>(delta)[wg >> 8];   // (a scalar load is a dword load)
-        e += (dword >> (8u * ((wg >> 6) & 3u))) & 0xFFu;
+        const uint32_t dword = reinterpret_cast<const uint32_t*>(delta)[wg >> (8u - wide)];   // (a scalar load is a dword load)
+        e += (dword >> (((wg >> 6) & (3u >> wide)) << (3u + wide))) & (0xFFu | (wide * 0xFF00u));
         en = load_batch_entry(entries + e);
         // every field is needed HERE (empty non-volatile asm: the value becomes opaque, memory is untouched, the loads stay
-        // scalar): left alone the compiler fetches end_wg, runs the loop and only then asks for the rest of the entry
+        // scalar): left alone the compiler fetches end_wg, runs the search and only then asks for the rest of the entry
         pin_batch_view(en);
-        while (en.end_wg <= wg) {   // only buffers of fewer than 64 workgroups take this
-            ++e;
+        if (en.end_wg <= wg) {
+            // Only buffers of fewer than 64 workgroups take this: `e` owns workgroup 64 * (wg / 64), so the owner of `wg` is one of
+            // the next (wg & 63) entries.  Bisection over their end_wg fields -- at most six dependent dword loads, where walking
+            // on entry by entry took up to 63 loads of a whole 96-byte entry (`magic` carries the entry count in this mode).
+            uint32_t lo = e + 1, hi = e + (wg & 63u);
+            hi = hi < magic - 1u ? hi : magic - 1u;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t end = reinterpret_cast<const uint32_t*>(entries + mid)[7];   // BatchEntry::end_wg
+                if (end <= wg)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            e = lo;
             en = load_batch_entry(entries + e);
         }
     }
@@ -289,12 +307,14 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
     return wgs;
 }
 
-void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, uint8_t* index)
+bool build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, uint8_t* index)
 {
     const size_t n_base = batch_index_base_count(total_wgs), n_delta = batch_index_delta_count(total_wgs);
     uint32_t* base = reinterpret_cast<uint32_t*>(index);
-    uint8_t* delta = index + n_base * 4;
     std::memset(index, 0, batch_index_bytes(total_wgs));
+    // owner of workgroup 64 j for every j, relative to the owner of the span's first workgroup
+    std::vector<uint32_t> d(n_delta);
+    uint32_t largest = 0;
     size_t cur = 0;
     for (size_t j = 0; j < n_delta; ++j) {
         const uint32_t wg = (uint32_t)(j * kBatchIndexWgs);
@@ -302,9 +322,20 @@ void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t tot
             ++cur;
         if (wg % kBatchBaseWgs == 0)
             base[wg / kBatchBaseWgs] = (uint32_t)cur;
-        const size_t d = cur - base[wg / kBatchBaseWgs];
-        delta[j] = (uint8_t)(d > 255 ? 255 : d);   // saturated: the kernel walks on from there
+        d[j] = (uint32_t)(cur - base[wg / kBatchBaseWgs]);   // < 4096: every entry owns at least one workgroup
+        largest = std::max(largest, d[j]);
     }
+    const bool wide = largest > 255;
+    uint8_t* delta = index + n_base * 4;
+    for (size_t j = 0; j < n_delta; ++j) {
+        if (wide) {
+            delta[2 * j] = (uint8_t)d[j];
+            delta[2 * j + 1] = (uint8_t)(d[j] >> 8);
+        } else {
+            delta[j] = (uint8_t)d[j];
+        }
+    }
+    return wide;
 }
 
 namespace {
@@ -338,7 +369,7 @@ BatchFn batch_variant(int variant, bool sa, bool sc, bool inverse)
 }  // namespace
 
 hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint8_t* d_index,
-                        uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
+                        uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, bool wide_index, hipStream_t stream,
                         const BatchEntry* strided_first, int64_t src_stride, int64_t dst_stride)
 {
     if (n_entries == 0 || total_wgs == 0)
@@ -347,10 +378,12 @@ hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const Batch
         return hipErrorInvalidValue;
     if (uniform_wgs != 0 && (uint64_t)uniform_wgs * n_entries != total_wgs)
         return hipErrorInvalidValue;
-    const uint32_t magic = uniform_wgs > 1 ? (uint32_t)((1ull << 32) / uniform_wgs) : 0;
-    if (uniform_wgs == 1)
-        uniform_wgs = 0;   // 2^32 does not fit the magic word; one workgroup per buffer takes the general lookup
-    static const bool no_array = std::getenv("DXTLT_BATCH_NO_ARRAY") != nullptr;   // A/B switch
+    // uniform: floor(2^32 / uniform_wgs), the kernel's multiply-high is exact or one short and one compare puts it right.  One
+    // workgroup per buffer (thousands of textures of a tile or less): 2^32 - 1 stands in for 2^32 -- the product's high word is
+    // wg - 1 (0 for wg 0), the same compare makes it wg: e == wg without a table lookup.  General lookup: the entry count (the
+    // bound of the kernel's bisection).
+    const uint32_t magic = uniform_wgs > 1 ? (uint32_t)((1ull << 32) / uniform_wgs) : uniform_wgs == 1 ? 0xFFFFFFFFu : n_entries;
+    static const bool no_array = experiment_env("DXTLT_BATCH_NO_ARRAY") != nullptr;   // A/B switch (experiments build)
     if (strided_first != nullptr && uniform_wgs != 0 && !no_array && strided_first->form == 1) {
         const hipError_t e = launch_tiled_array(fmt, inverse, s, strided_first->src, strided_first->dst, strided_first->blocks, n_entries,
                                                 src_stride, dst_stride, stream);
@@ -372,8 +405,8 @@ hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const Batch
     case kBc3: k = batch_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_index, (uint32_t)batch_index_base_count(total_wgs), uniform_wgs, magic,
-                       strided);
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_index,
+                       (uint32_t)batch_index_base_count(total_wgs) | (wide_index ? 0x80000000u : 0u), uniform_wgs, magic, strided);
     return hipGetLastError();
 }
 

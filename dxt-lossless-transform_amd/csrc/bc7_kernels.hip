@@ -472,12 +472,19 @@ hipError_t launch_range(bool inverse, const void* src, void* dst, uint64_t total
     const uint8_t* aos = static_cast<const uint8_t*>(inverse ? dst : src);     // the range's first block
     const uint8_t* soa = static_cast<const uint8_t*>(inverse ? src : dst);     // byte 0 of the whole transformed buffer
     const uint64_t range_main = first_block >= main_blocks ? 0 : (first_block + num_blocks > main_blocks ? main_blocks : first_block + num_blocks) - first_block;
-    // Workgroup size: 256 lanes x 4 blocks per lane unless DXTLT_BC7_LANES says 512 or 1024 (experiments; DESIGN.md
-    // section 9 has the measurements).  A launch of 2^32 or more threads is refused: at most 2^21 granules per launch.
-    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 512 || x == 1024 ? x : 256; }();
+    // Workgroup size: 256 lanes x 4 blocks per lane (DESIGN.md section 8 has the measurements; the experiments side build,
+    // -DDXTLT_EXPERIMENTS, also carries the 512- and 1024-lane kernels behind DXTLT_BC7_LANES).  A launch of 2^32 or more
+    // threads is refused: at most 2^21 granules per launch.
     using Kernel = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, int);
+#ifdef DXTLT_EXPERIMENTS
+    static const int lanes = [] { const char* v = std::getenv("DXTLT_BC7_LANES"); const int x = v ? std::atoi(v) : 0; return x == 512 || x == 1024 ? x : 256; }();
     const Kernel fwd = lanes == 1024 ? bc7_forward<1024, false> : lanes == 512 ? bc7_forward<512, false> : bc7_forward<256, false>;
     const Kernel inv = lanes == 1024 ? bc7_inverse<1024, false> : lanes == 512 ? bc7_inverse<512, false> : bc7_inverse<256, false>;
+#else
+    constexpr int lanes = 256;
+    const Kernel fwd = bc7_forward<256, false>;
+    const Kernel inv = bc7_inverse<256, false>;
+#endif
     constexpr uint64_t kMaxGranules = 1ull << 21;
     for (uint64_t g0 = 0; g0 < range_main / kT; g0 += kMaxGranules) {
         const uint64_t ng = range_main / kT - g0 < kMaxGranules ? range_main / kT - g0 : kMaxGranules;

@@ -4,7 +4,21 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace dxtlt {
+
+// A/B switches read from the environment exist in the experiments side build only (-DDXTLT_EXPERIMENTS, bcn_device.h): in the
+// shipped library the variable is never looked at.
+inline const char* experiment_env(const char* name)
+{
+#ifdef DXTLT_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 enum Format : int { kBc1 = 1, kBc2 = 2, kBc3 = 3 };
 
@@ -105,17 +119,19 @@ static_assert(sizeof(BatchEntry) == 96, "BatchEntry layout is shared between hos
 // The workgroup -> entry index of a batch launch, in two levels so that the bytes a workgroup reads are shared with as many other
 // workgroups of its CU as possible (what a lookup costs is its scalar-cache MISSES, not its round trips: batch_kernels.hip):
 //   base[k]   (uint32) for workgroups [4096 k, 4096 k + 4096): the entry that owns workgroup 4096 k
-//   delta[j]  (uint8)  for workgroups [64 j, 64 j + 64): entry that owns workgroup 64 j, minus base[j / 64], saturated at 255
-// base[wg / 4096] + delta[wg / 64] is the owner of workgroup 64 * (wg / 64) or, when more than 255 entries begin inside one
-// 4096-workgroup span, an entry in front of it; every entry carries its own end_wg and the kernel walks on from there.
-// One 64-byte line of `delta` serves 4096 workgroups (sixteen per CU), one of `base` 65536.
+//   delta[j]  for workgroups [64 j, 64 j + 64): entry that owns workgroup 64 j, minus base[j / 64] -- a byte each; 16 bits each
+//             (the WIDE form) when more than 255 entries begin inside some 4096-workgroup span, i.e. for launches of thousands of
+//             buffers of a few tiles, so that the delta never saturates
+// base[wg / 4096] + delta[wg / 64] is the owner of workgroup 64 * (wg / 64); the owner of wg is that entry or one of the next
+// wg % 64, found by bisection over the entries' end_wg.  One 64-byte line of byte deltas serves 4096 workgroups (sixteen per
+// CU), one of `base` 65536.
 constexpr uint32_t kBatchIndexWgs = 64, kBatchBaseWgs = 4096;
 inline size_t batch_index_base_count(uint32_t total_wgs) { return ((size_t)total_wgs + kBatchBaseWgs - 1) / kBatchBaseWgs; }
 inline size_t batch_index_delta_count(uint32_t total_wgs) { return ((size_t)total_wgs + kBatchIndexWgs - 1) / kBatchIndexWgs; }
-// bytes of the index as build_batch_index lays it out: base[] then delta[], padded to 16
+// bytes of the index as build_batch_index lays it out -- base[] then delta[] -- with room for the wide form, padded to 16
 inline size_t batch_index_bytes(uint32_t total_wgs)
 {
-    return (batch_index_base_count(total_wgs) * 4 + batch_index_delta_count(total_wgs) + 15) & ~(size_t)15;
+    return (batch_index_base_count(total_wgs) * 4 + 2 * batch_index_delta_count(total_wgs) + 15) & ~(size_t)15;
 }
 
 // Fills first_wg-relative planning fields of `e` (src, dst, blocks set by the caller; first_wg too) for settings `s` and
@@ -127,18 +143,19 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
 // with a small kernel on `stream` -- no copy-engine hand-over in front of the batch kernel.
 hipError_t launch_table_upload(const void* host_mapped, void* dev, size_t bytes, hipStream_t stream);
 
-// d_entries / d_index: device copies of the entry table and of the workgroup index (build_batch_index: base[] then delta[]),
-// total_wgs = end_wg of the last entry.
+// d_entries / d_index: device copies of the entry table and of the workgroup index (build_batch_index: base[] then delta[];
+// wide_index = its return value), total_wgs = end_wg of the last entry.
 // uniform_wgs: 0, or the number of workgroups EVERY entry owns (first_wg == index * uniform_wgs): the kernel then finds a
-// workgroup's entry by division instead of through the coarse index.
+// workgroup's entry by division instead of through the index (1: the entry IS the workgroup number).
 // strided_first != nullptr (needs uniform_wgs != 0): the batch is a regular array -- every entry equals *strided_first but for
 // its pointers, which advance by src_stride / dst_stride bytes per entry; the kernel then reads no table at all.
 hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const BatchEntry* d_entries, const uint8_t* d_index,
-                        uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, hipStream_t stream,
+                        uint32_t n_entries, uint32_t total_wgs, uint32_t uniform_wgs, bool wide_index, hipStream_t stream,
                         const BatchEntry* strided_first = nullptr, int64_t src_stride = 0, int64_t dst_stride = 0);
 
-// the index (batch_index_bytes(total_wgs) bytes) from the entries (sorted by first_wg, each owning at least one workgroup, no gaps)
-void build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, uint8_t* index);
+// the index (batch_index_bytes(total_wgs) bytes) from the entries (sorted by first_wg, each owning at least one workgroup, no
+// gaps); returns true when it chose the wide (16-bit delta) form
+bool build_batch_index(const BatchEntry* entries, size_t n_entries, uint32_t total_wgs, uint8_t* index);
 
 // A regular array of aligned buffers as the single-buffer aligned kernel with blockIdx.y = buffer (bcn_kernels.hip);
 // hipErrorNotSupported when the array does not have that shape.

@@ -44,12 +44,16 @@ inline unsigned lds_pad_for_wgs_per_cu(int wgs_per_cu, unsigned threads, unsigne
     return want > static_lds ? want - static_lds : 0u;
 }
 
-// the cap a kernel runs with: its measured best, unless DXTLT_EXPERIMENT_WGS_PER_CU=<n> (read once per process) overrides
-// it for the kernels that take one (n = 8: no cap)
+// the cap a kernel runs with: its measured best; in the experiments side build (-DDXTLT_EXPERIMENTS) DXTLT_EXPERIMENT_WGS_PER_CU=<n>
+// (read once per process) overrides it for the kernels that take one (n = 8: no cap)
 inline int wgs_per_cu_or(int measured_best)
 {
+#ifdef DXTLT_EXPERIMENTS
     static const int v = [] { const char* e = std::getenv("DXTLT_EXPERIMENT_WGS_PER_CU"); return e ? std::atoi(e) : 0; }();
     return v > 0 ? v : measured_best;
+#else
+    return measured_best;
+#endif
 }
 
 #if defined(__HIPCC__)

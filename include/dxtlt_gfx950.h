@@ -108,6 +108,10 @@ int32_t dxtlt_transform_bc3_auto(const uint8_t *input_ptr, uint8_t *output_ptr, 
  * to call from several threads with the same Context (each call gets its own scratch buffer).  Process-wide. */
 void dxtlt_set_auto_estimator_threads(int32_t threads);
 int32_t dxtlt_get_auto_estimator_threads(void);
+/* A cap on the above for auto transforms called FROM THE CALLING THREAD (0 = no cap; returns the previous cap).  For bindings
+ * whose estimator type makes no thread-safety promise: with a cap of 1 around the call the callbacks run one at a time on the
+ * calling thread whatever the process-wide setting says (rust/core-bodies/gfx950_glue.rs: SerialEstimatorCalls). */
+int32_t dxtlt_set_auto_estimator_threads_for_this_thread(int32_t cap);
 
 /* ---- device pointers, whole buffer, asynchronous on `hip_stream` (a hipStream_t; NULL = default) -- */
 int32_t dxtlt_transform_bc1_with_settings_device(const void *d_input, void *d_output, size_t len,
@@ -171,10 +175,12 @@ int32_t dxtlt_transform_batch_device(const DxtltBatchItem *items, size_t count, 
 /* Test hook, no device needed: plans `count` buffers of one format, direction and settings the way
  * dxtlt_transform_batch_device plans one launch (addresses are numbers here, nothing is dereferenced) and returns the
  * launch's workgroups; entries_out[i] describes buffer i (an empty buffer owns no workgroup), index_out receives the
- * workgroup -> entry index: uint32 base[ceil(wgs / 4096)], then uint8 delta[ceil(wgs / 64)] -- the owner of workgroup w is
- * the first entry at or behind base[w / 4096] + delta[w / 64] (counting buffers that own workgroups) whose end_wg > w.
- * 0xFFFFFFFF: index_capacity too small, or a buffer the batch kernel does not take (stream bases off their element
- * width: launched alone by the batch call). */
+ * workgroup -> entry index: uint32 base[ceil(wgs / 4096)], then delta[ceil(wgs / 64)] -- uint8 each, or (*index_is_wide_out
+ * == 1: more than 255 buffers begin inside some span of 4096 workgroups) little-endian uint16 each; base[w / 4096] +
+ * delta[w / 64] (counting buffers that own workgroups) is the owner of workgroup 64 * (w / 64), and the owner of w is that
+ * entry or one of the next w % 64: the first whose end_wg > w.  index_capacity: at least 4 * ceil(wgs / 4096) +
+ * 2 * ceil(wgs / 64) + 15.  0xFFFFFFFF: index_capacity too small, or a buffer the batch kernel does not take (stream bases
+ * off their element width: launched alone by the batch call). */
 typedef struct DxtltDebugPlannedEntry {
     uint32_t first_wg, end_wg;   /* workgroups [first_wg, end_wg): whole tiles first, then the edge tile if there is one */
     uint32_t full_tiles;
@@ -185,7 +191,8 @@ typedef struct DxtltDebugPlannedEntry {
 } DxtltDebugPlannedEntry;
 uint32_t dxtlt_debug_plan_batch(int32_t format, int32_t inverse, int32_t variant, int32_t split_alpha, int32_t split_colour,
                                 const uint64_t *src_addresses, const uint64_t *dst_addresses, const uint64_t *blocks, size_t count,
-                                DxtltDebugPlannedEntry *entries_out, uint8_t *index_out, size_t index_capacity);
+                                DxtltDebugPlannedEntry *entries_out, uint8_t *index_out, size_t index_capacity,
+                                uint32_t *index_is_wide_out);
 
 /* The same for HOST buffers (d_input / d_output of every item are host pointers here) -- the reference's own call
  * pattern: one call per file, host pointers, textures of 0.1-20 MiB (tools/dxt-lossless-transform-cli/src/commands/

@@ -3,7 +3,7 @@
 //! Candidate order, the estimated section, the strict `<` tie-break and the final transform with the winner are
 //! implemented on the library side exactly as in the reference (csrc/auto_transform.cpp), so the same estimator
 //! yields the same settings and the same bytes.
-use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge};
+use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge, SerialEstimatorCalls};
 use crate::transform::{Bc2EstimateSettings, DetermineBestTransformError};
 use crate::Bc2TransformSettings;
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
@@ -28,6 +28,7 @@ where
     }
     let bridge = EstimatorBridge::new(&transform_options.size_estimator);
     let table = vtable(&bridge);
+    let _serial = SerialEstimatorCalls::new();   // `T` is not `Sync`: one callback at a time, on this thread (gfx950_glue.rs)
     let (mut mode, mut split_colour, mut estimator_error) = (0u8, false, 0u32);
     let rc = dxtlt_transform_bc2_auto(
         input_ptr, output_ptr, len, &table, transform_options.use_all_decorrelation_modes,

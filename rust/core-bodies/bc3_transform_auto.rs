@@ -1,7 +1,7 @@
 //! UNCOMPILED (see ../README.md).  New body for
 //! core/dxt-lossless-transform-bc3/src/transform/transform_auto.rs (:196-294).  Two estimator calls per candidate
 //! (alpha endpoints, colour endpoints), sizes added, as in the reference; implemented in csrc/auto_transform.cpp.
-use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge};
+use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge, SerialEstimatorCalls};
 use crate::transform::{Bc3EstimateSettings, DetermineBestTransformError};
 use crate::Bc3TransformSettings;
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
@@ -26,6 +26,7 @@ where
     }
     let bridge = EstimatorBridge::new(&transform_options.size_estimator);
     let table = vtable(&bridge);
+    let _serial = SerialEstimatorCalls::new();   // `T` is not `Sync`: one callback at a time, on this thread (gfx950_glue.rs)
     let (mut mode, mut split_alpha, mut split_colour, mut estimator_error) = (0u8, false, false, 0u32);
     let rc = dxtlt_transform_bc3_auto(
         input_ptr, output_ptr, len, &table, transform_options.use_all_decorrelation_modes,

@@ -59,12 +59,13 @@ pub(crate) fn device_is_absent(rc: i32) -> bool {
 /// The estimator's error type is generic, the callback's return value a `u32`: the first error is parked here and handed
 /// back to the caller.
 ///
-/// The bounds are the reference's own (`T: SizeEstimationOperations`, nothing more): the library calls the callbacks one at
-/// a time from the calling thread unless `dxtlt_set_auto_estimator_threads(n > 1)` was called, and this glue never calls
-/// it.  A caller who opts in must hand over an estimator whose methods may run concurrently (`T: Sync`); that promise is
-/// theirs, at the call to the setter, not a bound on these functions -- which would not compile for the reference's
-/// signatures.  Whatever the setting, the glue itself is sound: it only ever forms SHARED references to the bridge, and the
-/// error slot is written under a lock.
+/// The bounds are the reference's own (`T: SizeEstimationOperations`, nothing more -- a `T: Sync` bound would not compile for
+/// the reference's signatures), so nothing here may let `T`'s methods run concurrently.  The library runs the callbacks on
+/// several threads only when somebody called the process-wide `dxtlt_set_auto_estimator_threads(n > 1)`; this glue never does,
+/// and it does not rely on nobody else having done so either: every auto body holds a `SerialEstimatorCalls` guard around its
+/// FFI call, which caps the CALLING thread's auto transforms at one estimator thread
+/// (`dxtlt_set_auto_estimator_threads_for_this_thread(1)`) and restores the previous cap on drop.  With it the callbacks run
+/// one at a time on the calling thread: `&T` never crosses a thread, whatever the rest of the process configured.
 pub(crate) struct EstimatorBridge<'a, T: SizeEstimationOperations> {
     pub estimator: &'a T,
     locked: AtomicBool,
@@ -111,6 +112,24 @@ unsafe extern "C" fn estimate_compressed_size<T: SizeEstimationOperations>(
     match bridge.estimator.estimate_compressed_size(input_ptr, len_bytes, output_ptr, output_len) {
         Ok(n) => { *out_size = n; 0 }
         Err(e) => { bridge.park(e); 1 }
+    }
+}
+
+/// While alive: auto transforms called from this thread run their estimator callbacks one at a time on this thread (see
+/// `EstimatorBridge`).  Restores the thread's previous cap on drop, so nesting is harmless.
+pub(crate) struct SerialEstimatorCalls {
+    previous_cap: i32,
+}
+
+impl SerialEstimatorCalls {
+    pub(crate) fn new() -> Self {
+        Self { previous_cap: unsafe { dxtlt_gfx950_sys::dxtlt_set_auto_estimator_threads_for_this_thread(1) } }
+    }
+}
+
+impl Drop for SerialEstimatorCalls {
+    fn drop(&mut self) {
+        unsafe { dxtlt_gfx950_sys::dxtlt_set_auto_estimator_threads_for_this_thread(self.previous_cap) };
     }
 }
 

@@ -74,6 +74,8 @@ extern "C" {
     /// opt-in: the estimator on `threads` host threads, every distinct section once (callbacks must be thread-safe)
     pub fn dxtlt_set_auto_estimator_threads(threads: i32);
     pub fn dxtlt_get_auto_estimator_threads() -> i32;
+    /// cap for auto transforms called from THIS thread (0 = none); returns the previous cap
+    pub fn dxtlt_set_auto_estimator_threads_for_this_thread(cap: i32) -> i32;
 
     // ---- data that already lives in HBM: device pointers, asynchronous on a HIP stream -----------------------------
     pub fn dxtlt_transform_bc1_with_settings_device(d_input: *const c_void, d_output: *mut c_void, len: usize,

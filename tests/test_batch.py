@@ -46,9 +46,9 @@ def test_batch_equals_oracle_item_by_item(pkg, oracle):
 
 @pytest.mark.gpu
 def test_batch_index_with_hundreds_of_tiny_buffers_between_large_ones(pkg, oracle):
-    """The workgroup -> buffer index is one byte per 64 workgroups on top of a base per 4096 (bcn_launch.h) and SATURATES when
-    more than 255 buffers begin inside one 4096-workgroup span; the kernel then walks the entries from where the index leaves
-    it.  A large buffer, 700 buffers of one to three tiles of different sizes (no two neighbours alike: no equal-size
+    """The workgroup -> buffer index is one byte per 64 workgroups on top of a base per 4096 (bcn_launch.h), 16 bits per 64 when
+    more than 255 buffers begin inside one 4096-workgroup span; the kernel finds the owner among the entries that begin inside a
+    64-workgroup group by bisection.  A large buffer, 700 buffers of one to three tiles of different sizes (no two neighbours alike: no equal-size
     shortcut), another large one, 300 more tiny ones: every buffer against the oracle, guard bytes intact, both directions."""
     from dxt_lossless_transform_amd import batch
 
@@ -78,6 +78,44 @@ def test_batch_index_with_hundreds_of_tiny_buffers_between_large_ones(pkg, oracl
             want = oracle.transform(fmt, x, 1, True, True, inverse=inverse)
             assert np.array_equal(got[o:o + n * B], want), (inverse, k, n)
             assert (got[o + n * B:o + n * B + 64] == 0x5A).all(), (inverse, k, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["one_workgroup_each", "one_to_three_tiles"])
+def test_batch_of_tens_of_thousands_of_tiny_buffers(pkg, oracle, shape):
+    """Thumbnails and the last levels of mip chains: 20 000 BC1 buffers in one call.  `one_workgroup_each`: every buffer smaller
+    than a tile -- all own ONE workgroup, the kernel's entry is its workgroup number (uniform lookup, no index).
+    `one_to_three_tiles`: different sizes, 60+ buffers begin inside every 64-workgroup group and thousands inside every
+    4096-workgroup span -- the index takes its wide (16-bit) form and the owner is found by bisection (round 4: a byte that
+    saturated and a walk of up to ~3800 dependent entry loads per workgroup).  Every buffer against the oracle, both
+    directions, guard bytes intact."""
+    from dxt_lossless_transform_amd import batch
+
+    dev = torch.device("cuda:0")
+    fmt, B = "bc1", 8
+    st = settings_for(pkg, fmt, 1, 0, 1)
+    rng = np.random.default_rng(0x71A7 + len(shape))
+    hi = 512 if shape == "one_workgroup_each" else 1500
+    counts = [int(x) for x in rng.integers(1, hi, 20000)]
+    offs, at = [], 0
+    for n in counts:
+        offs.append(at)
+        at += (n * B + 64 + 255) // 256 * 256
+    src = oracle.fill_splitmix64(at, 0x71A7)
+    for inverse in (False, True):
+        hx = np.zeros(at, dtype=np.uint8)
+        for n, o in zip(counts, offs):
+            x = src[o:o + n * B]
+            hx[o:o + n * B] = oracle.transform(fmt, x, 1, True, False) if inverse else x
+        xd = torch.from_numpy(hx).to(dev)
+        yd = torch.full((at,), 0x5A, dtype=torch.uint8, device=dev)
+        batch.transform_batch([(fmt, inverse, xd[o:o + n * B], yd[o:o + n * B], st) for n, o in zip(counts, offs)])
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy()
+        for k, (n, o) in enumerate(zip(counts, offs)):
+            want = src[o:o + n * B] if inverse else oracle.transform(fmt, src[o:o + n * B], 1, True, False)
+            assert np.array_equal(got[o:o + n * B], want), (shape, inverse, k, n)
+            assert (got[o + n * B:o + n * B + 64] == 0x5A).all(), (shape, inverse, k, n)
 
 
 @pytest.mark.gpu

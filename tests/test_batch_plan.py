@@ -57,21 +57,32 @@ def plan(lib, fmt, inverse, variant, sa, sc, srcs, dsts, blocks):
     cap = 1 << 20
     index = (C.c_uint8 * cap)()
     lib.dxtlt_debug_plan_batch.restype = C.c_uint32
-    lib.dxtlt_debug_plan_batch.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
-    total = lib.dxtlt_debug_plan_batch(fmt, int(inverse), variant, int(sa), int(sc), a(srcs), a(dsts), a(blocks), n, out, index, cap)
+    lib.dxtlt_debug_plan_batch.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    wide = C.c_uint32(7)
+    total = lib.dxtlt_debug_plan_batch(fmt, int(inverse), variant, int(sa), int(sc), a(srcs), a(dsts), a(blocks), n, out, index, cap,
+                                       C.byref(wide))
+    plan.last_wide = wide.value
     return total, list(out)[:n], np.frombuffer(index, dtype=np.uint8)
 
 
-def owner_by_index(index, total, owners, wg):
-    """the kernel's lookup: base[wg / 4096] + delta[wg / 64], then walk while the entry ends at or before wg"""
+def owner_by_index(index, total, owners, wg, wide):
+    """the kernel's lookup: base[wg / 4096] + delta[wg / 64] owns workgroup 64 * (wg / 64); when that entry ends at or before wg,
+    bisection over the end_wg of the next wg % 64 entries.  Returns (entry, dependent loads of the search)."""
     n_base = (total + 4095) // 4096
     base = index[: 4 * n_base].view(np.uint32)
-    delta = index[4 * n_base:]
+    delta = index[4 * n_base:].view(np.uint16) if wide else index[4 * n_base:]
     e = int(base[wg >> 12]) + int(delta[wg >> 6])
     steps = 0
-    while owners[e].end_wg <= wg:
-        e += 1
-        steps += 1
+    if owners[e].end_wg <= wg:
+        lo, hi = e + 1, min(e + (wg & 63), len(owners) - 1)
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            steps += 1
+            if owners[mid].end_wg <= wg:
+                lo = mid + 1
+            else:
+                hi = mid
+        e = lo
     return e, steps
 
 
@@ -150,9 +161,52 @@ def test_index_finds_the_owner_of_every_workgroup(lib, inverse):
         truth[g.first_wg:g.end_wg] = i
     sample = sorted(set(range(0, total, 61)) | set(range(min(total, 20000))) | {total - 1} | {g.first_wg for g in owners} |
                     {g.end_wg - 1 for g in owners})
+    assert plan.last_wide == 1, "the case is meant to need the wide index (more than 255 entries begin inside one span)"
     worst = 0
     for wg in sample:
-        e, steps = owner_by_index(index, total, owners, wg)
+        e, steps = owner_by_index(index, total, owners, wg, True)
         assert e == truth[wg], wg
         worst = max(worst, steps)
-    assert worst >= 64, "the case is meant to saturate the byte index (more than 255 entries inside one span)"
+    assert 1 <= worst <= 6, worst      # bisection over at most 63 candidates
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_index_stays_narrow_for_a_corpus_and_goes_wide_for_thousands_of_tiny_buffers(lib, inverse):
+    """A corpus of mip-chained textures (hundreds to thousands of workgroups each) keeps the byte index -- one cache line per 4096
+    workgroups; 70 000 buffers of one to three tiles each switch it to 16-bit deltas instead of saturating (round 4: a walk of
+    up to ~3800 dependent entry loads per workgroup).  Every workgroup's owner is found in at most six search steps."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    texs = bench.corpus_textures(0.2)
+    blocks = [t[2] for t in texs]
+    srcs, dsts, at = [], [], 0x7D00_0000_0000
+    for b in blocks:
+        srcs.append(at); dsts.append(at + (1 << 38)); at += (b * 8 + 255) // 256 * 256
+    total, got, index = plan(lib, 1, inverse, 1, 0, 1, srcs, dsts, blocks)
+    assert total not in (0, 0xFFFFFFFF) and plan.last_wide == 0
+    owners = [g for g in got if g.end_wg > g.first_wg]
+    for wg in list(range(0, total, 997)) + [g.first_wg for g in owners] + [g.end_wg - 1 for g in owners]:
+        e, steps = owner_by_index(index, total, owners, wg, False)
+        assert owners[e].first_wg <= wg < owners[e].end_wg and steps <= 6
+
+    rng = np.random.default_rng(77 + inverse)
+    blocks = [int(x) for x in rng.integers(1, 3 * 512, 70000)]      # BC1: 512 blocks per tile
+    srcs, dsts, at = [], [], 0x7C00_0000_0000
+    for b in blocks:
+        srcs.append(at); dsts.append(at + (1 << 38)); at += (b * 8 + 255) // 256 * 256
+    total, got, index = plan(lib, 1, inverse, 1, 0, 1, srcs, dsts, blocks)
+    assert total not in (0, 0xFFFFFFFF) and plan.last_wide == 1
+    owners = [g for g in got if g.end_wg > g.first_wg]
+    truth = np.zeros(total, dtype=np.int64)
+    for i, g in enumerate(owners):
+        truth[g.first_wg:g.end_wg] = i
+    worst = 0
+    for wg in range(0, total, 7):
+        e, steps = owner_by_index(index, total, owners, wg, True)
+        assert e == truth[wg], wg
+        worst = max(worst, steps)
+    assert worst <= 6

@@ -148,6 +148,7 @@ def test_default_line_carries_the_other_single_gpu_configs_as_legs():
     assert legs["bc3"]["oracle_window_exact"] and legs["bc2"]["oracle_window_exact"] and legs["archive"]["oracle_windows_exact"]
     for name in ("corpus", "corpus_bc3"):     # the reference's benchmark shape in miniature: mip-chained, odd block counts, one batch call
         assert legs[name]["oracle_textures_exact"] is True and legs[name]["textures"] >= 9
+        assert legs[name]["forward_gaps_exact"] is True and legs[name]["oracle_textures_checked"] >= 3
         assert legs[name]["largest_blocks"] == 1398103 and legs[name]["smallest_blocks"] % 2 == 1   # 4096 x 4096 with mips; odd counts
     assert legs["bc7_uniform"]["oracle_prefix_exact"] and legs["bc7_skewed"]["oracle_prefix_exact"]
     assert legs["bc7_skewed"]["mode_counts"][6] > 2 * legs["bc7_uniform"]["mode_counts"][6]

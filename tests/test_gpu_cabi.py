@@ -295,6 +295,49 @@ def test_parallel_estimator_calls_once_per_distinct_section_and_concurrently(lib
         assert overlap > 1
 
 
+def test_per_thread_cap_keeps_the_estimator_on_the_calling_thread(lib, pkg, estimator_threads):
+    """dxtlt_set_auto_estimator_threads_for_this_thread(1): what the Rust glue holds around its auto calls, because its
+    estimator type is not `Sync` (rust/core-bodies/gfx950_glue.rs, SerialEstimatorCalls).  With the process-wide setting at 6
+    the capped thread's callbacks must still all run on that thread, one at a time, in the reference's sequence of calls; the
+    cap is per thread (another thread is not capped) and the setter returns the previous cap."""
+    import threading
+
+    lib.dxtlt_set_auto_estimator_threads_for_this_thread.argtypes = [C.c_int32]
+    lib.dxtlt_set_auto_estimator_threads_for_this_thread.restype = C.c_int32
+    n, fmt = 3, "bc3"
+    out = CORE_S[n]()
+    x = np.tile(payload(fmt), 64)
+    seen = []
+
+    def record(_ctx, _p, _n, _o, _ol, out_size):
+        seen.append(threading.get_ident())
+        out_size[0] = 100 + len(seen)
+        return 0
+
+    def max_size(_ctx, _n, out_size):
+        out_size[0] = 0
+        return 0
+
+    est = cabi.DltSizeEstimator(None, cabi.MAXFN(max_size), cabi.ESTFN(record))
+    estimator_threads(6)
+    try:
+        assert lib.dxtlt_set_auto_estimator_threads_for_this_thread(1) == 0
+        y = np.zeros_like(x)
+        r = lib.dltbc3core_transform_auto(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est), cabi.AutoSettings(True), C.byref(out))
+        assert r.ErrorCode == 0
+        assert set(seen) == {threading.get_ident()} and len(seen) == 16 * 2     # the reference's sequence: every candidate, both sections
+        other = {}
+        t = threading.Thread(target=lambda: other.setdefault("cap", lib.dxtlt_set_auto_estimator_threads_for_this_thread(0)))
+        t.start(); t.join()
+        assert other["cap"] == 0                                               # a fresh thread has no cap
+        assert lib.dxtlt_set_auto_estimator_threads_for_this_thread(0) == 1
+        del seen[:]
+        r = lib.dltbc3core_transform_auto(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est), cabi.AutoSettings(True), C.byref(out))
+        assert r.ErrorCode == 0 and len(seen) == 8 + 2                         # uncapped again: distinct sections only, on worker threads
+    finally:
+        lib.dxtlt_set_auto_estimator_threads_for_this_thread(0)
+
+
 def test_parallel_estimator_reports_estimator_failures(lib, pkg, estimator_threads):
     estimator_threads(4)
     for n in (1, 3):

@@ -18,6 +18,7 @@ namespace {
 
 struct Mapping {
     size_t va_bytes;
+    size_t piece;
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
 
@@ -92,7 +93,7 @@ int vmm_alloc(int dev, size_t bytes, size_t chunk, uint64_t shuffle_seed, size_t
     if (hipError_t e = hipMemAddressReserve(&va, va_bytes, va_align ? va_align : size_t(2) << 20, nullptr, 0);   // (a power of two)
         e != hipSuccess)
         return fail("hipMemAddressReserve", e);
-    Mapping m{va_bytes, {}};
+    Mapping m{va_bytes, piece, {}};
     m.handles.reserve(n);
     for (size_t i = 0; i < n; ++i) {
         hipMemGenericAllocationHandle_t h;
@@ -138,6 +139,11 @@ int vmm_alloc(int dev, size_t bytes, size_t chunk, uint64_t shuffle_seed, size_t
     return 0;
 }
 
+// Unmaps and releases the physical handles.  The VIRTUAL range stays reserved for the life of the process, on purpose: on this
+// stack (ROCm 7.2.0, gfx950) a range that was unmapped, freed and handed out again by hipMemAddressReserve for a new mapping
+// showed STALE TRANSLATIONS -- the copy engine and kernels (and kernels on different XCDs) disagreed about the bytes behind one
+// address, wrong data without any fault (profiles/r05_placement_vmm.txt, "diagnose").  A range that is never mapped twice
+// cannot meet a stale entry.
 int vmm_free(void* p)
 {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -147,12 +153,18 @@ int vmm_free(void* p)
         return -1;
     }
     (void)hipDeviceSynchronize();
-    hipError_t e = hipMemUnmap(p, it->second.va_bytes);
-    for (auto h : it->second.handles)
+    hipError_t first = hipSuccess;
+    const Mapping& m = it->second;
+    for (size_t i = 0; i < m.handles.size(); ++i) {
+        const hipError_t e = hipMemUnmap(static_cast<uint8_t*>(p) + i * m.piece, m.piece);
+        if (e != hipSuccess && first == hipSuccess)
+            first = e;
+    }
+    for (auto h : m.handles)
         (void)hipMemRelease(h);
-    (void)hipMemAddressFree(p, it->second.va_bytes);
+    (void)hipDeviceSynchronize();
     g_maps.erase(it);
-    return e == hipSuccess ? 0 : fail("hipMemUnmap", e);
+    return first == hipSuccess ? 0 : fail("hipMemUnmap", first);
 }
 
 int vmm_copy(void* dst, const void* src, size_t n)
