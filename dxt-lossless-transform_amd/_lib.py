@@ -41,7 +41,8 @@ def _declare(l: C.CDLL) -> None:
     l.dxtlt_last_error.argtypes, l.dxtlt_last_error.restype = [], C.c_char_p
     l.dxtlt_device_count.argtypes, l.dxtlt_device_count.restype = [], i32
     l.dxtlt_set_tuning.argtypes, l.dxtlt_set_tuning.restype = [i32, i32], None
-    l.dxtlt_tuning_mask.argtypes, l.dxtlt_tuning_mask.restype = [], i32
+    if hasattr(l, "dxtlt_tuning_mask"):     # (absent from the round-4 library, which same-box A/B runs load through DXTLT_LIB_PATH)
+        l.dxtlt_tuning_mask.argtypes, l.dxtlt_tuning_mask.restype = [], i32
     l.dxtlt_version.argtypes, l.dxtlt_version.restype = [], C.c_char_p
     l.dxtlt_set_auto_estimator_threads.argtypes, l.dxtlt_set_auto_estimator_threads.restype = [i32], None
     l.dxtlt_get_auto_estimator_threads.argtypes, l.dxtlt_get_auto_estimator_threads.restype = [], i32

@@ -131,6 +131,52 @@ __device__ __forceinline__ lds_halfword* lds_halfwords(uint8_t* lds, int byte_of
     return (lds_halfword*)(lds + byte_off);
 }
 
+// The 6-byte alpha-index record of a BC3 block (bytes 2..7 of the block) in the LDS image: records are 6 bytes apart, so a
+// record's address is a multiple of 4 for every other block and 2 further for the blocks in between.  Round 1 moved it as three
+// halfwords (three DS instructions per lane and direction); here it is TWO: an aligned dword and a halfword, the order picked
+// by the address's bit 1 with selects (no divergent branch) going in, and one ds_read2_b32 of the two aligned dwords that
+// cover the record plus a funnel shift (v_alignbit) coming out.  Every access is naturally aligned (DS accesses at addresses
+// that are not multiples of their width run several times slower on gfx950, profiles/r01_s), and the pointers are volatile /
+// declared 4-byte aligned so that clang neither fuses them into such accesses nor widens the pair into a ds_read_b64.
+// Reference for the bytes: bc3/src/transform/standard/transform/portable32.rs:46-64 (alpha indices = block bytes 2..7, verbatim).
+#ifndef DXTLT_BC3_RECORD6
+#define DXTLT_BC3_RECORD6 1   // 0: the three-halfword form (A/B: profiles/r05_bc3_record6.txt)
+#endif
+typedef uint32_t u32x2_align4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef volatile uint32_t __attribute__((address_space(3))) lds_dword;
+
+// `addr` even; lo16 = record bytes 0..1 (low half), hi32 = record bytes 2..5
+__device__ __forceinline__ void lds_put_record6(uint8_t* lds, int addr, uint32_t lo16, uint32_t hi32)
+{
+#if DXTLT_BC3_RECORD6
+    const bool odd = (addr & 2) != 0;
+    const int a32 = odd ? addr + 2 : addr;
+    const int a16 = odd ? addr : addr + 4;
+    const uint32_t v32 = odd ? hi32 : (lo16 & 0xFFFFu) | (hi32 << 16);
+    const uint32_t v16 = odd ? lo16 : hi32 >> 16;
+    *(lds_dword*)(lds + a32) = v32;
+    *lds_halfwords(lds, a16) = (uint16_t)v16;
+#else
+    lds_halfwords(lds, addr)[0] = (uint16_t)lo16;
+    lds_halfwords(lds, addr)[1] = (uint16_t)hi32;
+    lds_halfwords(lds, addr)[2] = (uint16_t)(hi32 >> 16);
+#endif
+}
+
+__device__ __forceinline__ void lds_get_record6(uint8_t* lds, int addr, uint32_t& lo16, uint32_t& hi32)
+{
+#if DXTLT_BC3_RECORD6
+    const u32x2_align4 w = *reinterpret_cast<const u32x2_align4*>(lds + (addr & ~3));
+    const uint32_t sh = (uint32_t)(addr & 2) * 8u;
+    const uint32_t rec = __builtin_amdgcn_alignbit(w.y, w.x, sh);   // record bytes 0..3
+    lo16 = rec & 0xFFFFu;
+    hi32 = (rec >> 16) | ((w.y >> sh) << 16);                       // bytes 2..3, then bytes 4..5
+#else
+    lo16 = lds_at<uint16_t>(lds, addr + 0);
+    hi32 = (uint32_t)lds_at<uint16_t>(lds, addr + 2) | ((uint32_t)lds_at<uint16_t>(lds, addr + 4) << 16);
+#endif
+}
+
 template <int FMT, int VARIANT, bool SA, bool SC, int T>
 __device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
 {
@@ -165,12 +211,7 @@ __device__ __forceinline__ void scatter_to_image(uint8_t* lds, int u, u32x4 q)
         } else {
             lds_at<uint16_t>(lds, 0 * T + 2 * u) = (uint16_t)q.x;
         }
-        // 6-byte alpha-index record, only 2-byte aligned: three halfword stores.  Volatile, or clang fuses the last
-        // two into a ds_write_b32 that is misaligned for every other lane -- such DS accesses run several times
-        // slower than aligned ones on gfx950 (profiles/r01_s).
-        lds_halfwords(lds, 2 * T + 6 * u)[0] = (uint16_t)(q.x >> 16);
-        lds_halfwords(lds, 2 * T + 6 * u)[1] = (uint16_t)q.y;
-        lds_halfwords(lds, 2 * T + 6 * u)[2] = (uint16_t)(q.y >> 16);
+        lds_put_record6(lds, 2 * T + 6 * u, q.x >> 16, q.y);   // the 6-byte alpha-index record, only 2-byte aligned
         if constexpr (SC) {
             lds_at<uint16_t>(lds, 8 * T + 2 * u) = (uint16_t)c;
             lds_at<uint16_t>(lds, 10 * T + 2 * u) = (uint16_t)(c >> 16);
@@ -219,16 +260,15 @@ __device__ __forceinline__ u32x4 gather_from_image(uint8_t* lds, int u)
             a01 = (uint32_t)lds_at<uint8_t>(lds, 0 * T + u) | ((uint32_t)lds_at<uint8_t>(lds, 1 * T + u) << 8);
         else
             a01 = lds_at<uint16_t>(lds, 0 * T + 2 * u);
-        const uint32_t i01 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 0);
-        const uint32_t i23 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 2);
-        const uint32_t i45 = lds_at<uint16_t>(lds, 2 * T + 6 * u + 4);
+        uint32_t i01, i2345;
+        lds_get_record6(lds, 2 * T + 6 * u, i01, i2345);
         uint32_t c;
         if constexpr (SC)
             c = (uint32_t)lds_at<uint16_t>(lds, 8 * T + 2 * u) | ((uint32_t)lds_at<uint16_t>(lds, 10 * T + 2 * u) << 16);
         else
             c = lds_at<uint32_t>(lds, 8 * T + 4 * u);
         q.x = a01 | (i01 << 16);
-        q.y = i23 | (i45 << 16);
+        q.y = i2345;
         q.z = recorrelate2<VARIANT>(c);
         q.w = lds_at<uint32_t>(lds, 12 * T + 4 * u);
     }
@@ -628,9 +668,13 @@ __device__ __forceinline__ void scatter_shifted(uint8_t* lds, int u, u32x4 q, co
             } else {
                 lds_put<2, NAT>(lds, base[F::alpha] + 2 * u, q.x & 0xFFFF);
             }
-            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 0, q.x >> 16);
-            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 2, q.y & 0xFFFF);
-            lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 4, q.y >> 16);
+            if constexpr (NAT && DXTLT_BC3_RECORD6) {
+                lds_put_record6(lds, base[F::aidx] + 6 * u, q.x >> 16, q.y);   // (an even address: the shift is natural)
+            } else {
+                lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 0, q.x >> 16);
+                lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 2, q.y & 0xFFFF);
+                lds_put<2, NAT>(lds, base[F::aidx] + 6 * u + 4, q.y >> 16);
+            }
         }
         if constexpr (SC) {
             lds_put<2, NAT>(lds, base[F::col] + 2 * u, c & 0xFFFF);
@@ -688,11 +732,18 @@ __device__ __forceinline__ u32x4 gather_shifted(uint8_t* lds, int u, const int (
                 a01 = (uint32_t)lds_get<1>(lds, base[F::alpha] + u) | ((uint32_t)lds_get<1>(lds, base[F::a1] + u) << 8);
             else
                 a01 = (uint32_t)lds_get<2, NAT>(lds, base[F::alpha] + 2 * u);
-            const uint32_t i01 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 0);
-            const uint32_t i23 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 2);
-            const uint32_t i45 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 4);
-            q.x = a01 | (i01 << 16);
-            q.y = i23 | (i45 << 16);
+            if constexpr (NAT && DXTLT_BC3_RECORD6) {
+                uint32_t i01, i2345;
+                lds_get_record6(lds, base[F::aidx] + 6 * u, i01, i2345);   // (reads up to 2 bytes past the record: the region's padding)
+                q.x = a01 | (i01 << 16);
+                q.y = i2345;
+            } else {
+                const uint32_t i01 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 0);
+                const uint32_t i23 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 2);
+                const uint32_t i45 = (uint32_t)lds_get<2, NAT>(lds, base[F::aidx] + 6 * u + 4);
+                q.x = a01 | (i01 << 16);
+                q.y = i23 | (i45 << 16);
+            }
         }
         uint32_t c;
         if constexpr (SC)
@@ -892,8 +943,10 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
 constexpr int kHaloAlign = DXTLT_HALO_ALIGN;
 constexpr int kHaloBlocks = kHaloAlign;
 constexpr int kHaloPad = kHaloAlign;   // bytes between the stream regions of the LDS image: room for d_s
-template <int FMT>
-constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, 256) + kHaloBlocks) + kHaloPad * 6; }
+// THREADS: lanes of a halo tile (256, the product's; 512: round 5's experiment -- half the halo share per tile -- kept selectable
+// through dxtlt_set_tuning(512, ...) for the single-buffer call, profiles/r05_halo_512.txt)
+template <int FMT, int THREADS = 256>
+constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, THREADS) + kHaloBlocks) + kHaloPad * 6; }
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -902,6 +955,17 @@ __device__ __forceinline__ void static_for(F&& f)
         f(std::integral_constant<int, I>{});
         static_for<I + 1, N>(f);
     }
+}
+
+// f(std::integral_constant<int, W>) for the calling wave's number W (uniform), W < WAVES
+template <int WAVES, typename F>
+__device__ __forceinline__ void for_this_wave(int t, F&& f)
+{
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    static_for<0, WAVES>([&](auto wi) {
+        if (w == decltype(wi)::value)
+            f(wi);
+    });
 }
 
 // bytes [lo, hi) of a 16-byte segment (both pointers 16-byte aligned at byte 0) as the fewest naturally aligned 1/2/4/8-byte
@@ -941,12 +1005,12 @@ __device__ __forceinline__ void copy_segment_bytes(uint8_t* dst, const uint8_t* 
 // neighbouring buffer's), some of them with narrow stores, and write-through next to that is the collapse round 1 met on shared
 // lines.  Measured on 4096 x (256 KiB - 1 block) BC3, forward: plain nt throughout 0.66; write-through for every sector that is
 // the tile's alone 0.49; write-through except in the line where the stream begins or ends 0.55 (profiles/r04_batch_edge_tiles.txt).
-template <int FMT, bool SA, bool SC, int W, bool EDGE = false>
+template <int FMT, bool SA, bool SC, int W, bool EDGE = false, int THREADS = 256>
 __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, const uint8_t* lds, int t, const uint64_t (&gb)[6],
                                                    const Shifts& sh, const int (&vlo)[6], const int (&vhi)[6])
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, THREADS);
     constexpr int H = kHaloBlocks;
     constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
     const int o = t * 16;
@@ -988,14 +1052,14 @@ __device__ __forceinline__ void halo_copy_out_wave(uint8_t* __restrict__ soa, co
         __builtin_nontemporal_store(lds_at<u32x4>(const_cast<uint8_t*>(lds), la), reinterpret_cast<u32x4*>(soa + g));
 }
 
-// one halo tile; `lds`: halo_lds_bytes<FMT>() bytes
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
+// one halo tile; `lds`: halo_lds_bytes<FMT, THREADS>() bytes
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT, int THREADS = 256>
 __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa,
                                               uint64_t /*total_blocks: in sh.gbase*/, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
                                               uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, THREADS);
     constexpr int H = kHaloBlocks;
     constexpr int HV = H * fmt_block(FMT) / 16;  // halo vectors at most: 64 (BC2 / BC3) or 32 (BC1)
     const int t = threadIdx.x;
@@ -1006,7 +1070,7 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     for (int s = 0; s < 6; ++s)
         base[s] = s < S.n ? S.off[s] * (T + H) + kHaloPad * s + sh.d[s] + S.width[s] * H : 0;
 
-    const uint8_t* tile_aos = aos + tile * 4096;
+    const uint8_t* tile_aos = aos + tile * (THREADS * 16);
     // TEMPORAL load (no `nt`): the tile's last blocks are read a second time, as the next tile's halo, by a workgroup on
     // another XCD; a line fetched with `nt` is gone by then and comes from HBM again (PMC: 1.25 x the algorithmic read with
     // a 63-block halo), a line fetched temporally is still in the memory-side cache.  Found by accident -- the compiler
@@ -1023,7 +1087,7 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
         const u32x4 qh = *reinterpret_cast<const u32x4*>(tile_aos - hv * 16 + t * 16);
         scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t - hv, normalize_vector<FMT, NORM>(qh), base);
     }
-    static_assert(HV <= 256, "the halo is loaded by the first lanes of the workgroup");
+    static_assert(HV <= THREADS, "the halo is loaded by the first lanes of the workgroup");
     WG_MARK_LOADS_DONE(2);
     scatter_shifted<FMT, VARIANT, SA, SC, NAT>(lds, t, normalize_vector<FMT, NORM>(q), base);
     __syncthreads();
@@ -1032,11 +1096,17 @@ __device__ __forceinline__ void fwd_halo_tile(const uint8_t* __restrict__ aos, u
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
     const int none[6] = {0, 0, 0, 0, 0, 0};   // (tile 0 and the last tile of a range run fwd_halo_edge_tile)
-    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
-    case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, none, none); break;
-    case 1: halo_copy_out_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, none, none); break;
-    case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, none, none); break;
-    default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, none, none); break;
+    if constexpr (THREADS == 256) {
+        switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+        case 0: halo_copy_out_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, none, none); break;
+        case 1: halo_copy_out_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, none, none); break;
+        case 2: halo_copy_out_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, none, none); break;
+        default: halo_copy_out_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, none, none); break;
+        }
+    } else {
+        for_this_wave<THREADS / 64>(t, [&](auto wi) {
+            halo_copy_out_wave<FMT, SA, SC, decltype(wi)::value, false, THREADS>(soa, lds, t, gb, sh, none, none);
+        });
     }
     WG_MARK(4);
 }
@@ -1110,12 +1180,12 @@ __device__ __forceinline__ EdgeSlot edge_slot_behind_window(int s_sel, int k, co
 // Tile 0 (no halo: the blocks in front of it may not exist) writes every stream from its first byte; a tile that is followed
 // by another one stops at the end of its window, the last one at the end of the stream -- up to 63 bytes past its window,
 // the extra segments lanes 0 .. 4 n - 1 look after.
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT, int THREADS = 256>
 __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, const Shifts& sh,
                                                    uint64_t tile, uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, THREADS);
     constexpr int H = kHaloBlocks;
     constexpr int PV = 16 / fmt_block(FMT);   // blocks per 16-byte vector
     const int t = threadIdx.x;
@@ -1126,7 +1196,7 @@ __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ a
 
     const uint64_t left = sh.range_blocks - tile * (uint64_t)T;       // the host launches no tile behind the range
     const int own = left < (uint64_t)T ? (int)left : T;
-    const uint8_t* tile_aos = aos + tile * 4096;
+    const uint8_t* tile_aos = aos + tile * (THREADS * 16);
     const int hv = sh.halo_vecs;
     const bool has_halo = tile > 0 && t < hv;
     const bool whole_vec = (t + 1) * PV <= own;
@@ -1157,11 +1227,17 @@ __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ a
         vlo[s] = tile == 0 ? d : 0;
         vhi[s] = own == T ? w * T : d + w * own;
     }
-    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
-    case 0: halo_copy_out_wave<FMT, SA, SC, 0, true>(soa, lds, t, gb, sh, vlo, vhi); break;
-    case 1: halo_copy_out_wave<FMT, SA, SC, 1, true>(soa, lds, t, gb, sh, vlo, vhi); break;
-    case 2: halo_copy_out_wave<FMT, SA, SC, 2, true>(soa, lds, t, gb, sh, vlo, vhi); break;
-    default: halo_copy_out_wave<FMT, SA, SC, 3, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+    if constexpr (THREADS == 256) {
+        switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+        case 0: halo_copy_out_wave<FMT, SA, SC, 0, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+        case 1: halo_copy_out_wave<FMT, SA, SC, 1, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+        case 2: halo_copy_out_wave<FMT, SA, SC, 2, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+        default: halo_copy_out_wave<FMT, SA, SC, 3, true>(soa, lds, t, gb, sh, vlo, vhi); break;
+        }
+    } else {
+        for_this_wave<THREADS / 64>(t, [&](auto wi) {
+            halo_copy_out_wave<FMT, SA, SC, decltype(wi)::value, true, THREADS>(soa, lds, t, gb, sh, vlo, vhi);
+        });
     }
     constexpr int XS = kHaloAlign / 16;   // up to kHaloAlign - 1 bytes of a stream lie behind its window: XS more segments per stream
     if (t < XS * S.n) {
@@ -1184,12 +1260,12 @@ __device__ __forceinline__ void fwd_halo_edge_tile(const uint8_t* __restrict__ a
 
 // Workgroups [0, sh.full_tiles) are whole tiles (tile 0 through the edge body: it has a head to write); a workgroup behind
 // them, when the launch has one, is the edge tile at the end of the range.
-template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT>
-__global__ void __launch_bounds__(256)
+template <int FMT, int VARIANT, bool SA, bool SC, int NORM, bool NAT, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS)
 fwd_tiled_halo(const uint8_t* __restrict__ aos_arg, uint8_t* __restrict__ soa_arg, uint64_t total_blocks, uint64_t first_block,
                Shifts sh_arg)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT>()];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[halo_lds_bytes<FMT, THREADS>()];
     WG_MARK(0);
     const uint32_t wg = blockIdx.x;
     const Shifts sh = shifts_fetched_at_once(sh_arg);
@@ -1200,9 +1276,9 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos_arg, uint8_t* __restrict__ soa_ar
     const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : shifts_xcd_contiguous(sh, false) ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
     const bool edge = !whole || tile == 0;
     if (edge)
-        fwd_halo_edge_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, sh, tile, lds);
+        fwd_halo_edge_tile<FMT, VARIANT, SA, SC, NORM, NAT, THREADS>(aos, soa, sh, tile, lds);
     else
-        fwd_halo_tile<FMT, VARIANT, SA, SC, NORM, NAT>(aos, soa, total_blocks, first_block, sh, tile, lds);
+        fwd_halo_tile<FMT, VARIANT, SA, SC, NORM, NAT, THREADS>(aos, soa, total_blocks, first_block, sh, tile, lds);
 }
 
 // Loads of wave W of an inverse shifted tile: lane t fetches the aligned 16-byte segment that holds image byte 16 t.

@@ -88,6 +88,7 @@ struct KernelSet {
     TiledFn tiled[4];  // aligned tiles of 64, 128, 256, 512 threads
     ShiftFn shifted;   // inverse: shifted tiles + edge tile (256 threads); forward: nullptr (experiments build: the first form)
     ShiftFn halo[2];   // forward: halo tiles + edge tiles ([1]: natural shifts); inverse: nullptr
+    ShiftFn halo512;   // forward, natural shifts: the same with 512-lane tiles (dxtlt_set_tuning(512, ...): profiles/r05_halo_512.txt)
 #ifdef DXTLT_EXPERIMENTS
     GenericFn generic;
 #endif
@@ -112,6 +113,7 @@ KernelSet kernels_for(bool inverse)
         ks.tiled[3] = fwd_tiled<FMT, VARIANT, SA, SC, 512>;
         ks.halo[0] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false>;
         ks.halo[1] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true>;
+        ks.halo512 = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true, 512>;
     }
 #ifdef DXTLT_EXPERIMENTS
     if (inverse) {
@@ -293,8 +295,10 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (tuning && !normalizing && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
                                    tuning->tile_threads == 512))
         threads = tuning->tile_threads;   // (normalisation: the default is the only tile size instantiated)
+    // halo tiles of 512 lanes (natural shifts, no normalisation) when the tuning knob asks for 512-lane tiles
+    const bool halo512 = use_shift && !inverse && threads == 512 && ks.halo512 != nullptr && shifts_of(0, true).natural;
     if (use_shift)
-        threads = 256;
+        threads = halo512 ? 512 : 256;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
 
 #ifdef DXTLT_EXPERIMENTS
@@ -316,6 +320,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         const bool first_form = use_shift && !inverse && (force_bits & 0x400);
         const bool old_routing = (force_bits & 0x2000) != 0;
         if (first_form || (old_routing && use_shift)) {
+            const uint64_t T = (uint64_t)tile_blocks(fmt, 256);   // (these routes know 256-lane tiles only)
             const uint64_t tiles = r.num_blocks / T;
             Shifts sh = shifts_of(0, !inverse && !first_form);
             sh.xcd_remap = remap_override >= 0 ? remap_override : (!inverse && !first_form) ? 0 : 1;
@@ -376,8 +381,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             tail = tail || sh.d[i] > 0;
         sh.full_tiles = (uint32_t)num_tiles;
         sh.range_blocks = r.num_blocks;
-        hipLaunchKernelGGL(ks.halo[sh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
-                           r.total_blocks, r.first_block, sh);
+        hipLaunchKernelGGL(halo512 ? ks.halo512 : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))),
+                           dim3(halo512 ? 512 : 256), 0, stream, src8, dst8, r.total_blocks, r.first_block, sh);
         return hipGetLastError();
     }
     if (use_shift) {

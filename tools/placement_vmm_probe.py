@@ -31,11 +31,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=12)
 ap.add_argument("--workloads", default="bc7,corpus")
 ap.add_argument("--arms", default="hipmalloc,whole,2m,2m-shuf,small,small-shuf")
+ap.add_argument("--arm-sep", default=",", help="separator of --arms (the hm: / vw: arms hold commas: use ';')")
 ap.add_argument("--copy", default="kernel", choices=("kernel", "hipmemcpy"), help="how data gets into / is checked in the probe's buffers")
 ap.add_argument("--diagnose", action="store_true", help="first: do hipMemcpy / hipMemset agree with kernel copies on VMM-backed buffers?")
 ap.add_argument("--min-chunk-kib", type=int, default=64)
 ap.add_argument("--min-trials", type=int, default=4, help="trials of the small-chunk arms (hundreds of thousands of handles each)")
 ap.add_argument("--alloc-budget-s", type=float, default=15.0, help="projected seconds per trio above which the 'min' chunk is doubled")
+ap.add_argument("--placed-trials", type=int, default=6, help="trials of the hm: / vw: arms (chosen virtual addresses)")
 ap.add_argument("--bc7-gib", type=float, default=4.0)
 ap.add_argument("--corpus-scale", type=float, default=1.0)
 args = ap.parse_args()
@@ -90,7 +92,7 @@ def _seconds_per_handle(chunk, total=256 << 20):
 
 
 _largest = int(max(args.bc7_gib * (1 << 30), 8.5 * (1 << 30) * args.corpus_scale))
-while min_chunk < (2 << 20):
+while min_chunk < (2 << 20) and any(a.startswith("small") for a in args.arms.split(args.arm_sep)):
     per = _seconds_per_handle(min_chunk)
     proj = per * 3 * (_largest // min_chunk)
     print(f"chunk {min_chunk} B: {per * 1e6:.1f} us per handle (create + map), projected {proj:.1f} s per trio of the largest workload", flush=True)
@@ -121,23 +123,43 @@ def differ(a, b, n):
     return d, first.value
 
 
+def parse_placed_arm(arm):
+    """`hm:A:ox,oy,oz` -- hipMalloc of the buffer + A MiB + slack, the pointer rounded up to an A-MiB boundary, then ox / oy / oz MiB
+    further in (x, y, z): the VIRTUAL address bits of every buffer are the probe's choice, the physical pages the driver's.
+    `vw:A:ox,oy,oz` -- the same with one hipMemCreate handle behind a range reserved at an A-MiB boundary."""
+    kind, align, offs = arm.split(":")
+    return kind, int(float(align) * (1 << 20)), [int(float(o) * (1 << 20)) for o in offs.split(",")]
+
+
 class Buf:
-    def __init__(self, nbytes, arm, seed):
-        chunk, shuf = ARMS[arm]
-        self.vmm = chunk is not None
+    def __init__(self, nbytes, arm, seed, which=0):
         p = vp(0)
         t0 = time.perf_counter()
-        if self.vmm:
-            ck(h.vmm_alloc(0, nbytes, chunk, seed if shuf else 0, 0, C.byref(p)), f"vmm_alloc({arm})")
+        self.offset = 0
+        if ":" in arm:
+            kind, align, offs = parse_placed_arm(arm)
+            off = offs[which]
+            self.vmm = kind == "vw"
+            if self.vmm:
+                ck(h.vmm_alloc(0, nbytes + off, 0, 0, align, C.byref(p)), f"vmm_alloc({arm})")
+                self.offset = off
+            else:
+                ck(h.plain_alloc(0, nbytes + align + off, C.byref(p)), "hipMalloc")
+                self.offset = (-p.value) % align + off
         else:
-            ck(h.plain_alloc(0, nbytes, C.byref(p)), "hipMalloc")
+            chunk, shuf = ARMS[arm]
+            self.vmm = chunk is not None
+            if self.vmm:
+                ck(h.vmm_alloc(0, nbytes, chunk, seed if shuf else 0, 0, C.byref(p)), f"vmm_alloc({arm})")
+            else:
+                ck(h.plain_alloc(0, nbytes, C.byref(p)), "hipMalloc")
         self.alloc_s = time.perf_counter() - t0
-        self.ptr, self.nbytes = p.value, nbytes
+        self.base, self.ptr, self.nbytes = p.value, p.value + self.offset, nbytes
 
     def free(self):
-        if self.ptr:
-            ck((h.vmm_free if self.vmm else h.plain_free)(self.ptr), "free")
-            self.ptr = 0
+        if self.base:
+            ck((h.vmm_free if self.vmm else h.plain_free)(self.base), "free")
+            self.base = self.ptr = 0
 
 
 def steady(fwd, inv, nbytes, steps=20):
@@ -177,14 +199,14 @@ def run_arm(name, arm, nbytes, source, make_calls, algorithmic=None):
 
 def _run_arm(name, arm, nbytes, source, make_calls, algorithmic):
     rows = []
-    for k in range(args.min_trials if arm.startswith("small") else args.trials):
+    for k in range(args.min_trials if arm.startswith("small") else args.placed_trials if ":" in arm else args.trials):
         sp_mib = SPACERS_MIB[k % len(SPACERS_MIB)]
-        spacer = Buf(sp_mib << 20, "hipmalloc" if arm == "hipmalloc" else "whole", 0) if sp_mib else None
+        spacer = Buf(sp_mib << 20, "hipmalloc" if arm == "hipmalloc" or arm.startswith("hm:") else "whole", 0) if sp_mib else None
         if spacer is not None:
             LIVE.append(spacer)
         trio = []
         for j in range(3):
-            trio.append(Buf(nbytes, arm, 0xA110C000 + 16 * k + j))
+            trio.append(Buf(nbytes, arm, 0xA110C000 + 16 * k + j, j))
             LIVE.append(trio[-1])
         x, y, z = trio
         copy_in(x.ptr, source.data_ptr(), nbytes)
@@ -197,7 +219,7 @@ def _run_arm(name, arm, nbytes, source, make_calls, algorithmic):
         if not exact:
             print(f"   round trip: {bad} of {nbytes // 16} 16-byte vectors differ, the first at byte {16 * first:#x}", flush=True)
         rows.append((fw, iv))
-        print(f"{name:7s} {arm:9s} trial {k:2d} spacer {sp_mib:5d} MiB  x {x.ptr:#x} y-x {(y.ptr - x.ptr) / 2**20:10.1f} MiB z-y {(z.ptr - y.ptr) / 2**20:10.1f} MiB"
+        print(f"{name:7s} {arm:14s} trial {k:2d} spacer {sp_mib:5d} MiB  x {x.ptr:#x} y-x {(y.ptr - x.ptr) / 2**20:10.1f} MiB z-y {(z.ptr - y.ptr) / 2**20:10.1f} MiB"
               f"  alloc {x.alloc_s + y.alloc_s + z.alloc_s:6.2f} s  fwd {fw:.4f} inv {iv:.4f}  roundtrip {'exact' if exact else 'WRONG'}", flush=True)
         for b in LIVE:
             b.free()
@@ -264,7 +286,7 @@ if "bc7" in args.workloads.split(","):
             assert rc == 0, _lib.last_error()
         return fwd, inv
 
-    for arm in args.arms.split(","):
+    for arm in args.arms.split(args.arm_sep):
         summary[("bc7", arm)] = run_arm("bc7", arm, n, src, bc7_calls)
     del src
     torch.cuda.empty_cache()
@@ -304,7 +326,7 @@ if "corpus" in args.workloads.split(","):
             assert rc == 0, _lib.last_error()
         return fwd, inv
 
-    for arm in args.arms.split(","):
+    for arm in args.arms.split(args.arm_sep):
         summary[("corpus_bc3", arm)] = run_arm("corpus", arm, arena, src, corpus_calls, sum(t[2] for t in texs) * B)
 
 print("\nsummary (fraction of 8 TB/s; min..max over the trials, spread)")
@@ -314,4 +336,4 @@ for (wl, arm), rows in summary.items():
         continue
     f = [r[0] for r in rows]
     i = [r[1] for r in rows]
-    print(f"{wl:11s} {arm:9s} fwd {min(f):.4f}..{max(f):.4f} ({max(f) - min(f):.4f})   inv {min(i):.4f}..{max(i):.4f} ({max(i) - min(i):.4f})")
+    print(f"{wl:11s} {arm:14s} fwd {min(f):.4f}..{max(f):.4f} ({max(f) - min(f):.4f})   inv {min(i):.4f}..{max(i):.4f} ({max(i) - min(i):.4f})")
