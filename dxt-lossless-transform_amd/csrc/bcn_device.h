@@ -92,6 +92,26 @@ __device__ __forceinline__ void gstore16_aos(uint8_t* aos_base, void* p, u32x4 v
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// f(std::integral_constant<int, W>) for the calling wave's number W (uniform), W < WAVES
+template <int WAVES, typename F>
+__device__ __forceinline__ void for_this_wave(int t, F&& f)
+{
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    static_for<0, WAVES>([&](auto wi) {
+        if (w == decltype(wi)::value)
+            f(wi);
+    });
+}
+
 __host__ __device__ constexpr int fmt_block(int fmt) { return fmt == kBc1 ? 8 : 16; }
 // one 16-byte vector per lane: a THREADS-wide workgroup owns THREADS*16 bytes of blocks
 __host__ __device__ constexpr int tile_blocks(int fmt, int threads) { return threads * 16 / fmt_block(fmt); }
@@ -112,6 +132,48 @@ __device__ __forceinline__ uint64_t soa_offset_of_image_byte(int o, uint64_t tot
             r = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0 + (uint64_t)(o - lo);
     }
     return r;
+}
+
+// The same for a lane of wave W of the workgroup (W known at compile time: for_this_wave).  A wave's 1 KiB of the image meets at
+// most three streams (BC3 with split alphas, wave 0) and usually one, so the per-lane select chain over all streams -- six
+// compares and six 64-bit multiply-adds per lane, 40 % of the aligned inverse kernel's instructions, all in front of its load --
+// shrinks to the streams the wave can meet, and the stream bases stay on the scalar unit.
+#ifndef DXTLT_WAVE_OFFSETS
+#define DXTLT_WAVE_OFFSETS 1   // 0: the per-lane select chain of rounds 1-4 (A/B: profiles/r05_wave_offsets.txt)
+#endif
+template <int FMT, bool SA, bool SC, int T, int W>
+__device__ __forceinline__ uint64_t soa_offset_of_image_byte_in_wave(int o, uint64_t total_blocks, uint64_t blk0)
+{
+    constexpr Streams S = make_streams(FMT, SA, SC);
+    constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
+    uint64_t r = 0;
+    static_for<0, S.n>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int lo = S.off[s] * T;
+        constexpr int hi = lo + S.width[s] * T;
+        if constexpr (lo < wave_hi && hi > wave_lo) {
+            constexpr bool only = lo <= wave_lo && hi >= wave_hi;   // the whole wave sits in this stream
+            const uint64_t base = (uint64_t)S.off[s] * total_blocks + (uint64_t)S.width[s] * blk0;   // uniform
+            if (only || (o >= lo && o < hi))
+                r = base + (uint64_t)(uint32_t)(o - lo);
+        }
+    });
+    return r;
+}
+
+template <int FMT, bool SA, bool SC, int THREADS>
+__device__ __forceinline__ uint64_t soa_offset_of_lane(int t, uint64_t total_blocks, uint64_t blk0)
+{
+    constexpr int T = tile_blocks(FMT, THREADS);
+#if DXTLT_WAVE_OFFSETS
+    uint64_t o = 0;
+    for_this_wave<THREADS / 64>(t, [&](auto wi) {
+        o = soa_offset_of_image_byte_in_wave<FMT, SA, SC, T, decltype(wi)::value>(t * 16, total_blocks, blk0);
+    });
+    return o;
+#else
+    return soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, blk0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -333,7 +395,7 @@ __device__ __forceinline__ void fwd_aligned_tile(const uint8_t* __restrict__ aos
     __syncthreads();
     WG_MARK(3);
     const u32x4 v = lds_at<u32x4>(lds, t * 16);
-    const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
+    const uint64_t o = soa_offset_of_lane<FMT, SA, SC, THREADS>(t, total_blocks, first_block + tile * T);
     gstore16(soa + o, v);
     WG_MARK(4);
 }
@@ -344,7 +406,7 @@ __device__ __forceinline__ void inv_aligned_tile(const uint8_t* __restrict__ soa
 {
     constexpr int T = tile_blocks(FMT, THREADS);
     const int t = threadIdx.x;
-    const uint64_t o = soa_offset_of_image_byte<FMT, SA, SC, T>(t * 16, total_blocks, first_block + tile * T);
+    const uint64_t o = soa_offset_of_lane<FMT, SA, SC, THREADS>(t, total_blocks, first_block + tile * T);
     lds_at<u32x4>(lds, t * 16) = gload16(soa + o);
     __syncthreads();
     const u32x4 q = gather_from_image<FMT, VARIANT, SA, SC, T>(lds, t);
@@ -943,30 +1005,10 @@ fwd_tiled_shift(const uint8_t* __restrict__ aos, uint8_t* __restrict__ soa, uint
 constexpr int kHaloAlign = DXTLT_HALO_ALIGN;
 constexpr int kHaloBlocks = kHaloAlign;
 constexpr int kHaloPad = kHaloAlign;   // bytes between the stream regions of the LDS image: room for d_s
-// THREADS: lanes of a halo tile (256, the product's; 512: round 5's experiment -- half the halo share per tile -- kept selectable
-// through dxtlt_set_tuning(512, ...) for the single-buffer call, profiles/r05_halo_512.txt)
+// THREADS: lanes of a halo tile -- 256; 128 for BC1 without the colour split (launch_transform); 512 in the experiments build
+// (round 5's attempt to halve the halo share per tile: BC3 +-0.005, BC1 -0.025, profiles/r05_halo_512.txt)
 template <int FMT, int THREADS = 256>
 constexpr int halo_lds_bytes() { return fmt_block(FMT) * (tile_blocks(FMT, THREADS) + kHaloBlocks) + kHaloPad * 6; }
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// f(std::integral_constant<int, W>) for the calling wave's number W (uniform), W < WAVES
-template <int WAVES, typename F>
-__device__ __forceinline__ void for_this_wave(int t, F&& f)
-{
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    static_for<0, WAVES>([&](auto wi) {
-        if (w == decltype(wi)::value)
-            f(wi);
-    });
-}
 
 // bytes [lo, hi) of a 16-byte segment (both pointers 16-byte aligned at byte 0) as the fewest naturally aligned 1/2/4/8-byte
 // pieces -- at most six.  A first version moved them one byte at a time: fifteen dependent narrow stores into one 64-byte

@@ -88,7 +88,10 @@ struct KernelSet {
     TiledFn tiled[4];  // aligned tiles of 64, 128, 256, 512 threads
     ShiftFn shifted;   // inverse: shifted tiles + edge tile (256 threads); forward: nullptr (experiments build: the first form)
     ShiftFn halo[2];   // forward: halo tiles + edge tiles ([1]: natural shifts); inverse: nullptr
-    ShiftFn halo512;   // forward, natural shifts: the same with 512-lane tiles (dxtlt_set_tuning(512, ...): profiles/r05_halo_512.txt)
+    ShiftFn halo128;   // BC1 without the colour split, natural shifts: 128-lane halo tiles (see launch_transform); else nullptr
+#ifdef DXTLT_EXPERIMENTS
+    ShiftFn halo512;   // natural shifts: 512-lane halo tiles, dxtlt_set_tuning(512, ...) -- measured and not adopted (profiles/r05_halo_512.txt)
+#endif
 #ifdef DXTLT_EXPERIMENTS
     GenericFn generic;
 #endif
@@ -113,7 +116,11 @@ KernelSet kernels_for(bool inverse)
         ks.tiled[3] = fwd_tiled<FMT, VARIANT, SA, SC, 512>;
         ks.halo[0] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false>;
         ks.halo[1] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true>;
+        if constexpr (FMT == kBc1 && !SC)
+            ks.halo128 = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true, 128>;
+#ifdef DXTLT_EXPERIMENTS
         ks.halo512 = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true, 512>;
+#endif
     }
 #ifdef DXTLT_EXPERIMENTS
     if (inverse) {
@@ -295,10 +302,25 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (tuning && !normalizing && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
                                    tuning->tile_threads == 512))
         threads = tuning->tile_threads;   // (normalisation: the default is the only tile size instantiated)
-    // halo tiles of 512 lanes (natural shifts, no normalisation) when the tuning knob asks for 512-lane tiles
-    const bool halo512 = use_shift && !inverse && threads == 512 && ks.halo512 != nullptr && shifts_of(0, true).natural;
+    // Lanes of the halo / shifted tiles: 256 -- except BC1 WITHOUT the colour split, whose forward halo tiles take 128.  That
+    // setting's two 2 KiB stream runs per 256-lane tile are the one tile shape the memory side dislikes: the ALIGNED kernel shows
+    // it too (4 GiB, forward: 0.861 with 128 lanes, 0.810 with 256, 0.821 with 512; with the split 0.846 / 0.839 / 0.804), and it
+    // is what round 3 reported as "no-split halo forward -0.026, cause not found" (tools/bc1_nosplit_probe.py,
+    // profiles/r05_bc1_nosplit.txt).  The experiments build also knows 512-lane halo tiles (measured: BC3 +-0.005, BC1 -0.025).
+    int shift_threads = 256;
+    ShiftFn halo_alt = nullptr;
+    if (use_shift && !inverse && ks.halo128 != nullptr && shifts_of(0, true).natural) {
+        shift_threads = 128;
+        halo_alt = ks.halo128;
+    }
+#ifdef DXTLT_EXPERIMENTS
+    if (use_shift && !inverse && threads == 512 && ks.halo512 != nullptr && shifts_of(0, true).natural) {
+        shift_threads = 512;
+        halo_alt = ks.halo512;
+    }
+#endif
     if (use_shift)
-        threads = halo512 ? 512 : 256;
+        threads = shift_threads;
     const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
 
 #ifdef DXTLT_EXPERIMENTS
@@ -381,8 +403,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             tail = tail || sh.d[i] > 0;
         sh.full_tiles = (uint32_t)num_tiles;
         sh.range_blocks = r.num_blocks;
-        hipLaunchKernelGGL(halo512 ? ks.halo512 : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))),
-                           dim3(halo512 ? 512 : 256), 0, stream, src8, dst8, r.total_blocks, r.first_block, sh);
+        hipLaunchKernelGGL(halo_alt ? halo_alt : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))),
+                           dim3(threads), 0, stream, src8, dst8, r.total_blocks, r.first_block, sh);
         return hipGetLastError();
     }
     if (use_shift) {

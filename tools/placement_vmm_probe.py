@@ -1,4 +1,8 @@
-"""What is "physical placement"?    The BC7 kernels ran at 0.72-0.78 of peak by allocation inside one process and
+"""DO NOT RUN THE VMM ARMS ON A SHARED POOL AGAIN: on ROCm 7.2.0 / gfx950 hipMemMap-backed ranges returned wrong data once a virtual
+range was reused and, in the last pass, raised a GPU memory access fault inside a range just reported mapped (profiles/r05_placement_vmm.txt
+items 1 and 5).  The hipmalloc and hm: arms are plain hipMalloc and safe.  Kept as the record of how round 5's figures were taken.
+
+What is "physical placement"?    The BC7 kernels ran at 0.72-0.78 of peak by allocation inside one process and
 the BC3 corpus inverse at two levels by process (profiles/r04_bc7_placement.txt, r04_batch_edge_tiles.txt).  Here the allocator is under
 the probe's control: the three buffers of a measurement are backed through HIP's virtual-memory API (tools/vmm_helper.cpp) --
 

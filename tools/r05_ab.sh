@@ -13,6 +13,7 @@ for round in 1 2; do
     DXTLT_LIB_PATH=$(lib_path $lib) timeout -k 10 400 python tools/ab_bench_legs.py >> $OUT/ab_legs.txt 2>&1 || exit 3
   done
 done
+[ "${SHIFT_PROBE:-0}" = 1 ] || exit 0
 for lib in "$@"; do
   echo "== $lib" >> $OUT/ab_shift_probe.txt
   for only in aligned128 odd plus; do
