@@ -123,12 +123,13 @@ extern "C" int dxtlt_debug_read_wg_marks(uint32_t* out, size_t count)
 #define WG_TIMING_END(kind)
 #endif
 
-template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE>
-__global__ void __launch_bounds__(256)
+// THREADS = shift_tile_threads(FMT): the lanes of every tile of the launch (256; bcn_device.h has the 128-lane BC1 measurement)
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int THREADS = shift_tile_threads(FMT)>
+__global__ void __launch_bounds__(THREADS)
 batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restrict__ index_arg, uint32_t n_base, uint32_t uniform_wgs,
              uint32_t magic, StridedBatch strided)
 {
-    constexpr int kLds = INVERSE ? kShiftLdsBytes : halo_lds_bytes<FMT>();
+    constexpr int kLds = INVERSE ? shift_lds_bytes(1, THREADS) : halo_lds_bytes<FMT, THREADS>();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLds];
     const uint32_t wg = blockIdx.x;
     WG_TIMING_BEGIN
@@ -220,9 +221,9 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
     if (aligned && local < en.full_tiles) {
         // every stream base on a 128-byte line: the aligned tile, tiles in launch order (as the single-buffer call runs it)
         if constexpr (INVERSE)
-            inv_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+            inv_aligned_tile<FMT, VARIANT, SA, SC, THREADS>(en.src, en.dst, en.blocks, 0, local, lds);
         else
-            fwd_aligned_tile<FMT, VARIANT, SA, SC, 256>(en.src, en.dst, en.blocks, 0, local, lds);
+            fwd_aligned_tile<FMT, VARIANT, SA, SC, THREADS>(en.src, en.dst, en.blocks, 0, local, lds);
         WG_TIMING_END(1);
         return;
     }
@@ -241,26 +242,29 @@ batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restri
     sh.halo_vecs = (int)(en.flags >> 8) & 0xFF;
     sh.full_tiles = en.full_tiles;
     sh.range_blocks = en.blocks;
+    // The whole tile FIRST, with a return behind it: laid out behind the edge tile's code, the whole tile's block inherits the edge
+    // tile's outstanding loads in the compiler's wait-count analysis (the two are alternatives, but the structurised control flow
+    // falls through one into the other) and gets an s_waitcnt vmcnt(0) between its own two loads (tests/test_isa_invariants.py).
     if constexpr (INVERSE) {
-        if (local >= en.full_tiles) {
-            inv_shift_edge_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, sh, en.full_tiles, lds);
-            WG_TIMING_END(4);
-        } else {
+        if (local < en.full_tiles) {
             // Neighbouring tiles share 128-byte lines: consecutive tiles stay on one XCD (xcd_contiguous_tile).  Workgroup
             // residues mod 8 are XCDs whatever the buffer's first workgroup and rotation are: equal residues of `local` meet on
             // one XCD (but for the few workgroups the rotation wraps around).
             const uint64_t tile = xcd_contiguous_tile(local, en.full_tiles);
-            inv_shift_tile<FMT, VARIANT, SA, SC>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
+            inv_shift_tile<FMT, VARIANT, SA, SC, THREADS>(en.src, en.dst, en.blocks, 0, sh, tile, lds);
             WG_TIMING_END(2);
+            return;
         }
+        inv_shift_edge_tile<FMT, VARIANT, SA, SC, THREADS>(en.src, en.dst, en.blocks, sh, en.full_tiles, lds);
+        WG_TIMING_END(4);
     } else {
-        if (local == 0 || local >= en.full_tiles) {
-            fwd_halo_edge_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, sh, local, lds);
-            WG_TIMING_END(local == 0 ? 3 : 4);
-        } else {
-            fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true>(en.src, en.dst, en.blocks, 0, sh, local, lds);
+        if (local != 0 && local < en.full_tiles) {
+            fwd_halo_tile<FMT, VARIANT, SA, SC, kNormNone, true, THREADS>(en.src, en.dst, en.blocks, 0, sh, local, lds);
             WG_TIMING_END(2);
+            return;
         }
+        fwd_halo_edge_tile<FMT, VARIANT, SA, SC, kNormNone, true, THREADS>(en.src, en.dst, sh, local, lds);
+        WG_TIMING_END(local == 0 ? 3 : 4);
     }
 }
 
@@ -272,7 +276,7 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
     const Streams S = make_streams(fmt, sa, s.split_colour);
     const void* soa = inverse ? (const void*)e.src : (const void*)e.dst;
     // any AoS alignment: unaligned 16-byte vector accesses are exact and cheap on gfx950 (launch_transform)
-    const uint64_t T = (uint64_t)tile_blocks(fmt, 256);
+    const uint64_t T = (uint64_t)tile_blocks(fmt, shift_tile_threads(fmt));
     const uint64_t tiles = e.blocks / T, rest = e.blocks % T;
     // The tile forms of launch_transform: aligned tiles when every stream base is on a 128-byte line; otherwise forward halo
     // tiles (windows moved back to a 64-byte boundary) and inverse shifted tiles (slices displaced by the base modulo 16).
@@ -405,7 +409,7 @@ hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const Batch
     case kBc3: k = batch_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(256), 0, stream, d_entries, d_index,
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(shift_tile_threads(fmt)), 0, stream, d_entries, d_index,
                        (uint32_t)batch_index_base_count(total_wgs) | (wide_index ? 0x80000000u : 0u), uniform_wgs, magic, strided);
     return hipGetLastError();
 }

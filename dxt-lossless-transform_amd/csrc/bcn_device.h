@@ -101,15 +101,26 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
-// f(std::integral_constant<int, W>) for the calling wave's number W (uniform), W < WAVES
+// f(std::integral_constant<int, W>) for the calling wave's number W (uniform), W < WAVES: an if / else-if chain with the last wave
+// as the default, like a switch -- mutually exclusive paths, so that the waits one path needs for its loads are not merged into
+// the others (a run of independent `if (w == W)` made the compiler put an s_waitcnt vmcnt(0) between wave 0's two loads of the
+// inverse shifted tile: tests/test_isa_invariants.py)
+template <int W, int WAVES, typename F>
+__device__ __forceinline__ void for_this_wave_from(int w, F&& f)
+{
+    if constexpr (W + 1 >= WAVES) {
+        f(std::integral_constant<int, W>{});
+    } else {
+        if (w == W)
+            f(std::integral_constant<int, W>{});
+        else
+            for_this_wave_from<W + 1, WAVES>(w, f);
+    }
+}
 template <int WAVES, typename F>
 __device__ __forceinline__ void for_this_wave(int t, F&& f)
 {
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    static_for<0, WAVES>([&](auto wi) {
-        if (w == decltype(wi)::value)
-            f(wi);
-    });
+    for_this_wave_from<0, WAVES>(__builtin_amdgcn_readfirstlane(t >> 6), f);
 }
 
 __host__ __device__ constexpr int fmt_block(int fmt) { return fmt == kBc1 ? 8 : 16; }
@@ -887,8 +898,25 @@ __device__ __forceinline__ void shifted_segment(int o, const uint64_t (&gb)[6], 
 }
 
 // LDS bytes of a shifted tile of R x 256 lanes' worth of blocks: the image plus 16 bytes of padding per stream
-constexpr int shift_lds_bytes(int r) { return r * 256 * 16 + 16 * 6; }
+constexpr int shift_lds_bytes(int r, int threads = 256) { return r * threads * 16 + 16 * 6; }
 constexpr int kShiftLdsBytes = shift_lds_bytes(1);
+
+// Lanes of the halo (forward), shifted (inverse) and edge tiles and of the batch kernel: 256 -- except the FORWARD halo tiles of BC1
+// WITHOUT the colour split, which take 128.  That setting's 256-lane tile writes two runs of exactly 2 KiB (colours, indices), the one
+// shape the memory side's write path dislikes -- the ALIGNED kernel shows it as soon as it is run with 256 lanes (forward 0.810
+// against 0.861 with 128 lanes; with the split 0.839 / 0.846; +50 % TCC_EA0_WRREQ_STALL at identical request counts) -- and it is
+// what round 3 reported as "BC1 no-split halo forward -0.026, cause not found" (tools/bc1_nosplit_probe.py,
+// profiles/r05_bc1_nosplit.txt).  128 lanes for EVERY BC1 tile was measured too (-DDXTLT_BC1_SHIFT_THREADS=128: the size the
+// aligned BC1 tiles have had since round 1) and is not the default: single call +0.004 / -0.005, corpus batch -0.033 / -0.008
+// (twice the workgroups, twice the halo share, twice the lookups per byte).
+#ifndef DXTLT_BC1_SHIFT_THREADS
+#define DXTLT_BC1_SHIFT_THREADS 256
+#endif
+__host__ __device__ constexpr int shift_tile_threads(int fmt) { return fmt == kBc1 ? DXTLT_BC1_SHIFT_THREADS : 256; }
+__host__ __device__ constexpr int halo_tile_threads(int fmt, bool split_colour)
+{
+    return fmt == kBc1 && !split_colour ? 128 : shift_tile_threads(fmt);
+}
 // R = sub-tiles of 256 lanes per workgroup.  Only R = 1 is instantiated: with misaligned stream bases every slice shares
 // its first and last 128-byte line with the neighbouring tiles (BC3, 256 blocks per tile: 12 of 38 lines), and R = 4
 // cuts that to 12 of 134 -- but it measured slower, not faster (BC3 odd count 0.710 / 0.773 forward / inverse against
@@ -1334,12 +1362,12 @@ fwd_tiled_halo(const uint8_t* __restrict__ aos_arg, uint8_t* __restrict__ soa_ar
 // A load may fetch the whole aligned segment even when only part of it belongs to this tile's slice: the other bytes land
 // in the stream's LDS padding.  Only a segment that pokes outside the transformed buffer itself (first tile of the first
 // stream, last tile of the last stream) is fetched piecewise.  All loads of the wave are issued before the first wait.
-template <int FMT, bool SA, bool SC, int W>
+template <int FMT, bool SA, bool SC, int W, int THREADS = 256>
 __device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ soa, uint8_t* lds, int t,
                                                     const uint64_t (&gb)[6], const Shifts& sh, uint64_t total_bytes)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, THREADS);
     constexpr int wave_lo = W * 1024, wave_hi = wave_lo + 1024;
     const int o = t * 16;
     int la = 0, k = 0, shift = 0;
@@ -1382,7 +1410,12 @@ __device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ 
         tail_inside = g_t + 16 <= total_bytes;
     }
     u32x4 v_main = {0, 0, 0, 0}, v_tail = {0, 0, 0, 0};
-    asm volatile("" : "+v"(v_main), "+v"(v_tail));   // both cleared here, not between the loads
+    // both destinations cleared HERE, not between the loads -- and the tail's address and predicates made values of this point too
+    // (with 128-lane tiles the compiler sank their computation behind the first load and put the wait in front of it)
+    int tail_flags = (has_tail ? 1 : 0) | (tail_inside ? 2 : 0);
+    asm volatile("" : "+v"(v_main), "+v"(v_tail), "+v"(g_t), "+v"(tail_flags));
+    has_tail = (tail_flags & 1) != 0;
+    tail_inside = (tail_flags & 2) != 0;
     if (main_inside)
         v_main = gload16(soa + g);
     if constexpr (W == 0) {
@@ -1403,14 +1436,14 @@ __device__ __forceinline__ void inv_shift_load_wave(const uint8_t* __restrict__ 
         copy_partial_segment<false>(lds + la, soa + g, (k == 0) ? shift : 0, (k == 0) ? 16 : shift);
 }
 
-// one shifted tile, inverse; `lds`: kShiftLdsBytes
-template <int FMT, int VARIANT, bool SA, bool SC>
+// one shifted tile, inverse; `lds`: shift_lds_bytes(1, THREADS)
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS = 256>
 __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
                                                uint64_t total_blocks, uint64_t /*first_block: in sh.gbase*/, const Shifts& sh, uint64_t tile,
                                                uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, THREADS);
     const int t = threadIdx.x;
     int base[6];
 #pragma unroll
@@ -1420,27 +1453,33 @@ __device__ __forceinline__ void inv_shift_tile(const uint8_t* __restrict__ soa, 
     const uint64_t total_bytes = total_blocks * (uint64_t)fmt_block(FMT);
     uint64_t gb[6];
     slice_bases<FMT, SA, SC, T>(tile, sh, gb);
-    switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
-    case 0: inv_shift_load_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, total_bytes); break;
-    case 1: inv_shift_load_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, total_bytes); break;
-    case 2: inv_shift_load_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, total_bytes); break;
-    default: inv_shift_load_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, total_bytes); break;
+    if constexpr (THREADS == 256) {
+        switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+        case 0: inv_shift_load_wave<FMT, SA, SC, 0>(soa, lds, t, gb, sh, total_bytes); break;
+        case 1: inv_shift_load_wave<FMT, SA, SC, 1>(soa, lds, t, gb, sh, total_bytes); break;
+        case 2: inv_shift_load_wave<FMT, SA, SC, 2>(soa, lds, t, gb, sh, total_bytes); break;
+        default: inv_shift_load_wave<FMT, SA, SC, 3>(soa, lds, t, gb, sh, total_bytes); break;
+        }
+    } else {
+        for_this_wave<THREADS / 64>(t, [&](auto wi) {
+            inv_shift_load_wave<FMT, SA, SC, decltype(wi)::value, THREADS>(soa, lds, t, gb, sh, total_bytes);
+        });
     }
     __syncthreads();
     const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t, base)
                                : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t, base);
-    gstore16_aos(aos, aos + tile * 4096 + t * 16, q);
+    gstore16_aos(aos, aos + tile * (THREADS * 16) + t * 16, q);
 }
 
 // The inverse edge tile: shifted tile `tile` (= sh.full_tiles) of a range whose last 1 .. T - 1 blocks it owns.  A segment is
 // fetched when it holds bytes of those blocks' records: whole when it lies inside the transformed buffer (the bytes that
 // belong to the next stream land in LDS nobody reads), byte by byte where it pokes out of the buffer.
-template <int FMT, int VARIANT, bool SA, bool SC>
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS = 256>
 __device__ __forceinline__ void inv_shift_edge_tile(const uint8_t* __restrict__ soa, uint8_t* __restrict__ aos,
                                                     uint64_t total_blocks, const Shifts& sh, uint64_t tile, uint8_t* lds)
 {
     constexpr Streams S = make_streams(FMT, SA, SC);
-    constexpr int T = tile_blocks(FMT, 256);
+    constexpr int T = tile_blocks(FMT, THREADS);
     constexpr int PV = 16 / fmt_block(FMT);
     const int t = threadIdx.x;
     int base[6];
@@ -1487,11 +1526,16 @@ __device__ __forceinline__ void inv_shift_edge_tile(const uint8_t* __restrict__ 
         else
             copy_segment_bytes(lds + ex.lds_base + ex.wo, gx, xlo, xhi);
     }
+    // vmcnt(0), spelled out.  Every load above has been waited for on the path that issued it, but not on every path the compiler
+    // sees, and in a kernel that holds this tile AND a whole tile (the two are alternatives, yet the structurised control flow falls
+    // through one into the other) the whole tile inherited "loads outstanding" and got a wait between ITS two loads
+    // (tests/test_isa_invariants.py; BC3 inverse 0.77 -> 0.70 when that happened in round 4).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (t * PV < own) {
         const u32x4 q = sh.natural ? gather_shifted<FMT, VARIANT, SA, SC, true>(lds, t, base)
                                    : gather_shifted<FMT, VARIANT, SA, SC, false>(lds, t, base);
-        uint8_t* out = aos + tile * 4096 + t * 16;
+        uint8_t* out = aos + tile * (THREADS * 16) + t * 16;
         if ((t + 1) * PV <= own)
             __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(out));
         else   // BC1, odd count: only the vector's first block exists
@@ -1500,12 +1544,12 @@ __device__ __forceinline__ void inv_shift_edge_tile(const uint8_t* __restrict__ 
 }
 
 // Workgroups [0, sh.full_tiles) are whole tiles; a workgroup behind them, when the launch has one, is the edge tile.
-template <int FMT, int VARIANT, bool SA, bool SC>
-__global__ void __launch_bounds__(256)
+template <int FMT, int VARIANT, bool SA, bool SC, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS)
 inv_tiled_shift(const uint8_t* __restrict__ soa_arg, uint8_t* __restrict__ aos_arg, uint64_t total_blocks, uint64_t first_block,
                 Shifts sh_arg)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kShiftLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[shift_lds_bytes(1, THREADS)];
     const uint32_t wg = blockIdx.x;
     const Shifts sh = shifts_fetched_at_once(sh_arg);
     const uint8_t* __restrict__ soa = fetched_now(soa_arg);
@@ -1516,9 +1560,9 @@ inv_tiled_shift(const uint8_t* __restrict__ soa_arg, uint8_t* __restrict__ aos_a
     const uint64_t tile = !whole ? (uint64_t)sh.full_tiles : shifts_xcd_contiguous(sh, true) ? xcd_contiguous_tile(wg, sh.full_tiles) : (uint64_t)wg;
     const bool edge = !whole;
     if (edge)
-        inv_shift_edge_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, sh, tile, lds);
+        inv_shift_edge_tile<FMT, VARIANT, SA, SC, THREADS>(soa, aos, total_blocks, sh, tile, lds);
     else
-        inv_shift_tile<FMT, VARIANT, SA, SC>(soa, aos, total_blocks, first_block, sh, tile, lds);
+        inv_shift_tile<FMT, VARIANT, SA, SC, THREADS>(soa, aos, total_blocks, first_block, sh, tile, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -86,9 +86,8 @@ using GenericFn = void (*)(const uint8_t*, uint8_t*, uint64_t, uint64_t, uint64_
 
 struct KernelSet {
     TiledFn tiled[4];  // aligned tiles of 64, 128, 256, 512 threads
-    ShiftFn shifted;   // inverse: shifted tiles + edge tile (256 threads); forward: nullptr (experiments build: the first form)
-    ShiftFn halo[2];   // forward: halo tiles + edge tiles ([1]: natural shifts); inverse: nullptr
-    ShiftFn halo128;   // BC1 without the colour split, natural shifts: 128-lane halo tiles (see launch_transform); else nullptr
+    ShiftFn shifted;   // inverse: shifted tiles + edge tile (shift_tile_threads(fmt) lanes); forward: nullptr (experiments build: the first form, 256)
+    ShiftFn halo[2];   // forward: halo tiles + edge tiles, halo_tile_threads(fmt, split_colour) lanes ([1]: natural shifts); inverse: nullptr
 #ifdef DXTLT_EXPERIMENTS
     ShiftFn halo512;   // natural shifts: 512-lane halo tiles, dxtlt_set_tuning(512, ...) -- measured and not adopted (profiles/r05_halo_512.txt)
 #endif
@@ -108,16 +107,14 @@ KernelSet kernels_for(bool inverse)
         ks.tiled[1] = inv_tiled<FMT, VARIANT, SA, SC, 128>;
         ks.tiled[2] = inv_tiled<FMT, VARIANT, SA, SC, 256>;
         ks.tiled[3] = inv_tiled<FMT, VARIANT, SA, SC, 512>;
-        ks.shifted = inv_tiled_shift<FMT, VARIANT, SA, SC>;
+        ks.shifted = inv_tiled_shift<FMT, VARIANT, SA, SC, shift_tile_threads(FMT)>;
     } else {
         ks.tiled[0] = fwd_tiled<FMT, VARIANT, SA, SC, 64>;
         ks.tiled[1] = fwd_tiled<FMT, VARIANT, SA, SC, 128>;
         ks.tiled[2] = fwd_tiled<FMT, VARIANT, SA, SC, 256>;
         ks.tiled[3] = fwd_tiled<FMT, VARIANT, SA, SC, 512>;
-        ks.halo[0] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false>;
-        ks.halo[1] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true>;
-        if constexpr (FMT == kBc1 && !SC)
-            ks.halo128 = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true, 128>;
+        ks.halo[0] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, false, halo_tile_threads(FMT, SC)>;
+        ks.halo[1] = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true, halo_tile_threads(FMT, SC)>;
 #ifdef DXTLT_EXPERIMENTS
         ks.halo512 = fwd_tiled_halo<FMT, VARIANT, SA, SC, kNormNone, true, 512>;
 #endif
@@ -164,8 +161,8 @@ KernelSet bc1_norm_kernels()
     TiledFn tiled = fwd_tiled<kBc1, VARIANT, false, SC, TH, NORM>;
     KernelSet ks{};
     ks.tiled[0] = ks.tiled[1] = ks.tiled[2] = ks.tiled[3] = tiled;
-    ks.halo[0] = fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, false>;
-    ks.halo[1] = fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, true>;
+    ks.halo[0] = fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, false, halo_tile_threads(kBc1, SC)>;
+    ks.halo[1] = fwd_tiled_halo<kBc1, VARIANT, false, SC, NORM, true, halo_tile_threads(kBc1, SC)>;
 #ifdef DXTLT_EXPERIMENTS
     ks.shifted = fwd_tiled_shift<kBc1, VARIANT, false, SC, NORM>;
     ks.generic = generic_kernel<kBc1, VARIANT, false, SC, false, NORM>;
@@ -302,17 +299,10 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (tuning && !normalizing && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
                                    tuning->tile_threads == 512))
         threads = tuning->tile_threads;   // (normalisation: the default is the only tile size instantiated)
-    // Lanes of the halo / shifted tiles: 256 -- except BC1 WITHOUT the colour split, whose forward halo tiles take 128.  That
-    // setting's two 2 KiB stream runs per 256-lane tile are the one tile shape the memory side dislikes: the ALIGNED kernel shows
-    // it too (4 GiB, forward: 0.861 with 128 lanes, 0.810 with 256, 0.821 with 512; with the split 0.846 / 0.839 / 0.804), and it
-    // is what round 3 reported as "no-split halo forward -0.026, cause not found" (tools/bc1_nosplit_probe.py,
-    // profiles/r05_bc1_nosplit.txt).  The experiments build also knows 512-lane halo tiles (measured: BC3 +-0.005, BC1 -0.025).
-    int shift_threads = 256;
+    // Lanes of the halo / shifted / edge tiles (bcn_device.h): 256, and 128 for the forward tiles of BC1 without the colour split.
+    // The experiments build also knows 512-lane halo tiles (measured: BC3 +-0.005, BC1 -0.025, profiles/r05_halo_512.txt).
+    int shift_threads = inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);
     ShiftFn halo_alt = nullptr;
-    if (use_shift && !inverse && ks.halo128 != nullptr && shifts_of(0, true).natural) {
-        shift_threads = 128;
-        halo_alt = ks.halo128;
-    }
 #ifdef DXTLT_EXPERIMENTS
     if (use_shift && !inverse && threads == 512 && ks.halo512 != nullptr && shifts_of(0, true).natural) {
         shift_threads = 512;
@@ -342,7 +332,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         const bool first_form = use_shift && !inverse && (force_bits & 0x400);
         const bool old_routing = (force_bits & 0x2000) != 0;
         if (first_form || (old_routing && use_shift)) {
-            const uint64_t T = (uint64_t)tile_blocks(fmt, 256);   // (these routes know 256-lane tiles only)
+            const int route_threads = first_form ? 256 : inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);   // (the first form: 256 lanes only)
+            const uint64_t T = (uint64_t)tile_blocks(fmt, route_threads);
             const uint64_t tiles = r.num_blocks / T;
             Shifts sh = shifts_of(0, !inverse && !first_form);
             sh.xcd_remap = remap_override >= 0 ? remap_override : (!inverse && !first_form) ? 0 : 1;
@@ -351,8 +342,8 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             sh.full_tiles = (uint32_t)tiles;
             sh.range_blocks = tiles * T;
             if (tiles > 0) {
-                hipLaunchKernelGGL(first_form || inverse ? ks.shifted : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)tiles), dim3(256), 0,
-                                   stream, src8, dst8, r.total_blocks, r.first_block, sh);
+                hipLaunchKernelGGL(first_form || inverse ? ks.shifted : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)tiles),
+                                   dim3(route_threads), 0, stream, src8, dst8, r.total_blocks, r.first_block, sh);
                 if (hipError_t e = hipGetLastError(); e != hipSuccess)
                     return e;
             }
@@ -413,7 +404,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         DXTLT_SET_EXPERIMENT_FIELDS(sh, false);
         sh.full_tiles = (uint32_t)num_tiles;
         sh.range_blocks = r.num_blocks;
-        hipLaunchKernelGGL(ks.shifted, dim3((unsigned)(num_tiles + (rest > 0 ? 1 : 0))), dim3(256), 0, stream, src8, dst8,
+        hipLaunchKernelGGL(ks.shifted, dim3((unsigned)(num_tiles + (rest > 0 ? 1 : 0))), dim3(threads), 0, stream, src8, dst8,
                            r.total_blocks, r.first_block, sh);
         return hipGetLastError();
     }
@@ -423,10 +414,11 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         if (hipError_t e = hipGetLastError(); e != hipSuccess)
             return e;
     }
-    // Behind aligned tiles (or a range smaller than a tile): the rest as ONE edge tile -- a halo tile 0 forward (no halo; writes
-    // every stream from its first byte to its last), a shifted tile 0 inverse -- of up to 256 lanes' worth of blocks (512-thread
-    // BC1 tiles, a tuning size, can leave two).
-    const uint64_t T256 = (uint64_t)tile_blocks(fmt, 256);
+    // Behind aligned tiles (or a range smaller than a tile): the rest as edge tiles -- a halo tile 0 forward (no halo; writes
+    // every stream from its first byte to its last), a shifted tile 0 inverse -- of up to shift_tile_threads lanes' worth of blocks
+    // each (one, unless a tuning size made the aligned tiles larger than that).
+    const int edge_threads = inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);
+    const uint64_t T256 = (uint64_t)tile_blocks(fmt, edge_threads);
     for (uint64_t at = num_tiles * T; at < r.num_blocks; at += T256) {
         Shifts e = shifts_of(at, !inverse);
         DXTLT_SET_EXPERIMENT_FIELDS(e, !inverse);
@@ -434,9 +426,9 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         e.range_blocks = std::min(T256, r.num_blocks - at);
         const uint64_t aos_off = at * (uint64_t)fmt_block(fmt);
         if (inverse)
-            hipLaunchKernelGGL(ks.shifted, dim3(1), dim3(256), 0, stream, src8, dst8 + aos_off, r.total_blocks, r.first_block, e);
+            hipLaunchKernelGGL(ks.shifted, dim3(1), dim3(edge_threads), 0, stream, src8, dst8 + aos_off, r.total_blocks, r.first_block, e);
         else
-            hipLaunchKernelGGL(ks.halo[e.natural ? 1 : 0], dim3(1), dim3(256), 0, stream, src8 + aos_off, dst8, r.total_blocks,
+            hipLaunchKernelGGL(ks.halo[e.natural ? 1 : 0], dim3(1), dim3(edge_threads), 0, stream, src8 + aos_off, dst8, r.total_blocks,
                                r.first_block, e);
         if (hipError_t err = hipGetLastError(); err != hipSuccess)
             return err;

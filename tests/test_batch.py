@@ -95,7 +95,7 @@ def test_batch_of_tens_of_thousands_of_tiny_buffers(pkg, oracle, shape):
     fmt, B = "bc1", 8
     st = settings_for(pkg, fmt, 1, 0, 1)
     rng = np.random.default_rng(0x71A7 + len(shape))
-    hi = 512 if shape == "one_workgroup_each" else 1500
+    hi = 512 if shape == "one_workgroup_each" else 1500    # BC1 tiles hold 512 blocks
     counts = [int(x) for x in rng.integers(1, hi, 20000)]
     offs, at = [], 0
     for n in counts:

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-TILE_BYTES = 4096   # one 256-lane tile
+TILE_BYTES = {1: 4096, 2: 4096, 3: 4096}   # one 256-lane tile (csrc/bcn_device.h, shift_tile_threads)
 
 
 class Planned(C.Structure):
@@ -35,7 +35,7 @@ def expected(fmt, inverse, sa, sc, src, dst, blocks):
     forward / shifted tiles (base modulo 16) inverse; an edge tile for the blocks behind the last whole tile and, forward, for
     the stream tails the moved-back windows leave out; None when a shift is no multiple of its stream's element width"""
     B = 8 if fmt == 1 else 16
-    T = TILE_BYTES // B
+    T = TILE_BYTES[fmt] // B
     soa = src if inverse else dst
     mask = 15 if inverse else 63
     bases = [soa + off * blocks for off, _ in streams(fmt, sa, sc)]
@@ -96,7 +96,7 @@ def lib(pkg):
 def test_plan_follows_the_tile_rules(lib, fmt, sa, sc, inverse):
     rng = np.random.default_rng(1000 * fmt + 10 * sa + sc + 7 * inverse)
     B = 8 if fmt == 1 else 16
-    T = TILE_BYTES // B
+    T = TILE_BYTES[fmt] // B
     blocks = [0, 1, T - 1, T, T + 1, 8 * T, 64 * T - 1, 64 * T, 64 * T + 23] + [int(x) for x in rng.integers(1, 300 * T, 40)]
     # mip-chain counts, counts that keep every stream on its line, and transformed-side pointers off by 0 .. 120 bytes
     blocks += [(4 ** k - 1) // 3 for k in range(4, 11)] + [T * 7 * 32, T * 3 * 64]

@@ -49,9 +49,10 @@ def kernel_body(asm: str, mangled_fragment: str, prefix: str = "_ZN5dxtlt12batch
     return [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
 
 
-@pytest.mark.parametrize("kernel", ["ILi3ELi1ELb1ELb1ELb1E", "ILi1ELi1ELb0ELb1ELb1E"])   # BC3 / BC1 default settings, inverse
-def test_wave0_of_the_inverse_shifted_tile_issues_both_loads_before_it_waits(batch_asm, kernel):
-    lines = kernel_body(batch_asm, kernel)
+@pytest.mark.parametrize("which, kernel", [("batch", "ILi3ELi1ELb1ELb1ELb1E"), ("batch", "ILi1ELi1ELb0ELb1ELb1E"),   # BC3 / BC1 default settings, inverse
+                                           ("single", "ILi3ELi1ELb1ELb1E"), ("single", "ILi1ELi1ELb0ELb1E"), ("single", "ILi2ELi1ELb0ELb1E")])
+def test_wave0_of_the_inverse_shifted_tile_issues_both_loads_before_it_waits(batch_asm, single_asm, which, kernel):
+    lines = kernel_body(batch_asm, kernel) if which == "batch" else kernel_body(single_asm, kernel, "_ZN5dxtlt15inv_tiled_shift")
     nt_loads = [i for i, l in enumerate(lines) if l.startswith("global_load_dwordx4") and l.endswith(" nt")]
     assert len(nt_loads) >= 2
     back_to_back = 0

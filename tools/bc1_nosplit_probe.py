@@ -5,6 +5,7 @@
                                                       aligned tiles at 64 / 128 / 256 / 512 lanes (is it the 256-lane tile shape?),
                                                       halo / shifted tiles forced on ALIGNED data (the kernel without any misalignment),
                                                       2^29 + {1, 3, 16, 17, 33, 63} blocks (which shifts?)
+    python tools/bc1_nosplit_probe.py pmc256 SC     the same for the ALIGNED kernel at 256 lanes on 2^29 blocks (the shape without a halo)
     python tools/bc1_nosplit_probe.py pmc SC        the workload for rocprofv3 --pmc passes (tools/pmc_passes.py): 2^29 + 1 blocks,
                                                       split_colour = SC, three forward + inverse pairs
 """
@@ -53,6 +54,20 @@ def measure(n, sc, threads=0, force=0):
     return 16 * n / (tf * 1e-3) / 8e12, 16 * n / (ti * 1e-3) / 8e12
 
 
+if sys.argv[1] == "pmc256":
+    # the ALIGNED kernel at 256 lanes, where the deficit shows without any halo: 2^29 blocks, split_colour = SC
+    sc = int(sys.argv[2])
+    x = torch.empty(8 * BASE, dtype=torch.uint8, device=dev)
+    pkg.fill_splitmix64(x, 0xB1)
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    pkg.set_tuning(256, 0)
+    for _ in range(3):
+        pkg.transform_bc1_with_settings(x, y, settings(sc))
+        pkg.untransform_bc1_with_settings(y, z, settings(sc))
+    torch.cuda.synchronize()
+    pkg.set_tuning(0, 0)
+    assert torch.equal(x, z)
+    sys.exit(0)
 if sys.argv[1] == "pmc":
     sc = int(sys.argv[2])
     n = BASE + 1
