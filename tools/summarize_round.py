@@ -131,10 +131,10 @@ leg_traffic = {
     "bc3": {"bytes": 8 << 30, "fwd": find("fwd_tiled<3, 1, true, true", 2 * (8 << 30)), "inv": find("inv_tiled<3, 1, true, true", 2 * (8 << 30))},
     "bc2": {"bytes": 8 << 30, "fwd": find("fwd_tiled<2, 1, false, true", 2 * (8 << 30)), "inv": find("inv_tiled<2, 1, false, true", 2 * (8 << 30))},
     "bc7": {"bytes": 4 << 30, "fwd": find("bc7_forward<", 2 * (4 << 30)), "inv": find("bc7_inverse<", 2 * (4 << 30))},
-    "corpus": {"bytes": CB.get(1), "fwd": find("batch_kernel<1, 1, false, true, false>", 2 * (CB.get(1) or 0)),
-               "inv": find("batch_kernel<1, 1, false, true, true>", 2 * (CB.get(1) or 0))},
-    "corpus_bc3": {"bytes": CB.get(3), "fwd": find("batch_kernel<3, 1, true, true, false>", 2 * (CB.get(3) or 0)),
-                   "inv": find("batch_kernel<3, 1, true, true, true>", 2 * (CB.get(3) or 0))},
+    "corpus": {"bytes": CB.get(1), "fwd": find("batch_kernel<1, 1, false, true, false, 256>", 2 * (CB.get(1) or 0)),
+               "inv": find("batch_kernel<1, 1, false, true, true, 256>", 2 * (CB.get(1) or 0))},
+    "corpus_bc3": {"bytes": CB.get(3), "fwd": find("batch_kernel<3, 1, true, true, false, 256>", 2 * (CB.get(3) or 0)),
+                   "inv": find("batch_kernel<3, 1, true, true, true, 256>", 2 * (CB.get(3) or 0))},
     "archive_texture": {"bytes": 256 << 20,
                         "bc1_fwd": find("fwd_tiled<1, 1, false, true", 2 * (256 << 20)), "bc1_inv": find("inv_tiled<1, 1, false, true", 2 * (256 << 20)),
                         "bc3_fwd": find("fwd_tiled<3, 1, true, true", 2 * (256 << 20)), "bc3_inv": find("inv_tiled<3, 1, true, true", 2 * (256 << 20))},
