@@ -34,7 +34,9 @@ HELPER = os.path.join(ROOT, "tools", "libvmm_helper.so")
 ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=12)
 ap.add_argument("--workloads", default="bc7,corpus")
-ap.add_argument("--arms", default="hipmalloc,whole,2m,2m-shuf,small,small-shuf")
+ap.add_argument("--arms", default="hipmalloc", help="round 5 ran hipmalloc,whole,2m,2m-shuf,small,small-shuf and the hm: / vw: arms")
+ap.add_argument("--vmm-is-unsafe-here-and-i-run-it-anyway", dest="allow_vmm", action="store_true",
+                help="the VMM arms (everything but hipmalloc and hm:...) returned wrong data and faulted on ROCm 7.2.0 / gfx950")
 ap.add_argument("--arm-sep", default=",", help="separator of --arms (the hm: / vw: arms hold commas: use ';')")
 ap.add_argument("--copy", default="kernel", choices=("kernel", "hipmemcpy"), help="how data gets into / is checked in the probe's buffers")
 ap.add_argument("--diagnose", action="store_true", help="first: do hipMemcpy / hipMemset agree with kernel copies on VMM-backed buffers?")
@@ -46,6 +48,10 @@ ap.add_argument("--bc7-gib", type=float, default=4.0)
 ap.add_argument("--corpus-scale", type=float, default=1.0)
 args = ap.parse_args()
 
+_vmm_arms = [a for a in args.arms.split(args.arm_sep) if a != "hipmalloc" and not a.startswith("hm:")]
+if (_vmm_arms or args.diagnose) and not args.allow_vmm:
+    sys.exit(f"arms {_vmm_arms or ['--diagnose']} map memory through HIP's VMM, which returned wrong data and raised a GPU memory fault on this "
+             "stack (profiles/r05_placement_vmm.txt items 1 and 5); pass --vmm-is-unsafe-here-and-i-run-it-anyway on a box of your own")
 HELPER_SRC = os.path.join(ROOT, "tools", "vmm_helper.cpp")
 if not os.path.exists(HELPER) or os.path.getmtime(HELPER) < os.path.getmtime(HELPER_SRC):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", HELPER_SRC, "-o", HELPER])
