@@ -261,6 +261,48 @@ def test_rust_sys_crate_matches_the_c_prototypes_by_type(pkg):
         assert re.search(r"pub const " + cname + r": i32 = " + value + ";", src), cname
 
 
+def _call_args(text, start):
+    """the top-level comma-separated arguments of the call whose '(' is at text[start]"""
+    depth, cur, args = 0, "", []
+    for ch in text[start:]:
+        if ch in "([{":
+            depth += 1
+            if depth == 1:
+                continue
+        if ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                break
+        if ch == "," and depth == 1:
+            args.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return args
+
+
+def test_rust_bodies_call_the_sys_crate_with_the_declared_argument_lists():
+    """Every `dxtlt_*(...)` call in rust/core-bodies/*.rs (source only) passes as many arguments as the `-sys` crate's `extern "C"`
+    declaration of that function takes -- and calls nothing the crate does not declare.  (The declarations themselves are checked
+    against the C prototypes by type above; together: bodies -> extern block -> header -> exported symbol.)"""
+    sys_src = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "rust", "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read())
+    declared = {n: len(_split_args(a)) for n, a in re.findall(r"pub fn (dxtlt_\w+)\(([^)]*)\)", sys_src)}
+    seen = 0
+    for path in glob.glob(os.path.join(ROOT, "rust", "core-bodies", "*.rs")):
+        src = re.sub(r"//[^\n]*", "", open(path).read())
+        for m in re.finditer(r"\b(dxtlt_\w+)\s*\(", src):
+            name = m.group(1)
+            if src[max(0, m.start() - 3):m.start()] == "fn ":
+                continue
+            assert name in declared, (os.path.basename(path), name)
+            args = _call_args(src, m.end() - 1)
+            assert len(args) == declared[name], (os.path.basename(path), name, args, declared[name])
+            seen += 1
+    assert seen >= 12      # six transforms, three autos, the threshold, the error text, the per-thread estimator cap (x 2) ...
+
+
 def test_shipped_library_contains_no_experiment_code(pkg):
     """The experiment switches of rounds 1-4 (element-granular kernel, first-form shifted tiles, a wrong-output timing switch, the
     per-workgroup timing arrays) are compiled only with -DDXTLT_EXPERIMENTS / -DDXTLT_WG_TIMING, into side builds under
