@@ -18,6 +18,8 @@ def timed(fn, steps=40):
 res = {}
 rounds = 2
 for fmt, B in (("bc3", 16), ("bc1", 8)):
+    if os.environ.get("PROBE_FMT") and os.environ["PROBE_FMT"] != fmt:
+        continue
     base = (4 << 30) // B
     for label, n, force in (("aligned128", base, 0), ("aligned128_forced_shift", base, 2), ("aligned128_forced_shift_generic_lds", base, 2 | 0x20),
                             ("aligned16_only", base + 16, 0), ("aligned16_forced_shift", base + 16, 2),
