@@ -214,6 +214,149 @@ constexpr int kForceMask = 2 | 0x20;
 #endif
 int launch_force_mask() { return kForceMask; }
 
+// ---- planning: which launches a range takes (pure host arithmetic on addresses; dxtlt_debug_plan_transform exposes it to the
+// CPU tests, launch_transform executes it) ---------------------------------------------------------------------------------------
+namespace {
+
+struct PlannedLaunch {
+    int kind;             // 0: aligned tiles; 1: halo tiles + edge tiles (forward); 2: shifted tiles + edge tile (inverse)
+    int threads;          // lanes per workgroup
+    uint32_t grid;        // workgroups
+    uint64_t aos_offset;  // bytes from the range's AoS pointer to the launch's (an edge tile behind aligned tiles starts further in)
+    Shifts sh;            // kinds 1 and 2
+};
+
+// One range of at most 2^31 blocks.  `aligned_threads`: lanes of the aligned tiles (default or tuning); `halo_threads_override`:
+// 0, or the experiments build's 512.  emit(const PlannedLaunch&) -> hipError_t; the first error ends the walk.
+template <typename Emit>
+hipError_t plan_launches(Format fmt, bool inverse, bool sa, bool sc, const void* soa, const Range& r, int force_bits,
+                         int aligned_threads, int halo_threads_override, Emit&& emit)
+{
+    // Which tiles take the range?  (the table at the top of this file)  The AoS side may sit at any byte address: 16-byte vector
+    // loads / stores at unaligned addresses are exact on gfx950 under ROCm's default memory mode and cost little
+    // (tools/unaligned_lab.hip: a streaming copy at 0.845 of peak drops to 0.81-0.83 with misaligned loads, 0.78-0.79 with
+    // misaligned stores).
+    const Streams S = make_streams(fmt, sa, sc);
+    auto stream_base = [&](int i, uint64_t first_block) {
+        return reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks + (uint64_t)S.width[i] * first_block;
+    };
+    // The aligned tiles need 16-byte aligned stream bases to be correct and 128-byte aligned ones to be fast: with bases that
+    // are only 16-byte aligned every slice shares its first and last line with the neighbouring tiles, which the halo / shifted
+    // tiles handle and the aligned ones do not -- BC3 forward 0.65 against 0.77 of peak (profiles/r01_z/shift_probe.txt).
+    bool any_shift = false;
+    for (int i = 0; i < S.n; ++i)
+        any_shift = any_shift || (stream_base(i, r.first_block) & 127) != 0;
+    const bool use_shift = any_shift || (force_bits & 3) == 2;
+
+    // Shifts of the range [first_block + local_first, ...) for the halo tiles (stream base mod 64) or the shifted tiles (mod 16)
+    auto shifts_of = [&](uint64_t local_first, bool halo) {
+        Shifts sh{};
+        const uint64_t mask = halo ? (uint64_t)(kHaloAlign - 1) : 15;
+        int halo_blocks = 0;
+        for (int i = 0; i < S.n; ++i) {
+            sh.d[i] = (int)(stream_base(i, r.first_block + local_first) & mask);
+            halo_blocks = std::max(halo_blocks, (sh.d[i] + S.width[i] - 1) / S.width[i]);
+        }
+        fill_gbase(sh, S, r.total_blocks, r.first_block + local_first);
+        sh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, sh.d);
+        // only the blocks that have bytes inside a window are fetched as halo: max over the streams of ceil(d_s / w_s) blocks
+        const int per_vec = 16 / fmt_block(fmt);
+        sh.halo_vecs = halo ? (halo_blocks + per_vec - 1) / per_vec : 0;
+        return sh;
+    };
+    // Lanes of the halo / shifted / edge tiles (bcn_device.h): 256, and 128 for the forward tiles of BC1 without the colour split.
+    const int edge_threads = inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);
+    if (use_shift) {
+        Shifts sh = shifts_of(0, !inverse);
+        const int threads = (!inverse && halo_threads_override != 0 && sh.natural) ? halo_threads_override : edge_threads;
+        const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
+        const uint64_t num_tiles = r.num_blocks / T, rest = r.num_blocks - num_tiles * T;
+        // Forward: halo tiles + edge tiles in ONE launch -- tile 0 writes the head of every stream itself, and one more workgroup
+        // takes the blocks behind the last whole tile and the last d_s bytes of every stream.  Identity tile order, write-through
+        // stores: every window starts on a 64-byte sector, and the halo -- re-read by the next tile, on another XCD -- comes out of
+        // the memory-side cache (temporal loads; bcn_device.h).  Inverse: shifted tiles + the edge tile in one launch;
+        // XCD-contiguous tile order (neighbouring tiles share lines).
+        bool tail = rest > 0;
+        if (!inverse)
+            for (int i = 0; i < S.n; ++i)
+                tail = tail || sh.d[i] > 0;
+        sh.full_tiles = (uint32_t)num_tiles;
+        sh.range_blocks = r.num_blocks;
+        return emit(PlannedLaunch{inverse ? 2 : 1, threads, (uint32_t)(num_tiles + (tail ? 1 : 0)), 0, sh});
+    }
+    const uint64_t T = (uint64_t)tile_blocks(fmt, aligned_threads);
+    const uint64_t num_tiles = r.num_blocks / T;
+    if (num_tiles > 0)
+        if (hipError_t e = emit(PlannedLaunch{0, aligned_threads, (uint32_t)num_tiles, 0, Shifts{}}); e != hipSuccess)
+            return e;
+    // Behind aligned tiles (or a range smaller than a tile): the rest as edge tiles -- a halo tile 0 forward (no halo; writes
+    // every stream from its first byte to its last), a shifted tile 0 inverse -- of up to edge_threads lanes' worth of blocks
+    // each (one, unless a tuning size made the aligned tiles larger than that).
+    const uint64_t T_edge = (uint64_t)tile_blocks(fmt, edge_threads);
+    for (uint64_t at = num_tiles * T; at < r.num_blocks; at += T_edge) {
+        Shifts e = shifts_of(at, !inverse);
+        e.full_tiles = 0;
+        e.range_blocks = std::min(T_edge, r.num_blocks - at);
+        if (hipError_t err = emit(PlannedLaunch{inverse ? 2 : 1, edge_threads, 1, at * (uint64_t)fmt_block(fmt), e}); err != hipSuccess)
+            return err;
+    }
+    return hipSuccess;
+}
+
+// HIP refuses a launch of 2^32 or more threads (grid x workgroup), which a 64 GiB buffer reaches at 16 bytes per lane.  Larger
+// ranges go out as consecutive sub-ranges of 2^31 blocks (a multiple of every tile size, so stream alignment and tile boundaries
+// are the same as in one launch): the AoS side advances, the SoA side is addressed through first_block as always.
+constexpr uint64_t kMaxBlocksPerLaunch = 1ull << 31;
+
+int aligned_tile_threads(Format fmt, bool inverse, bool normalizing, const LaunchTuning* tuning)
+{
+    int threads = default_tile_threads(fmt, inverse);
+    if (tuning && !normalizing && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
+                                   tuning->tile_threads == 512))
+        threads = tuning->tile_threads;   // (normalisation: the default is the only tile size instantiated)
+    return threads;
+}
+
+}  // namespace
+
+int debug_plan_transform(Format fmt, bool inverse, const Settings& s, uint64_t src_address, uint64_t dst_address, const Range& r,
+                         const LaunchTuning* tuning, DebugPlannedLaunch* out, int cap)
+{
+    if (s.variant < 0 || s.variant > 3 || r.first_block + r.num_blocks > r.total_blocks || (fmt != kBc1 && fmt != kBc2 && fmt != kBc3))
+        return -1;
+    const bool sa = fmt == kBc3 && s.split_alpha, sc = s.split_colour;
+    const int force_bits = (tuning ? tuning->force_generic : 0) & kForceMask & (2 | 0x20);   // (the product's levers)
+    const void* soa = reinterpret_cast<const void*>(static_cast<uintptr_t>(inverse ? src_address : dst_address));
+    int n = 0;
+    for (uint64_t off = 0; off < r.num_blocks; off += kMaxBlocksPerLaunch) {
+        const Range sub{r.total_blocks, r.first_block + off, std::min(kMaxBlocksPerLaunch, r.num_blocks - off)};
+        const uint64_t sub_aos = off * (uint64_t)fmt_block(fmt);
+        const hipError_t e = plan_launches(fmt, inverse, sa, sc, soa, sub, force_bits, aligned_tile_threads(fmt, inverse, false, tuning), 0,
+                                           [&](const PlannedLaunch& l) {
+                                               if (n < cap) {
+                                                   DebugPlannedLaunch& o = out[n];
+                                                   o.kind = l.kind;
+                                                   o.threads = l.threads;
+                                                   o.workgroups = l.grid;
+                                                   o.full_tiles = l.kind ? l.sh.full_tiles : l.grid;
+                                                   o.range_blocks = l.kind ? l.sh.range_blocks : (uint64_t)l.grid * (uint64_t)tile_blocks(fmt, l.threads);
+                                                   o.aos_offset = sub_aos + l.aos_offset;
+                                                   for (int i = 0; i < 6; ++i) {
+                                                       o.shift[i] = (uint8_t)l.sh.d[i];
+                                                       o.gbase[i] = l.sh.gbase[i];
+                                                   }
+                                                   o.halo_vecs = (uint8_t)l.sh.halo_vecs;
+                                                   o.natural = (uint8_t)l.sh.natural;
+                                               }
+                                               ++n;
+                                               return hipSuccess;
+                                           });
+        if (e != hipSuccess)
+            return -1;
+    }
+    return n;
+}
+
 hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const void* src, void* dst,
                             const Range& r, hipStream_t stream, const LaunchTuning* tuning)
 {
@@ -224,11 +367,6 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     if (s.normalize != kNormNone && (fmt != kBc1 || inverse || s.normalize < 0 || s.normalize > kNormTransparentOnly))
         return hipErrorInvalidValue;  // normalisation exists for the BC1 forward transform only
 
-    // HIP refuses a launch of 2^32 or more threads (grid x workgroup), which a 64 GiB buffer reaches at 16 bytes per
-    // lane.  Larger ranges go out as consecutive sub-ranges of 2^31 blocks (a multiple of every tile size, so stream
-    // alignment and tile boundaries are the same as in one launch): the AoS side advances, the SoA side is addressed
-    // through first_block as always.
-    constexpr uint64_t kMaxBlocksPerLaunch = 1ull << 31;
     if (r.num_blocks > kMaxBlocksPerLaunch) {
         const uint64_t block_bytes = fmt_block(fmt);
         for (uint64_t off = 0; off < r.num_blocks; off += kMaxBlocksPerLaunch) {
@@ -262,59 +400,16 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
     uint8_t* dst8 = static_cast<uint8_t*>(dst);
     const void* soa = inverse ? src : (const void*)dst;
     const int force_bits = (tuning ? tuning->force_generic : 0) & kForceMask;
-
-    // Which tiles take the range?  (the table at the top of this file)  The AoS side may sit at any byte address: 16-byte vector
-    // loads / stores at unaligned addresses are exact on gfx950 under ROCm's default memory mode and cost little
-    // (tools/unaligned_lab.hip: a streaming copy at 0.845 of peak drops to 0.81-0.83 with misaligned loads, 0.78-0.79 with
-    // misaligned stores).
-    const Streams S = make_streams(fmt, sa, sc);
-    auto stream_base = [&](int i, uint64_t first_block) {
-        return reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks + (uint64_t)S.width[i] * first_block;
-    };
-    // The aligned tiles need 16-byte aligned stream bases to be correct and 128-byte aligned ones to be fast: with bases that
-    // are only 16-byte aligned every slice shares its first and last line with the neighbouring tiles, which the halo / shifted
-    // tiles handle and the aligned ones do not -- BC3 forward 0.65 against 0.77 of peak (profiles/r01_z/shift_probe.txt).
-    bool any_shift = false;
-    for (int i = 0; i < S.n; ++i)
-        any_shift = any_shift || (stream_base(i, r.first_block) & 127) != 0;
-    const bool use_shift = any_shift || (force_bits & 3) == 2;
-
-    // Shifts of the range [first_block + local_first, ...) for the halo tiles (stream base mod 64) or the shifted tiles (mod 16)
-    auto shifts_of = [&](uint64_t local_first, bool halo) {
-        Shifts sh{};
-        const uint64_t mask = halo ? (uint64_t)(kHaloAlign - 1) : 15;
-        int halo_blocks = 0;
-        for (int i = 0; i < S.n; ++i) {
-            sh.d[i] = (int)(stream_base(i, r.first_block + local_first) & mask);
-            halo_blocks = std::max(halo_blocks, (sh.d[i] + S.width[i] - 1) / S.width[i]);
-        }
-        fill_gbase(sh, S, r.total_blocks, r.first_block + local_first);
-        sh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, sh.d);
-        // only the blocks that have bytes inside a window are fetched as halo: max over the streams of ceil(d_s / w_s) blocks
-        const int per_vec = 16 / fmt_block(fmt);
-        sh.halo_vecs = halo ? (halo_blocks + per_vec - 1) / per_vec : 0;
-        return sh;
-    };
-    int threads = default_tile_threads(fmt, inverse);
-    if (tuning && !normalizing && (tuning->tile_threads == 64 || tuning->tile_threads == 128 || tuning->tile_threads == 256 ||
-                                   tuning->tile_threads == 512))
-        threads = tuning->tile_threads;   // (normalisation: the default is the only tile size instantiated)
-    // Lanes of the halo / shifted / edge tiles (bcn_device.h): 256, and 128 for the forward tiles of BC1 without the colour split.
-    // The experiments build also knows 512-lane halo tiles (measured: BC3 +-0.005, BC1 -0.025, profiles/r05_halo_512.txt).
-    int shift_threads = inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);
+    const int threads = aligned_tile_threads(fmt, inverse, normalizing, tuning);
+    int halo_threads_override = 0;
     ShiftFn halo_alt = nullptr;
+
 #ifdef DXTLT_EXPERIMENTS
-    if (use_shift && !inverse && threads == 512 && ks.halo512 != nullptr && shifts_of(0, true).natural) {
-        shift_threads = 512;
+    // ---- experiments build: 512-lane halo tiles and the routes of earlier rounds ------------------------------------------------
+    if (!inverse && threads == 512 && ks.halo512 != nullptr) {
+        halo_threads_override = 512;
         halo_alt = ks.halo512;
     }
-#endif
-    if (use_shift)
-        threads = shift_threads;
-    const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
-
-#ifdef DXTLT_EXPERIMENTS
-    // ---- experiments build: the routes of earlier rounds ------------------------------------------------------------------
     const int remap_override = tuning ? tuning->xcd_remap : -1;
     auto element_range = [&](uint64_t local_first, uint64_t count) -> hipError_t {
         if (count == 0)
@@ -325,6 +420,12 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
         return hipGetLastError();
     };
     {
+        const Streams S = make_streams(fmt, sa, sc);
+        bool any_shift = false;
+        for (int i = 0; i < S.n; ++i)
+            any_shift = any_shift || ((reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks +
+                                       (uint64_t)S.width[i] * r.first_block) & 127) != 0;
+        const bool use_shift = any_shift || (force_bits & 3) == 2;
         const void* aos = inverse ? (const void*)dst : src;
         const bool aos_ok = (reinterpret_cast<uintptr_t>(aos) & 15) == 0 || !(force_bits & 0x1000);
         if (!aos_ok || (force_bits & 3) == 1)
@@ -335,8 +436,18 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             const int route_threads = first_form ? 256 : inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);   // (the first form: 256 lanes only)
             const uint64_t T = (uint64_t)tile_blocks(fmt, route_threads);
             const uint64_t tiles = r.num_blocks / T;
-            Shifts sh = shifts_of(0, !inverse && !first_form);
-            sh.xcd_remap = remap_override >= 0 ? remap_override : (!inverse && !first_form) ? 0 : 1;
+            const bool halo = !inverse && !first_form;
+            Shifts sh{};
+            int halo_blocks = 0;
+            for (int i = 0; i < S.n; ++i) {
+                const uint64_t base = reinterpret_cast<uintptr_t>(soa) + (uint64_t)S.off[i] * r.total_blocks + (uint64_t)S.width[i] * r.first_block;
+                sh.d[i] = (int)(base & (uint64_t)(halo ? kHaloAlign - 1 : 15));
+                halo_blocks = std::max(halo_blocks, (sh.d[i] + S.width[i] - 1) / S.width[i]);
+            }
+            fill_gbase(sh, S, r.total_blocks, r.first_block);
+            sh.natural = (force_bits & 0x20) ? 0 : shifts_are_natural(S, sh.d);
+            sh.halo_vecs = halo ? (halo_blocks + 16 / fmt_block(fmt) - 1) / (16 / fmt_block(fmt)) : 0;
+            sh.xcd_remap = remap_override >= 0 ? remap_override : halo ? 0 : 1;
             sh.skip_partial = (force_bits & 0x10) ? 1 : 0;
             sh.line_policy = !first_form ? ((force_bits & 0x800) ? 1 : 3) : (force_bits & 0x40) ? 0 : (force_bits & 0x80) ? 2 : 1;
             sh.full_tiles = (uint32_t)tiles;
@@ -348,7 +459,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
                     return e;
             }
             uint64_t done = tiles * T;
-            if (!inverse && !first_form && tiles > 0) {
+            if (halo && tiles > 0) {
                 // what the halo tiles' windows leave out: the head of every stream of the range (records of its first 64 blocks)
                 // and everything behind the last window
                 if (hipError_t e = element_range(0, kHaloBlocks); e != hipSuccess)
@@ -358,6 +469,7 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             return element_range(done, r.num_blocks - done);
         }
         if (old_routing) {
+            const uint64_t T = (uint64_t)tile_blocks(fmt, threads);
             const uint64_t tiles = r.num_blocks / T;
             if (tiles > 0) {
                 hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)tiles), dim3(threads), 0, stream, src8, dst8,
@@ -368,74 +480,34 @@ hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const v
             return element_range(tiles * T, r.num_blocks - tiles * T);
         }
     }
-#define DXTLT_SET_EXPERIMENT_FIELDS(sh, halo)                                              \
-    do {                                                                                   \
-        (sh).xcd_remap = remap_override >= 0 ? remap_override : (halo) ? 0 : 1;            \
-        (sh).skip_partial = (force_bits & 0x10) ? 1 : 0;                                   \
-        (sh).line_policy = (halo) ? ((force_bits & 0x800) ? 1 : 3) : 1;                    \
-    } while (0)
     const int aligned_flags = remap_override >= 0 ? remap_override : 0;
 #else
-#define DXTLT_SET_EXPERIMENT_FIELDS(sh, halo) (void)0
     const int aligned_flags = 0;
 #endif
 
-    const uint64_t num_tiles = r.num_blocks / T;
-    const uint64_t rest = r.num_blocks - num_tiles * T;
-    if (use_shift && !inverse) {
-        // halo tiles + edge tiles in ONE launch: tile 0 writes the head of every stream itself, and one more workgroup takes the
-        // blocks behind the last whole tile and the last d_s bytes of every stream.  Identity tile order, write-through stores:
-        // every window starts on a 64-byte sector, and the halo -- re-read by the next tile, on another XCD -- comes out of the
-        // memory-side cache (temporal loads; bcn_device.h).
-        Shifts sh = shifts_of(0, true);
-        DXTLT_SET_EXPERIMENT_FIELDS(sh, true);
-        bool tail = rest > 0;
-        for (int i = 0; i < S.n; ++i)
-            tail = tail || sh.d[i] > 0;
-        sh.full_tiles = (uint32_t)num_tiles;
-        sh.range_blocks = r.num_blocks;
-        hipLaunchKernelGGL(halo_alt ? halo_alt : ks.halo[sh.natural ? 1 : 0], dim3((unsigned)(num_tiles + (tail ? 1 : 0))),
-                           dim3(threads), 0, stream, src8, dst8, r.total_blocks, r.first_block, sh);
+    return plan_launches(fmt, inverse, sa, sc, soa, r, force_bits, threads, halo_threads_override, [&](const PlannedLaunch& l) {
+        if (l.kind == 0) {
+            hipLaunchKernelGGL(ks.tiled[threads_slot(l.threads)], dim3(l.grid), dim3(l.threads), 0, stream, src8, dst8, r.total_blocks,
+                               r.first_block, aligned_flags, (int64_t)0, (int64_t)0);
+            return hipGetLastError();
+        }
+        Shifts sh = l.sh;
+#ifdef DXTLT_EXPERIMENTS
+        sh.xcd_remap = remap_override >= 0 ? remap_override : l.kind == 1 ? 0 : 1;
+        sh.skip_partial = (force_bits & 0x10) ? 1 : 0;
+        sh.line_policy = l.kind == 1 ? ((force_bits & 0x800) ? 1 : 3) : 1;
+#endif
+        if (l.kind == 2) {   // the AoS side is the destination
+            hipLaunchKernelGGL(ks.shifted, dim3(l.grid), dim3(l.threads), 0, stream, src8, dst8 + l.aos_offset, r.total_blocks,
+                               r.first_block, sh);
+        } else {
+            const ShiftFn k = (halo_alt != nullptr && l.threads == halo_threads_override) ? halo_alt : ks.halo[sh.natural ? 1 : 0];
+            hipLaunchKernelGGL(k, dim3(l.grid), dim3(l.threads), 0, stream, src8 + l.aos_offset, dst8, r.total_blocks, r.first_block, sh);
+        }
         return hipGetLastError();
-    }
-    if (use_shift) {
-        // shifted tiles + the edge tile in one launch; XCD-contiguous tile order (neighbouring tiles share lines)
-        Shifts sh = shifts_of(0, false);
-        DXTLT_SET_EXPERIMENT_FIELDS(sh, false);
-        sh.full_tiles = (uint32_t)num_tiles;
-        sh.range_blocks = r.num_blocks;
-        hipLaunchKernelGGL(ks.shifted, dim3((unsigned)(num_tiles + (rest > 0 ? 1 : 0))), dim3(threads), 0, stream, src8, dst8,
-                           r.total_blocks, r.first_block, sh);
-        return hipGetLastError();
-    }
-    if (num_tiles > 0) {
-        hipLaunchKernelGGL(ks.tiled[threads_slot(threads)], dim3((unsigned)num_tiles), dim3(threads), 0, stream, src8, dst8,
-                           r.total_blocks, r.first_block, aligned_flags, (int64_t)0, (int64_t)0);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess)
-            return e;
-    }
-    // Behind aligned tiles (or a range smaller than a tile): the rest as edge tiles -- a halo tile 0 forward (no halo; writes
-    // every stream from its first byte to its last), a shifted tile 0 inverse -- of up to shift_tile_threads lanes' worth of blocks
-    // each (one, unless a tuning size made the aligned tiles larger than that).
-    const int edge_threads = inverse ? shift_tile_threads(fmt) : halo_tile_threads(fmt, sc);
-    const uint64_t T256 = (uint64_t)tile_blocks(fmt, edge_threads);
-    for (uint64_t at = num_tiles * T; at < r.num_blocks; at += T256) {
-        Shifts e = shifts_of(at, !inverse);
-        DXTLT_SET_EXPERIMENT_FIELDS(e, !inverse);
-        e.full_tiles = 0;
-        e.range_blocks = std::min(T256, r.num_blocks - at);
-        const uint64_t aos_off = at * (uint64_t)fmt_block(fmt);
-        if (inverse)
-            hipLaunchKernelGGL(ks.shifted, dim3(1), dim3(edge_threads), 0, stream, src8, dst8 + aos_off, r.total_blocks, r.first_block, e);
-        else
-            hipLaunchKernelGGL(ks.halo[e.natural ? 1 : 0], dim3(1), dim3(edge_threads), 0, stream, src8 + aos_off, dst8, r.total_blocks,
-                               r.first_block, e);
-        if (hipError_t err = hipGetLastError(); err != hipSuccess)
-            return err;
-    }
-    return hipSuccess;
+    });
 }
-#undef DXTLT_SET_EXPERIMENT_FIELDS
+
 
 // A regular array of buffers whose stream bases all sit on 128-byte lines and whose block count is a whole number of tiles IS
 // the single-buffer aligned kernel with one more grid dimension: no table, no lookup (the batch kernel's lookup and entry

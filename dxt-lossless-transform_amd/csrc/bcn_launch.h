@@ -47,6 +47,24 @@ struct LaunchTuning {
 // the force_path bits this build of the kernels honours (2 | 0x20 in the shipped library)
 int launch_force_mask();
 
+// What launch_transform would enqueue for a range, without enqueueing anything (addresses are numbers: nothing is dereferenced,
+// no device is needed): the host logic of the single-buffer call for the CPU tests (dxtlt_debug_plan_transform).  Returns the
+// number of launches (records beyond `cap` are counted, not written), -1 for arguments launch_transform refuses.
+struct DebugPlannedLaunch {
+    int32_t kind;           // 0: aligned tiles; 1: halo tiles + edge tiles (forward); 2: shifted tiles + edge tile (inverse)
+    int32_t threads;        // lanes per workgroup
+    uint32_t workgroups;
+    uint32_t full_tiles;    // whole tiles among them (the others are edge tiles)
+    uint64_t range_blocks;  // blocks the launch covers
+    uint64_t aos_offset;    // bytes from the call's AoS pointer to the launch's first block
+    uint8_t shift[6];       // kinds 1, 2: stream base modulo 64 (forward) / 16 (inverse)
+    uint8_t halo_vecs;
+    uint8_t natural;
+    uint64_t gbase[6];
+};
+int debug_plan_transform(Format fmt, bool inverse, const Settings& s, uint64_t src_address, uint64_t dst_address, const Range& r,
+                         const LaunchTuning* tuning, DebugPlannedLaunch* out, int cap);
+
 // Forward: aos (input) -> soa (output).  Inverse: soa (input) -> aos (output).
 // Enqueues on `stream`; returns the first HIP error.
 hipError_t launch_transform(Format fmt, bool inverse, const Settings& s, const void* src, void* dst,

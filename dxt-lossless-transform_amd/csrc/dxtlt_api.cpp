@@ -968,6 +968,34 @@ void dxtlt_set_host_route_threshold_bytes(size_t bytes) { g_host_route_threshold
 
 int32_t dxtlt_tuning_mask(void) { return dxtlt::launch_force_mask(); }
 
+int32_t dxtlt_debug_plan_transform(int32_t format, int32_t inverse, int32_t variant, int32_t split_alpha, int32_t split_colour,
+                                   uint64_t src_address, uint64_t dst_address, uint64_t total_blocks, uint64_t first_block,
+                                   uint64_t num_blocks, DxtltDebugPlannedLaunch* out, int32_t cap)
+{
+    if (format < 1 || format > 3 || cap < 0 || (cap > 0 && out == nullptr) || first_block > total_blocks || num_blocks > total_blocks - first_block)
+        return -1;
+    std::vector<dxtlt::DebugPlannedLaunch> tmp((size_t)cap);
+    const Settings s{variant, split_alpha != 0, split_colour != 0, 0};
+    const dxtlt::LaunchTuning t = current_tuning();
+    const int n = dxtlt::debug_plan_transform((Format)format, inverse != 0, s, src_address, dst_address, Range{total_blocks, first_block, num_blocks},
+                                              &t, tmp.data(), cap);
+    for (int i = 0; i < n && i < cap; ++i) {
+        const dxtlt::DebugPlannedLaunch& l = tmp[(size_t)i];
+        DxtltDebugPlannedLaunch& o = out[i];
+        o.kind = l.kind;
+        o.threads = l.threads;
+        o.workgroups = l.workgroups;
+        o.full_tiles = l.full_tiles;
+        o.range_blocks = l.range_blocks;
+        o.aos_offset = l.aos_offset;
+        std::memcpy(o.shift, l.shift, sizeof o.shift);
+        o.halo_vecs = l.halo_vecs;
+        o.natural = l.natural;
+        std::memcpy(o.gbase, l.gbase, sizeof o.gbase);
+    }
+    return n;
+}
+
 void dxtlt_set_tuning(int32_t tile_threads, int32_t force_path)
 {
     g_tile_threads.store(tile_threads);

@@ -194,6 +194,32 @@ uint32_t dxtlt_debug_plan_batch(int32_t format, int32_t inverse, int32_t variant
                                 DxtltDebugPlannedEntry *entries_out, uint8_t *index_out, size_t index_capacity,
                                 uint32_t *index_is_wide_out);
 
+/* Test hook, no device needed: what a single-buffer DEVICE call (dxtlt_{un,}transform_bcN_with_settings_device,
+ * dxtlt_transform_range_device) on these addresses would enqueue -- addresses are numbers here, nothing is dereferenced.  One
+ * record per kernel launch, in stream order:
+ *   kind 0  aligned tiles: every stream base of the range on a 128-byte line; `workgroups` whole tiles of `threads` lanes x 16 bytes
+ *   kind 1  forward halo tiles (windows moved back to 64-byte sectors): `full_tiles` whole tiles (tile 0 runs as an edge tile: it
+ *           writes the head of every stream) and, when blocks or stream tails are left behind them, one edge-tile workgroup
+ *   kind 2  inverse shifted tiles (slices displaced by the base modulo 16): `full_tiles` whole tiles + an edge tile for the rest
+ * Behind aligned tiles the rest of a range (fewer blocks than a tile) is one more launch of one edge tile (kind 1 / 2, aos_offset
+ * = where it starts).  Ranges of more than 2^31 blocks are planned in pieces of 2^31.  Returns the number of launches (records
+ * beyond `cap` are counted, not written); -1 for arguments the call itself would refuse.  Honours dxtlt_set_tuning. */
+typedef struct DxtltDebugPlannedLaunch {
+    int32_t kind;
+    int32_t threads;        /* lanes per workgroup */
+    uint32_t workgroups;
+    uint32_t full_tiles;    /* whole tiles among them */
+    uint64_t range_blocks;  /* blocks the launch covers */
+    uint64_t aos_offset;    /* bytes from the call's block-array pointer to the launch's first block */
+    uint8_t shift[6];       /* kinds 1, 2: every stream base modulo 64 (forward) / 16 (inverse) */
+    uint8_t halo_vecs;      /* kind 1: 16-byte vectors of blocks in front of a tile that have bytes in its windows */
+    uint8_t natural;        /* every shift a multiple of its stream's element width */
+    uint64_t gbase[6];      /* off_s * total_blocks + w_s * first_block - shift[s] */
+} DxtltDebugPlannedLaunch;
+int32_t dxtlt_debug_plan_transform(int32_t format, int32_t inverse, int32_t variant, int32_t split_alpha, int32_t split_colour,
+                                   uint64_t src_address, uint64_t dst_address, uint64_t total_blocks, uint64_t first_block,
+                                   uint64_t num_blocks, DxtltDebugPlannedLaunch *out, int32_t cap);
+
 /* The same for HOST buffers (d_input / d_output of every item are host pointers here) -- the reference's own call
  * pattern: one call per file, host pointers, textures of 0.1-20 MiB (tools/dxt-lossless-transform-cli/src/commands/
  * transform/mod.rs:154-199).  Through the single-buffer host entry points every texture pays a PCIe round trip of its
