@@ -3,13 +3,13 @@
 // The reference transforms file after file (its CLI fans files out over rayon workers); a texture is typically
 // 0.1-20 MiB.  On MI355X one such buffer cannot fill the chip (a 1 MiB BC1 texture is 256 workgroups for 256 CUs) and
 // a launch costs the host ~5 us, longer than the kernel runs: measured 186 GiB/s for 1024 x 1 MiB through one call per
-// buffer, even when spread over eight streams (profiles/r01_x).  So a batch becomes ONE launch per (format, direction)
-// present in it: the host lays the buffers' workgroups end to end in a table (48 bytes per buffer plus a coarse
-// workgroup -> buffer index), sends the table to the device on the caller's stream (a small kernel reads the mapped
-// pinned slot: no copy-engine hand-over in front of the batch kernel) and launches batch_kernel (bcn_kernels.hip), in
-// which every workgroup looks its buffer up and runs one tile -- aligned, halo or shifted, as the single-buffer call would
-// choose for that buffer -- or 256 blocks of the element path with that buffer's settings.  Asynchronous and ordered like
-// a single call on the caller's stream.
+// buffer, even when spread over eight streams (profiles/r01_x).  So a batch becomes ONE launch per (format, direction
+// and settings combination) present in it: the host lays the buffers' workgroups end to end in a table (96 bytes per buffer
+// plus a two-level workgroup -> buffer index: bcn_launch.h), sends the tables of all its launches to the device in ONE upload on
+// the caller's stream (a small kernel reads the mapped pinned slot: no copy-engine hand-over in front of the batch kernel) and
+// launches batch_kernel (batch_kernels.hip), in which every workgroup looks its buffer up and runs one tile -- aligned, halo
+// or shifted, as the single-buffer call would choose for that buffer -- or the buffer's edge tile.  Asynchronous and ordered
+// like a single call on the caller's stream.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>

@@ -903,20 +903,19 @@ __host__ __device__ constexpr int halo_tile_threads(int fmt, bool split_colour)
 
 
 // ------------------------------------------------------------------------------------------------
-// Forward shifted tiles, second form ("halo tiles").  What the counters said about the form above on odd block counts
-// (profiles/r02_a_shift_pmc.txt, BC3 default settings, 2^26 + 1 blocks against 2^26): HBM requests identical and all of
-// them full 64-byte ones (TCC_EA0_WRREQ == TCC_EA0_WRREQ_64B, no read-modify-write), memory-side write stalls 50 x
-// LOWER -- but 5.5 x the vector-memory store instructions per wave (the typed partial segments), 2 x the VALU and 3.6 x
-// the SALU instructions, 2.65 x the issue-stall cycles: the kernel is bound by its own instruction stream, not by memory.
-// So the partial segments go: a tile's window on stream s is moved back by the stream's misalignment d_s, to the
-// aligned segments [G_s - d_s, G_s - d_s + w_s * T).  Its first d_s bytes are records of the up to 16 blocks BEFORE the
-// tile: the workgroup loads that halo too (16 blocks, one more load instruction for a quarter of wave 0; the lines were
-// just fetched by the previous tile, which the XCD-contiguous tile order keeps on the same L2), every stream region of
-// the LDS image is 16 blocks longer at the front, and what leaves the workgroup is exactly what leaves an aligned tile:
-// one full, aligned 16-byte store per lane.  Bytes no window covers -- the first 16 - d_s bytes of every stream of the
-// RANGE (tile 0 has no halo: the blocks before it may not exist or belong to another call) and everything behind the
-// last tile's windows -- are records of the first 16 and of the last 16 + (num_blocks mod T) blocks of the range, which
-// the element kernel writes (launch_transform); where the two overlap they write the same values.
+// Forward HALO tiles: the tiled structure for transformed buffers whose stream bases are off their lines, forward direction.
+// The first form (bcn_experiments.h) kept each tile's slices where they fall and moved the partial first / last 16-byte segment
+// of every slice with typed narrow stores; the counters on odd block counts (profiles/r02_a_shift_pmc.txt, BC3 default settings,
+// 2^26 + 1 blocks against 2^26) showed HBM requests identical and all of them full 64-byte ones, memory-side write stalls 50 x
+// LOWER -- but 5.5 x the vector-memory store instructions per wave, 2 x the VALU and 3.6 x the SALU instructions, 2.65 x the
+// issue-stall cycles: bound by its own instruction stream, not by memory.  So the partial segments went: a tile's window on
+// stream s is moved BACK by the stream's misalignment d_s, to the aligned range [G_s - d_s, G_s - d_s + w_s * T).  Its first d_s
+// bytes are records of blocks in front of the tile: the workgroup loads that halo too (Shifts::halo_vecs vectors, one more load
+// instruction for the first lanes of wave 0; the lines were fetched moments before by the previous tile and come out of the
+// memory-side cache), every stream region of the LDS image is kHaloBlocks longer at the front, and what leaves the workgroup is
+// exactly what leaves an aligned tile: one full, aligned 16-byte store per lane.  Bytes no whole tile's window covers -- the head
+// of every stream of the RANGE (tile 0 has no halo: the blocks before it may not exist or belong to another call) and everything
+// behind the last window -- are written by the EDGE tiles further down (rounds 1-3: by the element-granular kernel).
 // ------------------------------------------------------------------------------------------------
 // Windows are moved back to a 64-BYTE boundary, not just a 16-byte one (d_s = stream base mod 64): two tiles that meet
 // inside a 128-byte line then each write whole 64-byte sectors of it, which is what the memory side writes without a
