@@ -273,8 +273,8 @@ int32_t dxtlt_fill_splitmix64_device(void *d_dst, size_t len_bytes, uint64_t see
 const char *dxtlt_last_error(void);
 /* Number of visible HIP devices (0 if the runtime cannot initialise). */
 int32_t dxtlt_device_count(void);
-/* Size routing for callers that keep a CPU implementation of their own next to this library (the reference's crates do:
- * rust/core-bodies).  A host-pointer call is a PCIe round trip: at least ~17 us, at most ~25-43 GiB/s, where one CPU core of
+/* Size routing for callers that keep a CPU implementation of their own next to this library (the reference's crates can, as an
+ * opt-in: rust/core-bodies, feature `cpu-below-threshold`; by default they send every call here).  A host-pointer call is a PCIe round trip: at least ~17 us, at most ~25-43 GiB/s, where one CPU core of
  * the reference moves 20-50 GiB/s out of cache -- below the crossover the caller's own CPU path is faster (64 KiB: 20 us
  * here against 2.9 us there; measured crossover ~32 MiB).  Returns that crossover in bytes: the
  * value of $DXTLT_HOST_ROUTE_THRESHOLD_BYTES when set (0 = route everything to the device), else what

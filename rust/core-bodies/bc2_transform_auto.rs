@@ -3,7 +3,11 @@
 //! Candidate order, the estimated section, the strict `<` tie-break and the final transform with the winner are
 //! implemented on the library side exactly as in the reference (csrc/auto_transform.cpp), so the same estimator
 //! yields the same settings and the same bytes.
-use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge, SerialEstimatorCalls};
+use crate::gfx950_glue::{abort_on_device_failure, vtable, EstimatorBridge, SerialEstimatorCalls};
+#[cfg(feature = "cpu-without-device")]
+use crate::gfx950_glue::device_is_absent;
+#[cfg(feature = "cpu-below-threshold")]
+use crate::gfx950_glue::stays_on_cpu;
 use crate::transform::{Bc2EstimateSettings, DetermineBestTransformError};
 use crate::Bc2TransformSettings;
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
@@ -20,9 +24,9 @@ pub unsafe fn transform_bc2_auto<T>(
 where
     T: SizeEstimationOperations,
 {
-    // small inputs stay on the crate's own CPU path (the reference's body of this function, renamed `transform_bc2_auto_cpu`
-    // and kept unchanged behind the `cpu` feature; gfx950_glue.rs "size routing")
-    #[cfg(feature = "cpu")]
+    // OPT-IN (`cpu-below-threshold`, off by default): small inputs stay on the crate's own CPU path (the reference's body of this
+    // function, renamed `transform_bc2_auto_cpu`, compiled only under the internal `cpu` feature; gfx950_glue.rs "size routing")
+    #[cfg(feature = "cpu-below-threshold")]
     if stays_on_cpu(len) {
         return transform_bc2_auto_cpu(input_ptr, output_ptr, len, transform_options);
     }
@@ -43,7 +47,7 @@ where
         DXTLT_E_ESTIMATOR => Err(DetermineBestTransformError::SizeEstimationError(
             bridge.take_error().expect("the estimator callback failed, so it parked its error"))),
         DXTLT_E_ALLOCATION => Err(DetermineBestTransformError::AllocateError(AllocateError::default())),
-        #[cfg(feature = "cpu")]
+        #[cfg(feature = "cpu-without-device")]
         other if device_is_absent(other) => transform_bc2_auto_cpu(input_ptr, output_ptr, len, transform_options),
         other => abort_on_device_failure("transform_bc2_auto", other),
     }

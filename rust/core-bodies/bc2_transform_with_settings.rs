@@ -1,14 +1,24 @@
 //! UNCOMPILED (see ../README.md).  New bodies for
 //! core/dxt-lossless-transform-bc2/src/transform/transform_with_settings.rs (:30-73 and :93-138).
-//! Doc comments and safety sections of the reference stay as they are.  The reference's OWN bodies stay too: renamed
-//! `transform_bc2_with_settings_cpu` / `untransform_bc2_with_settings_cpu`, unchanged, behind the crate's `cpu` feature
-//! (default on) -- they are this crate's CPU implementation, on the reference's side of the boundary; libdxtlt_gfx950 has
-//! none and is never asked for one.
+//! Doc comments and safety sections of the reference stay as they are.
 //!
-//! Routing (gfx950_glue.rs): a call below `dxtlt_host_route_threshold_bytes()` (measured crossover 32 MiB) goes to the
-//! crate's own dispatch -- a PCIe round trip costs a small texture 2.5-7 x what one CPU core does -- everything else to the
-//! device.  Without the `cpu` feature every call goes to the device.
-use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu};
+//! DEFAULT FEATURES: every call goes to the device, whatever its size, and a machine without a HIP device panics with the
+//! library's `DXTLT_E_NO_DEVICE` text -- the shipped integration is the path this repository tests (the C ABI of
+//! libdxtlt_gfx950.so, which has no CPU implementation and is never asked for one).  Corpora of small files are served by ONE
+//! `dxtlt_transform_batch_host` / `dxtlt_transform_batch_device` call (sections 2 and 7), not by this per-file
+//! entry point.
+//!
+//! Two OPT-IN cargo features keep the reference's own bodies in the crate -- renamed `transform_bc2_with_settings_cpu` /
+//! `untransform_bc2_with_settings_cpu`, unchanged, compiled only under the internal feature `cpu` that both imply:
+//!   * `cpu-below-threshold`: a call below `dxtlt_host_route_threshold_bytes()` (measured crossover 32 MiB: a PCIe round trip
+//!     costs a small texture 2.5-7 x what one CPU core does) stays on the crate's own dispatch;
+//!   * `cpu-without-device`: `DXTLT_E_NO_DEVICE`, and only that status, takes the crate's own body.
+//! Calls that take either detour run reference-built code this repository neither contains nor tests.
+use crate::gfx950_glue::abort_on_device_failure;
+#[cfg(feature = "cpu-without-device")]
+use crate::gfx950_glue::device_is_absent;
+#[cfg(feature = "cpu-below-threshold")]
+use crate::gfx950_glue::stays_on_cpu;
 use crate::{Bc2TransformSettings, Bc2UntransformSettings};
 use dxtlt_gfx950_sys::{dxtlt_transform_bc2_with_settings, dxtlt_untransform_bc2_with_settings};
 
@@ -20,7 +30,7 @@ pub unsafe fn transform_bc2_with_settings(
     transform_options: Bc2TransformSettings,
 ) {
     debug_assert!(len.is_multiple_of(16));
-    #[cfg(feature = "cpu")]
+    #[cfg(feature = "cpu-below-threshold")]
     if stays_on_cpu(len) {
         return transform_bc2_with_settings_cpu(input_ptr, output_ptr, len, transform_options);
     }
@@ -31,7 +41,7 @@ pub unsafe fn transform_bc2_with_settings(
         transform_options.split_colour_endpoints,
     );
     if rc != 0 {
-        #[cfg(feature = "cpu")]
+        #[cfg(feature = "cpu-without-device")]
         if device_is_absent(rc) {
             return transform_bc2_with_settings_cpu(input_ptr, output_ptr, len, transform_options);
         }
@@ -47,7 +57,7 @@ pub unsafe fn untransform_bc2_with_settings(
     untransform_options: Bc2UntransformSettings,
 ) {
     debug_assert!(len.is_multiple_of(16));
-    #[cfg(feature = "cpu")]
+    #[cfg(feature = "cpu-below-threshold")]
     if stays_on_cpu(len) {
         return untransform_bc2_with_settings_cpu(input_ptr, output_ptr, len, untransform_options);
     }
@@ -57,7 +67,7 @@ pub unsafe fn untransform_bc2_with_settings(
         untransform_options.split_colour_endpoints,
     );
     if rc != 0 {
-        #[cfg(feature = "cpu")]
+        #[cfg(feature = "cpu-without-device")]
         if device_is_absent(rc) {
             return untransform_bc2_with_settings_cpu(input_ptr, output_ptr, len, untransform_options);
         }

@@ -1,7 +1,11 @@
 //! UNCOMPILED (see ../README.md).  New body for
 //! core/dxt-lossless-transform-bc3/src/transform/transform_auto.rs (:196-294).  Two estimator calls per candidate
 //! (alpha endpoints, colour endpoints), sizes added, as in the reference; implemented in csrc/auto_transform.cpp.
-use crate::gfx950_glue::{abort_on_device_failure, device_is_absent, stays_on_cpu, vtable, EstimatorBridge, SerialEstimatorCalls};
+use crate::gfx950_glue::{abort_on_device_failure, vtable, EstimatorBridge, SerialEstimatorCalls};
+#[cfg(feature = "cpu-without-device")]
+use crate::gfx950_glue::device_is_absent;
+#[cfg(feature = "cpu-below-threshold")]
+use crate::gfx950_glue::stays_on_cpu;
 use crate::transform::{Bc3EstimateSettings, DetermineBestTransformError};
 use crate::Bc3TransformSettings;
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
@@ -18,9 +22,9 @@ pub unsafe fn transform_bc3_auto<T>(
 where
     T: SizeEstimationOperations,
 {
-    // small inputs stay on the crate's own CPU path (the reference's body of this function, renamed `transform_bc3_auto_cpu`
-    // and kept unchanged behind the `cpu` feature; gfx950_glue.rs "size routing")
-    #[cfg(feature = "cpu")]
+    // OPT-IN (`cpu-below-threshold`, off by default): small inputs stay on the crate's own CPU path (the reference's body of this
+    // function, renamed `transform_bc3_auto_cpu`, compiled only under the internal `cpu` feature; gfx950_glue.rs "size routing")
+    #[cfg(feature = "cpu-below-threshold")]
     if stays_on_cpu(len) {
         return transform_bc3_auto_cpu(input_ptr, output_ptr, len, transform_options);
     }
@@ -42,7 +46,7 @@ where
         DXTLT_E_ESTIMATOR => Err(DetermineBestTransformError::SizeEstimationError(
             bridge.take_error().expect("the estimator callback failed, so it parked its error"))),
         DXTLT_E_ALLOCATION => Err(DetermineBestTransformError::AllocateError(AllocateError::default())),
-        #[cfg(feature = "cpu")]
+        #[cfg(feature = "cpu-without-device")]
         other if device_is_absent(other) => transform_bc3_auto_cpu(input_ptr, output_ptr, len, transform_options),
         other => abort_on_device_failure("transform_bc3_auto", other),
     }

@@ -4,14 +4,18 @@
 //! lock from `std` -- the estimator's first error is parked behind a spin lock built on `core::sync::atomic`.
 use core::cell::UnsafeCell;
 use core::ffi::{c_void, CStr};
-use core::sync::atomic::{AtomicBool, AtomicUsize, Ordering};
+#[cfg(feature = "cpu-below-threshold")]
+use core::sync::atomic::AtomicUsize;
+use core::sync::atomic::{AtomicBool, Ordering};
 
 use dxt_lossless_transform_api_common::estimate::SizeEstimationOperations;
-use dxtlt_gfx950_sys::{dxtlt_host_route_threshold_bytes, dxtlt_last_error, DltSizeEstimator};
+#[cfg(feature = "cpu-below-threshold")]
+use dxtlt_gfx950_sys::dxtlt_host_route_threshold_bytes;
+use dxtlt_gfx950_sys::{dxtlt_last_error, DltSizeEstimator};
 
 /// The reference's `transform_bcN_with_settings` cannot fail; a device can.  A failure must be loud -- never a silent
-/// detour that would hide a broken deployment.  (A machine WITHOUT a device is a different matter when the crate was
-/// built with its own CPU path: see `device_is_absent`.)
+/// detour that would hide a broken deployment.  That includes a machine WITHOUT a device, unless the crate was built with the
+/// opt-in feature `cpu-without-device` (see `device_is_absent`).
 #[cold]
 #[inline(never)]
 pub(crate) fn abort_on_device_failure(what: &str, rc: i32) -> ! {
@@ -19,25 +23,26 @@ pub(crate) fn abort_on_device_failure(what: &str, rc: i32) -> ! {
     panic!("{what}: libdxtlt_gfx950 status {rc}: {text}");
 }
 
-// ---- size routing ------------------------------------------------------------------------------------------------------
-// A host-pointer call into the library is a PCIe round trip: at least ~17 us and at most 25-43 GiB/s, where ONE core of this
-// crate's own SIMD path moves 20-50 GiB/s out of cache.  The reference's call pattern is one call per file from rayon
-// workers (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:154-199) on textures that average 4 MiB, its test
-// assets are 32-64 KiB: below the crossover the crate's own dispatch -- kept, untouched, behind the `cpu` feature -- is the
-// faster path (64 KiB: 2.9 us against 20 us), above it the device is.  The crossover is the library's to know
-// (`dxtlt_host_route_threshold_bytes()`: measured 32 MiB, overridable by $DXTLT_HOST_ROUTE_THRESHOLD_BYTES); it is read
-// once.
+// ---- opt-in detours to the crate's own CPU path (both OFF by default) -----------------------------------------------------
+// With the default features every call reaches the device and a missing device is a panic: the shipped integration is the
+// tested path.  What follows exists only under the opt-in features `cpu-below-threshold` / `cpu-without-device`.
+//
+// Why a maintainer might opt in: a host-pointer call into the library is a PCIe round trip -- at least ~17 us and at most
+// 25-43 GiB/s, where ONE core of this crate's own SIMD path moves 20-50 GiB/s out of cache.  The reference's call pattern is
+// one call per file from rayon workers (tools/dxt-lossless-transform-cli/src/commands/transform/mod.rs:154-199) on textures that
+// average 4 MiB, its test assets are 32-64 KiB (64 KiB: 2.9 us against 20 us).  The crossover is the library's to know
+// (`dxtlt_host_route_threshold_bytes()`: measured 32 MiB, overridable by $DXTLT_HOST_ROUTE_THRESHOLD_BYTES); it is read once.
+// The device route for such a corpus is ONE batch call (`dxtlt_transform_batch_host`), not a CPU detour.
 
 /// 0 = not asked yet; otherwise threshold + 1.
+#[cfg(feature = "cpu-below-threshold")]
 static ROUTE_THRESHOLD_PLUS_ONE: AtomicUsize = AtomicUsize::new(0);
 
-/// `true`: this call is small enough that the crate's own CPU dispatch is the faster path.  Always `false` without the
-/// `cpu` feature (the crate then has no implementation of its own left).
+/// `true`: this call is small enough that the crate's own CPU dispatch is the faster path.  Exists only under the opt-in
+/// feature `cpu-below-threshold`.
+#[cfg(feature = "cpu-below-threshold")]
 #[inline]
 pub(crate) fn stays_on_cpu(len: usize) -> bool {
-    if !cfg!(feature = "cpu") {
-        return false;
-    }
     let mut t = ROUTE_THRESHOLD_PLUS_ONE.load(Ordering::Relaxed);
     if t == 0 {
         t = unsafe { dxtlt_host_route_threshold_bytes() }.saturating_add(1).max(1);
@@ -46,12 +51,12 @@ pub(crate) fn stays_on_cpu(len: usize) -> bool {
     len < t - 1
 }
 
-/// `true`: the library found no HIP device AND the crate carries its own CPU path AND the `cpu-without-device` feature
-/// asks for it: the same binary then still works on a machine without a GPU.  Off by default: `DXTLT_E_NO_DEVICE` panics
-/// like every other status.
+/// `true`: the library found no HIP device.  Exists only under the opt-in feature `cpu-without-device`, with which the same
+/// binary still works on a machine without a GPU; without it `DXTLT_E_NO_DEVICE` panics like every other status.
+#[cfg(feature = "cpu-without-device")]
 #[inline]
 pub(crate) fn device_is_absent(rc: i32) -> bool {
-    cfg!(all(feature = "cpu", feature = "cpu-without-device")) && rc == dxtlt_gfx950_sys::DXTLT_E_NO_DEVICE
+    rc == dxtlt_gfx950_sys::DXTLT_E_NO_DEVICE
 }
 
 // ---- transform_bcN_auto: SizeEstimationOperations behind the C vtable ---------------------------------------------------

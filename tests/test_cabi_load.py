@@ -345,24 +345,59 @@ def test_host_route_threshold_default_setter_and_environment(pkg):
         assert r.returncode == 0 and int(r.stdout.strip()) == want, (value, r.stdout, r.stderr)
 
 
-def test_rust_bodies_route_by_size_and_glue_is_no_std():
-    """The shipped Rust bodies (source only) send small inputs to the crate's own CPU dispatch before the FFI call, keep the
-    loud panic for device failures, and the glue they share uses nothing from std (the core crates make std optional) and
-    puts no bound beyond the reference's on `vtable`."""
+def test_rust_bodies_default_to_the_device_and_glue_is_no_std():
+    """The shipped Rust bodies (source only): with the DEFAULT feature list every call is the FFI call -- no size detour, no
+    device-absent detour (both exist only behind opt-in features) -- device failures panic loudly, and the glue
+    they share uses nothing from std (the core crates make std optional) and puts no bound beyond the reference's on `vtable`."""
     import os
     import re
 
+    import tomli
+
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust", "core-bodies")
+    features = tomli.load(open(os.path.join(root, "Cargo.features.toml"), "rb"))["features"]
+    assert features["default"] == ["std"], "the default route must be the tested device path: no cpu feature by default"
+    assert features["cpu"] == [] and features["cpu-below-threshold"] == ["cpu"] and features["cpu-without-device"] == ["cpu"]
+
+    def without_optional_code(src):
+        """What is left of a body with the default features: an attribute `#[cfg(feature = "cpu…")]` removes the statement, match arm
+        or item that follows it (here always: one line, or a braced block that closes at the attribute's indentation)."""
+        out, lines, i = [], src.splitlines(), 0
+        while i < len(lines):
+            m = re.match(r'(\s*)#\[cfg\(feature = "(cpu[a-z-]*)"\)\]\s*$', lines[i])
+            if not m:
+                out.append(lines[i])
+                i += 1
+                continue
+            assert m.group(2) in ("cpu-below-threshold", "cpu-without-device"), lines[i]
+            i += 1
+            while lines[i].lstrip().startswith("#["):      # further attributes of the same item
+                i += 1
+            if lines[i].rstrip().endswith("{"):
+                while lines[i] != m.group(1) + "}":
+                    i += 1
+            i += 1
+        return "\n".join(out)
+
     for n in (1, 2, 3):
         src = open(os.path.join(root, f"bc{n}_transform_with_settings.rs")).read()
         for fn in (f"transform_bc{n}_with_settings", f"untransform_bc{n}_with_settings"):
             body = src[src.index(f"pub unsafe fn {fn}("):]
             body = body[:body.index("\n}\n") + 3]
+            # opt-in: the size route stands in front of the FFI call, the device-absent route behind it, each under its own feature
             route, ffi = body.index("if stays_on_cpu(len)"), body.index(f"dxtlt_{fn}(")
             assert route < ffi and f"return {fn}_cpu(" in body[route:ffi], fn
-            assert "abort_on_device_failure" in body[ffi:] and "device_is_absent(rc)" in body[ffi:], fn
+            assert '#[cfg(feature = "cpu-below-threshold")]\n    if stays_on_cpu(len)' in body, fn
+            assert '#[cfg(feature = "cpu-without-device")]\n        if device_is_absent(rc)' in body[ffi:], fn
+            # default: nothing but the FFI call and the loud failure
+            default = without_optional_code(body)
+            assert "_cpu(" not in default and "stays_on_cpu" not in default and "device_is_absent" not in default, fn
+            assert f"dxtlt_{fn}(" in default and "abort_on_device_failure" in default, fn
         auto = open(os.path.join(root, f"bc{n}_transform_auto.rs")).read()
         assert auto.index("if stays_on_cpu(len)") < auto.index(f"dxtlt_transform_bc{n}_auto(")
+        default = without_optional_code(auto)
+        assert "_cpu(" not in default.replace(f"transform_bc{n}_auto_cpu`", "") and "stays_on_cpu" not in default and "device_is_absent" not in default, n
+        assert f"dxtlt_transform_bc{n}_auto(" in default and "abort_on_device_failure" in default
         # the reference's bounds, nothing added
         assert re.search(r"where\s+T: SizeEstimationOperations,\s*\{", auto), n
     glue = open(os.path.join(root, "gfx950_glue.rs")).read()
@@ -370,5 +405,8 @@ def test_rust_bodies_route_by_size_and_glue_is_no_std():
     assert "std::" not in code and "Mutex" not in code
     assert re.search(r"pub\(crate\) fn vtable<T: SizeEstimationOperations>\(", code)
     assert "dxtlt_host_route_threshold_bytes()" in code
+    default_glue = without_optional_code(glue)
+    assert "stays_on_cpu" not in default_glue.replace("`stays_on_cpu`", "") and "fn device_is_absent" not in default_glue
+    assert 'feature = "cpu"' not in code, "only the two opt-in features gate code; `cpu` is internal (the kept bodies)"
     sys_src = open(os.path.join(os.path.dirname(root), "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read()
     assert "#![no_std]" in sys_src
