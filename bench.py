@@ -166,18 +166,27 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def per_rank_record(R, fwd_ms, inv_ms, elapsed_s) -> dict:
-    """`world_size_seen` + `per_rank` of the JSON line: every rank's own HIP-event times and wall clock of the timed steps
-    (a collective: every rank calls it).  With them the first record taken on more than one device shows a straggler and
-    proves that the process group -- RCCL under the nccl backend -- saw N ranks."""
-    rows = R.gather_over_ranks([R.rank, -1.0 if fwd_ms is None else fwd_ms, -1.0 if inv_ms is None else inv_ms, elapsed_s])
+def per_rank_record(R, fwd_ms, inv_ms, elapsed_s, flags=None) -> dict:
+    """`world_size_seen` + `per_rank` of the JSON line: every rank's own HIP-event times, wall clock of the timed steps and the
+    exactness flags of ITS OWN data (`flags`: name -> bool; the ranks' blocks differ, so each checks its own round trip and its own
+    oracle window) -- a collective: every rank calls it.  With them the first record taken on more than one device shows a
+    straggler, proves that the process group -- RCCL under the nccl backend -- saw N ranks, and verifies every rank's result."""
+    names = sorted(flags or {})
+    rows = R.gather_over_ranks([R.rank, -1.0 if fwd_ms is None else fwd_ms, -1.0 if inv_ms is None else inv_ms, elapsed_s]
+                               + [1.0 if flags[n] else 0.0 for n in names])
     per_rank = []
-    for r, f, i, e in rows:
+    for r, f, i, e, *fl in rows:
         row = {"rank": int(r), "elapsed_s": round(e, 5)}
         if f >= 0:
             row.update({"fwd_ms": round(f, 4), "inv_ms": round(i, 4)})
+        row.update({n: bool(v == 1.0) for n, v in zip(names, fl)})
         per_rank.append(row)
     return {"world_size_seen": R.world_size_seen(), "backend": R.backend if R.dist is not None else "none", "per_rank": per_rank}
+
+
+def all_ranks_exact(per_rank: dict, names) -> bool:
+    """The AND over every rank's row of every flag in `names` (a rank that did not report a flag counts as false)."""
+    return all(row.get(n) is True for row in per_rank["per_rank"] for n in names)
 
 
 BLOCK_BYTES = {"bc1": 8, "bc2": 16, "bc3": 16, "bc7": 16}
@@ -215,11 +224,39 @@ def rendezvous_only(args) -> None:
     total, first, blocks = job_shape(args, BLOCK_BYTES[fmt], R.world, R.rank)
     ranges = R.gather_over_ranks([float(R.rank), float(first), float(blocks)])
     seen = R.world_size_seen()
+    # the per-rank verification of a real N > 1 line, rehearsed without a device: every rank takes a window of ITS OWN block range
+    # (the same place and the same rank-dependent splitmix64 offset as main()), has two CPU statements of the transform agree on it
+    # (here they stand in for the HIP path and the oracle), and the flags travel through the very per_rank_record / all_ranks_exact
+    # the real run uses
+    flags_rows, all_exact = None, None
+    if fmt != "bc7":
+        import numpy as np
+
+        if R.rank == 0:
+            from oracle import oracle_c
+
+            oracle_c.lib()
+        R.cpu_barrier()
+        from oracle import oracle_c, oracle_np
+
+        block = BLOCK_BYTES[fmt]
+        seed = {"bc1": 0x0BC10002, "bc2": 0x0BC20002, "bc3": 0x0BC30003}[fmt]
+        win = min(1 << 12, blocks)
+        lf = min(blocks // 2 + 4097, blocks - win)
+        xin = oracle_c.fill_splitmix64(win * block, seed, (first + lf) * block // 8)
+        a = oracle_c.transform(fmt, xin, 1, True, True)
+        b = oracle_np.transform(fmt, xin, 1, True, True)
+        back = oracle_c.transform(fmt, a, 1, True, True, inverse=True)
+        rec = per_rank_record(R, None, None, 0.0, {"round_trip_exact": bool(np.array_equal(back, xin)),
+                                                   "oracle_window_exact": bool(np.array_equal(a, b))})
+        flags_rows = rec["per_rank"]
+        all_exact = all_ranks_exact(rec, ("round_trip_exact", "oracle_window_exact"))
     if R.rank == 0:
         print(json.dumps({"rendezvous": "ok", "n_gpus": R.world, "max_over_ranks": worst, "backend": R.backend,
                           "world_size_seen": seen, "per_rank": per_rank, "scaling": args.scaling,
                           "config": {"format": fmt, "total_blocks": total, "blocks_per_gpu": blocks},
-                          "ranges": [[int(r), int(f), int(b)] for r, f, b in ranges]}), flush=True)
+                          "ranges": [[int(r), int(f), int(b)] for r, f, b in ranges],
+                          "per_rank_flags": flags_rows, "bit_exact_roundtrip_and_oracle_window": all_exact}), flush=True)
     R.finish()
 
 
@@ -809,21 +846,32 @@ def leg_exact(leg: dict) -> bool:
     return bool(flags) and all(flags)
 
 
+# The driver's record of a run (BENCH_rNN.json `parsed`) keeps the contract keys and the FIRST 24 members of `config`, and drops
+# `legs`.  So `config` is ordered for it: the workload, then every BASELINE config's roofline fractions, then the headline's own
+# figures; descriptive members (mode, sharding, block counts, GiB/s -- all derivable) come behind.
+DRIVER_KEEPS = 24
+LEG_ORDER = ("bc3", "bc7_uniform", "bc7_skewed", "archive", "corpus", "corpus_bc3", "bc2")   # configs[2], [3] x2, [4]'s share, the corpus, BC2
+HEADLINE_ORDER = ("bit_exact_roundtrip_and_oracle_window", "fwd_frac", "inv_frac", "fwd_ms", "inv_ms", "format", "total_blocks")
+
+
 def summarize_legs_into_config(out: dict) -> None:
-    """The driver's record of a run keeps the contract keys and `config` / `roofline` with their scalar members, and drops
-    `legs` (BENCH_r04.json: `extra_keys`): configs[2]-[4] and the corpus were builder-side claims as far as that record went.
-    So `config` carries them in short -- `legs_summary[name] = [fwd frac, inv frac, every exactness flag true]` and, because a
-    nested value may be dropped too, the same as flat scalars `leg_<name>_{fwd_frac,inv_frac,exact}` -- and `inv_frac` (flat, also
-    in `roofline`) for the headline's inverse kernel."""
+    """Every leg rides in `config` in short, in the order the driver's 24 kept members want: `workload`, `legs_all_exact`,
+    `legs_inexact` (names of legs with any exactness flag false: round trip, oracle window / prefix / textures), then
+    `leg_<name>_{fwd_frac,inv_frac}` for LEG_ORDER, then the headline's flag, fractions and times.  Behind them, for readers of the
+    whole line: the descriptive members, `leg_<name>_exact` and the nested `legs_summary[name] = [fwd frac, inv frac, exact]`."""
     legs = out.get("legs") or {}
-    summary = {}
-    for name, leg in legs.items():
-        r = leg.get("roofline") or {}
-        f, i, ok = r.get("frac"), (r.get("inverse_kernel") or {}).get("frac"), leg_exact(leg)
+    cfg = out["config"]
+    names = [n for n in LEG_ORDER if n in legs] + [n for n in legs if n not in LEG_ORDER]
+    summary, fracs, exact = {}, {}, {}
+    for name in names:
+        r = legs[name].get("roofline") or {}
+        f, i, ok = r.get("frac"), (r.get("inverse_kernel") or {}).get("frac"), leg_exact(legs[name])
         summary[name] = [f, i, ok]
-        out["config"][f"leg_{name}_fwd_frac"], out["config"][f"leg_{name}_inv_frac"], out["config"][f"leg_{name}_exact"] = f, i, ok
-    out["config"]["legs_summary"] = summary
-    out["config"]["legs_all_exact"] = bool(summary) and all(v[2] for v in summary.values())
+        fracs[f"leg_{name}_fwd_frac"], fracs[f"leg_{name}_inv_frac"], exact[f"leg_{name}_exact"] = f, i, ok
+    head = {"workload": cfg["workload"], "legs_all_exact": bool(summary) and all(v[2] for v in summary.values()),
+            "legs_inexact": [n for n in names if not summary[n][2]], **fracs}
+    head.update({k: cfg[k] for k in HEADLINE_ORDER if k in cfg})
+    out["config"] = {**head, **{k: v for k, v in cfg.items() if k not in head}, **exact, "legs_summary": summary}
 
 
 def attach_corpus_traffic(legs: dict) -> None:
@@ -893,30 +941,38 @@ def bc7_main(args) -> None:
     elapsed = R.max_over_ranks(elapsed_here)
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
-    per_rank = per_rank_record(R, fwd_ms, inv_ms, elapsed_here)
-    ok = bool(torch.equal(z, x))
+    round_trip_exact = bool(torch.equal(z, x))
     cpu = None
-    if rank == 0:
-        import numpy as np
+    import numpy as np
 
+    if rank == 0:
         from oracle import oracle_c
 
-        # a 64 MiB prefix (whole granules: its streams are a transform of their own) against the CPU statement
-        sample = 64 << 20
-        small_y = torch.empty(sample, dtype=torch.uint8, device=dev)
-        bc7.transform_bc7(x[:sample], small_y)
-        xin = x[:sample].cpu().numpy()
-        t1 = time.perf_counter()
-        want = oracle_c.transform_bc7(xin)
-        t2 = time.perf_counter()
-        back = oracle_c.transform_bc7(want, inverse=True)
-        t3 = time.perf_counter()
-        ok = ok and bool(np.array_equal(small_y.cpu().numpy(), want)) and bool(np.array_equal(back, xin))
+        oracle_c.lib()          # one process brings the checker's .so up to date before the others load it
+    R.cpu_barrier()
+    from oracle import oracle_c
+
+    # a prefix of THIS rank's buffer (whole granules: its streams are a transform of their own) against the CPU statement: 64 MiB on
+    # rank 0 (also the cpu_baseline sample), 8 MiB on the others (their data differ: the fill starts at rank * nbytes / 8)
+    sample = min(nbytes, (64 << 20) if rank == 0 else (8 << 20))
+    small_y = torch.empty(sample, dtype=torch.uint8, device=dev)
+    bc7.transform_bc7(x[:sample], small_y)
+    xin = x[:sample].cpu().numpy()
+    t1 = time.perf_counter()
+    want = oracle_c.transform_bc7(xin)
+    t2 = time.perf_counter()
+    back = oracle_c.transform_bc7(want, inverse=True)
+    t3 = time.perf_counter()
+    oracle_prefix_exact = bool(np.array_equal(small_y.cpu().numpy(), want)) and bool(np.array_equal(back, xin))
+    if rank == 0:
         cpu = {"value": round(2 * sample / (t3 - t1) / 2**30, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
-               "sample": "64 MiB of the same mode-mixed workload, forward+inverse, scalar C restatement of this build's "
+               "sample": f"{sample >> 20} MiB of the same mode-mixed workload, forward+inverse, scalar C restatement of this build's "
                          "own BC7 format (oracle/dxtlt_oracle_bc7.c; the reference has no BC7 transform to time)",
                "fwd_value": round(sample / (t2 - t1) / 2**30, 3)}
-    assert ok, "GPU result differs from the oracle / round trip failed"
+    per_rank = per_rank_record(R, fwd_ms, inv_ms, elapsed_here,
+                               {"round_trip_exact": round_trip_exact, "oracle_prefix_exact": oracle_prefix_exact})
+    ok = all_ranks_exact(per_rank, ("round_trip_exact", "oracle_prefix_exact"))
+    assert ok, f"GPU result differs from the oracle / round trip failed: {per_rank['per_rank']}"
     if rank != 0:
         R.finish()
         return
@@ -1032,9 +1088,8 @@ def archive_main(args) -> None:
     barrier()
     elapsed_here = time.perf_counter() - t0
     elapsed = R.max_over_ranks(elapsed_here)
-    per_rank = per_rank_record(R, None, None, elapsed_here)
-
-    ok = all(bool(torch.equal(z, x)) for x, z in zip(xs, zs))
+    round_trip_exact = all(bool(torch.equal(z, x)) for x, z in zip(xs, zs))
+    ok = True
     win = 1 << 15
     for i in (0, 1, k - 1):                                # one window per format and the rank's last texture
         f = fmts[i]
@@ -1048,6 +1103,9 @@ def archive_main(args) -> None:
         for off, w in pkg.stream_table(f, st[f]):
             got[off * win: off * win + w * win] = ys[i][off * blocks + w * first: off * blocks + w * (first + win)].cpu().numpy()
         ok = ok and bool(np.array_equal(got, want))
+    # every rank's own textures (rank-dependent data): its round trip and its oracle windows ride in per_rank, the line's flag is the AND
+    per_rank = per_rank_record(R, None, None, elapsed_here, {"round_trip_exact": round_trip_exact, "oracle_windows_exact": ok})
+    ok = all_ranks_exact(per_rank, ("round_trip_exact", "oracle_windows_exact"))
     ratios = {}
     if rank == 0:
         golden = os.path.join(ROOT, "tests", "golden")
@@ -1068,7 +1126,7 @@ def archive_main(args) -> None:
                     ratios[f][f"plain_zstd{level}"] = round(tiled.size / zstd_ratio.compressed_size(tiled, level), 4)
                     ratios[f][f"transformed_gpu_zstd{level}"] = round(tiled.size / zstd_ratio.compressed_size(gpu_out, level), 4)
                     ratios[f][f"transformed_cpu_zstd{level}"] = round(tiled.size / zstd_ratio.compressed_size(cpu_out, level), 4)
-    assert ok, "GPU result differs from the oracle / round trip failed"
+    assert ok, f"GPU result differs from the oracle / round trip failed: {per_rank['per_rank']}"
     if rank != 0:
         R.finish()
         return
@@ -1371,26 +1429,32 @@ def main() -> None:
 
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
-    per_rank = per_rank_record(R, fwd_ms, inv_ms, elapsed_here)
+    # correctness inside the run, on EVERY rank (rank r's blocks are its own: fill_splitmix64(x, seed, first * block / 8)): exact round
+    # trip, and one window of the rank's own block range against the oracle; the flags ride in per_rank and the line's flag is their AND
+    import numpy as np
 
-    # correctness inside the run: exact round trip, and one window against the oracle
-    bit_exact = bool(torch.equal(z, x))
     if rank == 0:
-        import numpy as np
-
         from oracle import oracle_c
 
-        win = min(1 << 16, blocks)
-        lf = min(blocks // 2 + 4097, blocks - win)
-        xin = x[lf * block:(lf + win) * block].cpu().numpy()
-        want = oracle_c.transform(fmt, xin, int(settings.decorrelation_mode), settings.split_colour_endpoints,
-                                  getattr(settings, "split_alpha_endpoints", True))
-        got = np.empty_like(want)
-        for off, w in pkg.stream_table(fmt, settings):
-            lo = off * y_total + w * (y_first + lf)
-            got[off * win: off * win + w * win] = y[lo: lo + w * win].cpu().numpy()
-        bit_exact = bit_exact and bool(np.array_equal(got, want))
-    assert bit_exact, "GPU result differs from the oracle / round trip failed"
+        oracle_c.lib()          # one process brings the checker's .so up to date before the others load it
+    R.cpu_barrier()
+    from oracle import oracle_c
+
+    round_trip_exact = bool(torch.equal(z, x))
+    win = min(1 << 16, blocks)
+    lf = min(blocks // 2 + 4097, blocks - win)
+    xin = x[lf * block:(lf + win) * block].cpu().numpy()
+    want = oracle_c.transform(fmt, xin, int(settings.decorrelation_mode), settings.split_colour_endpoints,
+                              getattr(settings, "split_alpha_endpoints", True))
+    got = np.empty_like(want)
+    for off, w in pkg.stream_table(fmt, settings):
+        lo = off * y_total + w * (y_first + lf)
+        got[off * win: off * win + w * win] = y[lo: lo + w * win].cpu().numpy()
+    oracle_window_exact = bool(np.array_equal(got, want))
+    per_rank = per_rank_record(R, fwd_ms, inv_ms, elapsed_here,
+                               {"round_trip_exact": round_trip_exact, "oracle_window_exact": oracle_window_exact})
+    bit_exact = all_ranks_exact(per_rank, ("round_trip_exact", "oracle_window_exact"))
+    assert bit_exact, f"GPU result differs from the oracle / round trip failed: {per_rank['per_rank']}"
 
     if rank != 0:
         # rank 0 still drives every device for the sharded_host_array leg; stay out of its way, then leave together

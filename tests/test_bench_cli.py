@@ -154,7 +154,8 @@ def test_default_line_carries_the_other_single_gpu_configs_as_legs():
     assert legs["bc7_skewed"]["mode_counts"][6] > 2 * legs["bc7_uniform"]["mode_counts"][6]
     # the driver's record keeps `config` and drops `legs`: every leg rides there in short, nested and as flat scalars
     cfg = d["config"]
-    assert set(cfg["legs_summary"]) == set(legs) and cfg["legs_all_exact"] is True
+    assert set(cfg["legs_summary"]) == set(legs) and cfg["legs_all_exact"] is True and cfg["legs_inexact"] == []
+    assert_driver_keeps_every_config(list(cfg))
     assert 0 < cfg["inv_frac"] < 1 and cfg["inv_frac"] == d["roofline"]["inv_frac"] == d["roofline"]["inverse_kernel"]["frac"]
     for name, leg in legs.items():
         f, i, ok = cfg["legs_summary"][name]
@@ -174,6 +175,7 @@ def test_bench_two_ranks_self_launched_on_one_gpu(scaling):
     assert d["n_gpus"] == 2 and d["scaling"] == scaling
     assert d["world_size_seen"] == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1]
     assert all(r["fwd_ms"] > 0 and r["inv_ms"] > 0 and r["elapsed_s"] > 0 for r in d["per_rank"])
+    assert all(r["round_trip_exact"] is True and r["oracle_window_exact"] is True for r in d["per_rank"])      # every rank, its own data
     assert d["config"]["bit_exact_roundtrip_and_oracle_window"] is True
     total = d["config"]["total_blocks"]
     assert total == (d["config"]["blocks_per_gpu"] * 2)      # strong: the array split in two; weak: two shards of one array
@@ -187,6 +189,9 @@ def test_bench_bc7_and_archive_lines():
     a = _run_bench(["--workload", "archive", "--size-gib", "1", "--gpus", "2", "--archive-split", "range"],
                    env={"DXTLT_BENCH_BACKEND": "gloo"})
     assert a["config"]["archive_split"] == "range" and a["config"]["bit_exact_roundtrip_and_oracle_windows"] is True
+    assert len(a["per_rank"]) == 2 and all(r["round_trip_exact"] is True and r["oracle_windows_exact"] is True for r in a["per_rank"])
+    b = _run_bench(["--format", "bc7", "--gpus", "2"], env={"DXTLT_BENCH_BACKEND": "gloo"})
+    assert len(b["per_rank"]) == 2 and all(r["round_trip_exact"] is True and r["oracle_prefix_exact"] is True for r in b["per_rank"])
 
 
 def test_physical_cores_counts_cores_not_threads():
@@ -227,6 +232,75 @@ def test_eight_rank_rendezvous_the_driver_shape():
     assert rec["world_size_seen"] == 8 and len(rec["per_rank"]) == 8 and rec["scaling"] == "weak"
     assert rec["config"] == {"format": "bc1", "total_blocks": 8 * 2**30, "blocks_per_gpu": 2**30}
     assert rec["ranges"] == [[r, r * 2**30, 2**30] for r in range(8)]
+    # every rank verified a window of ITS OWN range (rank-dependent data) and the flags were all-gathered: N rows, N x 2 true flags
+    assert [row["rank"] for row in rec["per_rank_flags"]] == list(range(8))
+    assert all(row["round_trip_exact"] is True and row["oracle_window_exact"] is True for row in rec["per_rank_flags"])
+    assert rec["bit_exact_roundtrip_and_oracle_window"] is True
+
+
+@pytest.mark.parametrize("world,scaling", [(2, "weak"), (4, "strong")])
+def test_every_rank_reports_its_own_exactness_flags(world, scaling):
+    """bench.py --gpus N from a bare shell (self-launch), gloo, no device: the N > 1 record's `per_rank` rows each carry the rank's
+    own round-trip and oracle-window flags, and the line's flag is their AND."""
+    import json
+
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rendezvous-only", "--scaling", scaling,
+                        "--format", "bc3", "--size-gib", "0.25"], capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert rec["world_size_seen"] == world and len(rec["per_rank_flags"]) == world
+    assert sum(row["round_trip_exact"] is True for row in rec["per_rank_flags"]) == world
+    assert sum(row["oracle_window_exact"] is True for row in rec["per_rank_flags"]) == world
+    assert rec["bit_exact_roundtrip_and_oracle_window"] is True
+
+
+def test_all_ranks_exact_is_false_when_one_rank_disagrees():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rows = {"per_rank": [{"rank": 0, "round_trip_exact": True, "oracle_window_exact": True},
+                         {"rank": 1, "round_trip_exact": True, "oracle_window_exact": False}]}
+    assert bench.all_ranks_exact(rows, ("round_trip_exact",)) is True
+    assert bench.all_ranks_exact(rows, ("round_trip_exact", "oracle_window_exact")) is False
+    assert bench.all_ranks_exact({"per_rank": [{"rank": 0}]}, ("round_trip_exact",)) is False
+
+
+def test_config_is_ordered_for_the_24_members_the_driver_keeps():
+    """The driver's BENCH record keeps the first 24 members of `config`: after `workload` they are `legs_all_exact`, `legs_inexact`
+    and both roofline fractions of every BASELINE config (configs[2], configs[3] on both mode mixes, configs[4]'s share, the corpus
+    legs, BC2), then the headline's own flag / fractions / times; the descriptive members come behind."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    names = ("bc3", "bc2", "bc7_uniform", "bc7_skewed", "archive", "corpus", "corpus_bc3")       # the order run_legs produces them in
+    legs = {n: {"roofline": {"frac": 0.8, "inverse_kernel": {"frac": 0.79}}, "bit_exact_roundtrip": True, "oracle_window_exact": n != "bc2"}
+            for n in names}
+    cfg = {"workload": "w", "mode": "m", "format": "bc1", "blocks_per_gpu": 1, "bytes_per_gpu": 8, "total_blocks": 1, "seed": "0x1",
+           "sharding": "s", "bit_exact_roundtrip_and_oracle_window": True, "fwd_ms": 1.0, "inv_ms": 1.0, "fwd_GiBps": 1.0, "inv_GiBps": 1.0,
+           "fwd_frac": 0.8, "inv_frac": 0.8}
+    out = {"legs": legs, "config": dict(cfg)}
+    bench.summarize_legs_into_config(out)
+    keys = list(out["config"])
+    assert_driver_keeps_every_config(keys)
+    assert out["config"]["legs_inexact"] == ["bc2"] and out["config"]["legs_all_exact"] is False
+    assert set(cfg) <= set(keys) and all(out["config"][k] == v for k, v in cfg.items())            # nothing lost, only reordered
+    assert out["config"]["legs_summary"]["corpus"] == [0.8, 0.79, True] and out["config"]["leg_bc2_exact"] is False
+
+
+def assert_driver_keeps_every_config(keys):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    first = keys[:bench.DRIVER_KEEPS]
+    assert bench.DRIVER_KEEPS == 24 and first[:3] == ["workload", "legs_all_exact", "legs_inexact"]
+    for name in ("bc3", "bc7_uniform", "bc7_skewed", "archive", "corpus", "corpus_bc3", "bc2"):
+        assert f"leg_{name}_fwd_frac" in first and f"leg_{name}_inv_frac" in first, name
+    for k in ("bit_exact_roundtrip_and_oracle_window", "fwd_frac", "inv_frac", "fwd_ms", "inv_ms"):
+        assert k in first, k
+    for k in ("fwd_GiBps", "inv_GiBps", "mode", "sharding", "blocks_per_gpu", "bytes_per_gpu"):
+        assert k in keys and k not in first, k
 
 
 def test_strong_scaling_ranges_partition_the_array():
