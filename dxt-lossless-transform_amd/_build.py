@@ -23,13 +23,12 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-
 
 
 def _extra_flags(extra_flags=None) -> list:
-    """Extra compiler flags of a SIDE build (A/B experiments: tools/ab_build_rev.sh; -DDXTLT_EXPERIMENTS, -DDXTLT_WG_TIMING):
-    the argument, else $DXTLT_EXTRA_HIPCC_FLAGS.  A build with extra flags never touches the shipped library or its objects:
-    it goes to build/side-<hash of the flags>/ (objects and library), so a variable left set in a shell cannot put experiment
-    code into libdxtlt_gfx950.so, and objects of one flag set are never linked into another."""
-    if extra_flags is None:
-        extra_flags = os.environ.get("DXTLT_EXTRA_HIPCC_FLAGS", "").split()
-    return list(extra_flags)
+    """Extra compiler flags of a SIDE build (A/B experiments: -DDXTLT_EXPERIMENTS, -DDXTLT_WG_TIMING): ONLY the argument.  The
+    environment is never read here: build() / __graft_entry__.build() always bring the SHIPPED library up to date, whatever is
+    left set in a shell; $DXTLT_EXTRA_HIPCC_FLAGS is honoured by tools/ab_build_rev.sh alone, which passes it in explicitly.  A
+    build with extra flags never touches the shipped library or its objects: it goes to build/side-<hash of the flags>/ (objects
+    and library), and objects of one flag set are never linked into another."""
+    return list(extra_flags or [])
 
 
 def _dirs(extra: list):

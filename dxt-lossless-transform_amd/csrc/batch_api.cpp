@@ -32,9 +32,13 @@ namespace {
 using namespace dxtlt_host;
 using dxtlt::BatchEntry;
 
-// Table staging: a ring of pinned host buffers with device twins.  A slot is reused only after the copy that last read
-// it has finished (its event).  A call takes at most three slots (BC7 forward, BC7 inverse, one buffer for the tables of all its
-// BC1-3 groups), so it never waits for its own work, and blocks only when more than one earlier call is still in flight.
+// Table staging: a ring of pinned host buffers with device twins.  A slot is reused only after the copy and the kernels that last
+// read it have finished (its event).  A call takes exactly ONE slot -- the tables of its two BC7 launches and of all its BC1-3
+// groups share one staged buffer and one upload -- so it never waits for its own work, and its acquire blocks the host only when
+// kSlots earlier calls of this thread are all still in flight.  (Until round 6 a call with BC7 forward, BC7 inverse and BC1-3
+// items took three slots: the next such call's second acquire landed on a slot the previous call had left pending and waited in
+// hipEventSynchronize for that call's kernels -- an "asynchronous" call that host-blocked with a single earlier call in flight,
+// which dxtlt_transform_batch_host hit on every chunk.)
 constexpr int kSlots = 4;
 
 struct TableSlot {
@@ -206,10 +210,18 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
     static const bool no_uniform = dxtlt::experiment_env("DXTLT_BATCH_NO_UNIFORM") != nullptr;   // A/B switches of the experiments build (tools/batch_kernel_probe.py)
     static const bool no_strided = dxtlt::experiment_env("DXTLT_BATCH_NO_STRIDED") != nullptr;
 
-    // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one
-    for (int inverse = 0; inverse < 2; ++inverse) {
+    // BC7 items (format 7; no settings): their granules in one launch per direction, their tail parts in a second one.  Planned
+    // here, staged and launched below with everything else.
+    struct Bc7Plan {
         std::vector<dxtlt::bc7::BatchEntry> entries, tails;
+        std::vector<uint32_t> coarse;
         uint64_t wgs = 0;
+        size_t at = 0, entry_bytes = 0, tail_bytes = 0, bytes = 0;
+    };
+    Bc7Plan bc7_plans[2];
+    size_t table_bytes = 0;
+    for (int inverse = 0; inverse < 2; ++inverse) {
+        Bc7Plan& p = bc7_plans[inverse];
         for (size_t i = 0; i < count; ++i) {
             const DxtltBatchItem& it = items[i];
             if (it.format != 7 || it.len == 0 || (it.inverse != 0) != (inverse != 0))
@@ -218,57 +230,39 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             const uint8_t* src = static_cast<const uint8_t*>(it.d_input);
             uint8_t* dst = static_cast<uint8_t*>(it.d_output);
             if (main != 0) {
-                entries.push_back({src, dst, main, (uint32_t)wgs, 0});
-                wgs += main / 1024;
+                p.entries.push_back({src, dst, main, (uint32_t)p.wgs, 0});
+                p.wgs += main / 1024;
             }
             if (tail != 0)
-                tails.push_back({src + main * 16, dst + main * 16, 0, 0, (uint32_t)tail});
+                p.tails.push_back({src + main * 16, dst + main * 16, 0, 0, (uint32_t)tail});
         }
-        if (entries.empty() && tails.empty())
+        if (p.entries.empty() && p.tails.empty())
             continue;
-        const size_t coarse_n = ((size_t)wgs + 63) / 64;
-        const size_t entry_bytes = entries.size() * sizeof(dxtlt::bc7::BatchEntry), tail_bytes = tails.size() * sizeof(dxtlt::bc7::BatchEntry);
-        const size_t bytes = (entry_bytes + tail_bytes + coarse_n * sizeof(uint32_t) + 15) & ~(size_t)15;
-        TableSlot* slot = nullptr;
-        hipError_t e = g_ring.acquire(bytes, &slot);
-        if (e != hipSuccess)
-            return fail(kDevice, "batch table staging", e);
-        uint8_t* h = static_cast<uint8_t*>(slot->host);
-        if (entry_bytes) std::memcpy(h, entries.data(), entry_bytes);
-        if (tail_bytes) std::memcpy(h + entry_bytes, tails.data(), tail_bytes);
-        uint32_t* coarse = reinterpret_cast<uint32_t*>(h + entry_bytes + tail_bytes);
+        p.coarse.resize(((size_t)p.wgs + 63) / 64);
         size_t cur = 0;
-        for (size_t k = 0; k < coarse_n; ++k) {
-            while (cur + 1 < entries.size() && entries[cur + 1].first_wg <= (uint32_t)(k * 64))
+        for (size_t k = 0; k < p.coarse.size(); ++k) {
+            while (cur + 1 < p.entries.size() && p.entries[cur + 1].first_wg <= (uint32_t)(k * 64))
                 ++cur;
-            coarse[k] = (uint32_t)cur;
+            p.coarse[k] = (uint32_t)cur;
         }
-        const uint8_t* d = static_cast<const uint8_t*>(slot->dev);
-        e = upload_table(slot, bytes, user);
-        if (e == hipSuccess)
-            e = dxtlt::bc7::launch_batch(inverse != 0, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d),
-                                         reinterpret_cast<const uint32_t*>(d + entry_bytes + tail_bytes), (uint32_t)entries.size(),
-                                         (uint32_t)wgs, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d + entry_bytes),
-                                         (uint32_t)tails.size(), user);
-        hipError_t ev = hipEventRecord(slot->done, user);
-        slot->pending = ev == hipSuccess;
-        if (e != hipSuccess)
-            return fail(kDevice, "BC7 batch table copy / launch", e);
-        if (ev != hipSuccess)
-            return fail(kDevice, "batch event", ev);
+        p.entry_bytes = p.entries.size() * sizeof(dxtlt::bc7::BatchEntry);
+        p.tail_bytes = p.tails.size() * sizeof(dxtlt::bc7::BatchEntry);
+        p.bytes = (p.entry_bytes + p.tail_bytes + p.coarse.size() * sizeof(uint32_t) + 15) & ~(size_t)15;
+        p.at = table_bytes;
+        table_bytes += p.bytes;
     }
 
-    // Every group's table (entries, then the workgroup index) goes into ONE staged buffer and ONE upload per call, at 16-byte
-    // aligned offsets.  (One ring slot per group made a call with many settings combinations -- rare in a corpus, routine in the
-    // fuzz: up to 96 groups -- wait in hipEventSynchronize for kernels this same call had enqueued: the "asynchronous" call then
-    // drained its own work, and would deadlock under a caller whose stream is gated on an event recorded after the call returns.)
-    // With the two BC7 tables above a call takes at most three of the ring's slots.
+    // Every table of the call -- the two BC7 tables above, then every group's (entries, then the workgroup index) -- goes into ONE
+    // staged buffer and ONE upload, at 16-byte aligned offsets: one ring slot per call.  (One slot per group made a call with many
+    // settings combinations -- rare in a corpus, routine in the fuzz: up to 96 groups -- wait in hipEventSynchronize for kernels this
+    // same call had enqueued: the "asynchronous" call then drained its own work, and would deadlock under a caller whose stream is
+    // gated on an event recorded after the call returns.  Three slots per call -- BC7 forward, BC7 inverse, the groups -- still let
+    // the NEXT mixed call wait for this one's kernels; see the ring's comment.)
     struct Placed {
         int gi;
         size_t at, entry_bytes;
     };
     std::vector<Placed> placed;
-    size_t table_bytes = 0;
     for (int gi = 0; gi < kGroups; ++gi) {
         const Group& g = groups[gi];
         if (g.entries.empty())
@@ -277,11 +271,19 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         placed.push_back({gi, table_bytes, entry_bytes});
         table_bytes += entry_bytes + dxtlt::batch_index_bytes(g.wgs);
     }
-    if (!placed.empty()) {
+    if (table_bytes != 0) {
         TableSlot* slot = nullptr;
         hipError_t e = g_ring.acquire(table_bytes, &slot);
         if (e != hipSuccess)
             return fail(kDevice, "batch table staging", e);
+        for (const Bc7Plan& p : bc7_plans) {
+            if (p.bytes == 0)
+                continue;
+            uint8_t* h = static_cast<uint8_t*>(slot->host) + p.at;
+            if (p.entry_bytes) std::memcpy(h, p.entries.data(), p.entry_bytes);
+            if (p.tail_bytes) std::memcpy(h + p.entry_bytes, p.tails.data(), p.tail_bytes);
+            if (!p.coarse.empty()) std::memcpy(h + p.entry_bytes + p.tail_bytes, p.coarse.data(), p.coarse.size() * sizeof(uint32_t));
+        }
         std::vector<bool> wide(placed.size());
         for (size_t k = 0; k < placed.size(); ++k) {
             const Group& g = groups[placed[k].gi];
@@ -290,6 +292,19 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
             wide[k] = dxtlt::build_batch_index(g.entries.data(), g.entries.size(), g.wgs, h + placed[k].entry_bytes);
         }
         e = upload_table(slot, table_bytes, user);
+        const char* what = "batch table copy / launch";
+        for (int inverse = 0; inverse < 2 && e == hipSuccess; ++inverse) {
+            const Bc7Plan& p = bc7_plans[inverse];
+            if (p.bytes == 0)
+                continue;
+            const uint8_t* d = static_cast<const uint8_t*>(slot->dev) + p.at;
+            e = dxtlt::bc7::launch_batch(inverse != 0, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d),
+                                         reinterpret_cast<const uint32_t*>(d + p.entry_bytes + p.tail_bytes), (uint32_t)p.entries.size(),
+                                         (uint32_t)p.wgs, reinterpret_cast<const dxtlt::bc7::BatchEntry*>(d + p.entry_bytes),
+                                         (uint32_t)p.tails.size(), user);
+            if (e != hipSuccess)
+                what = "BC7 batch table copy / launch";
+        }
         for (size_t k = 0; k < placed.size() && e == hipSuccess; ++k) {
             const int gi = placed[k].gi;
             Group& g = groups[gi];
@@ -314,7 +329,7 @@ extern "C" int32_t dxtlt_transform_batch_device(const DxtltBatchItem* items, siz
         hipError_t ev = hipEventRecord(slot->done, user);
         slot->pending = ev == hipSuccess;
         if (e != hipSuccess)
-            return fail(kDevice, "batch table copy / launch", e);
+            return fail(kDevice, what, e);
         if (ev != hipSuccess)
             return fail(kDevice, "batch event", ev);
     }

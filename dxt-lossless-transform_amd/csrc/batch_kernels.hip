@@ -123,8 +123,9 @@ extern "C" int dxtlt_debug_read_wg_marks(uint32_t* out, size_t count)
 #define WG_TIMING_END(kind)
 #endif
 
-// THREADS = shift_tile_threads(FMT): the lanes of every tile of the launch (256; bcn_device.h has the 128-lane BC1 measurement)
-template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int THREADS = shift_tile_threads(FMT)>
+// THREADS = batch_tile_threads(FMT, SC, INVERSE): the lanes of every tile of the launch (256; 128 for the forward launch of BC1
+// without the colour split -- bcn_device.h has both measurements)
+template <int FMT, int VARIANT, bool SA, bool SC, bool INVERSE, int THREADS = batch_tile_threads(FMT, SC, INVERSE)>
 __global__ void __launch_bounds__(THREADS)
 batch_kernel(const BatchEntry* __restrict__ entries_arg, const uint8_t* __restrict__ index_arg, uint32_t n_base, uint32_t uniform_wgs,
              uint32_t magic, StridedBatch strided)
@@ -276,7 +277,7 @@ uint32_t plan_batch_entry(Format fmt, bool inverse, const Settings& s, BatchEntr
     const Streams S = make_streams(fmt, sa, s.split_colour);
     const void* soa = inverse ? (const void*)e.src : (const void*)e.dst;
     // any AoS alignment: unaligned 16-byte vector accesses are exact and cheap on gfx950 (launch_transform)
-    const uint64_t T = (uint64_t)tile_blocks(fmt, shift_tile_threads(fmt));
+    const uint64_t T = (uint64_t)tile_blocks(fmt, batch_tile_threads(fmt, s.split_colour, inverse));
     const uint64_t tiles = e.blocks / T, rest = e.blocks % T;
     // The tile forms of launch_transform: aligned tiles when every stream base is on a 128-byte line; otherwise forward halo
     // tiles (windows moved back to a 64-byte boundary) and inverse shifted tiles (slices displaced by the base modulo 16).
@@ -409,7 +410,7 @@ hipError_t launch_batch(Format fmt, bool inverse, const Settings& s, const Batch
     case kBc3: k = batch_variant<kBc3>(s.variant, sa, sc, inverse); break;
     default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(shift_tile_threads(fmt)), 0, stream, d_entries, d_index,
+    hipLaunchKernelGGL(k, dim3(total_wgs), dim3(batch_tile_threads(fmt, sc, inverse)), 0, stream, d_entries, d_index,
                        (uint32_t)batch_index_base_count(total_wgs) | (wide_index ? 0x80000000u : 0u), uniform_wgs, magic, strided);
     return hipGetLastError();
 }

@@ -895,6 +895,17 @@ __host__ __device__ constexpr int halo_tile_threads(int fmt, bool split_colour)
 {
     return fmt == kBc1 && !split_colour ? 128 : shift_tile_threads(fmt);
 }
+// Lanes of every tile of a BATCH launch, planned per (format, colour split, direction) like the single-buffer call's: the forward
+// launch of BC1 without the colour split takes the 128-lane tiles too (aligned, halo and edge tiles alike: the aligned tile shows the
+// 2 KiB + 2 KiB store shape just as the halo tile does).  -DDXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS=256 rebuilds the round-5 shape for
+// the same-box A/B (tools/batch_nosplit_probe.py, profiles/r06_batch_bc1_nosplit.txt).
+#ifndef DXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS
+#define DXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS 128
+#endif
+__host__ __device__ constexpr int batch_tile_threads(int fmt, bool split_colour, bool inverse)
+{
+    return !inverse && fmt == kBc1 && !split_colour ? DXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS : shift_tile_threads(fmt);
+}
 // R = sub-tiles of 256 lanes per workgroup.  Only R = 1 is instantiated: with misaligned stream bases every slice shares
 // its first and last 128-byte line with the neighbouring tiles (BC3, 256 blocks per tile: 12 of 38 lines), and R = 4
 // cuts that to 12 of 134 -- but it measured slower, not faster (BC3 odd count 0.710 / 0.773 forward / inverse against

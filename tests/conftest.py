@@ -10,6 +10,20 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "side_build: needs a GPU AND the -DDXTLT_EXPERIMENTS side build loaded through DXTLT_LIB_PATH; "
+                                       "selected only by name (-m side_build), never by -m gpu or -m 'not gpu'")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`side_build` tests exercise kernels the shipped library does not contain: they run only when asked for by name."""
+    if "side_build" in (config.option.markexpr or ""):
+        return
+    keep, drop = [], []
+    for item in items:
+        (drop if item.get_closest_marker("side_build") else keep).append(item)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope="session")

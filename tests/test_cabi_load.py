@@ -319,6 +319,14 @@ def test_shipped_library_contains_no_experiment_code(pkg):
     from dxt_lossless_transform_amd import _build
     assert _build._dirs([])[1] == _build.LIB_PATH
     assert _build._dirs(["-DDXTLT_EXPERIMENTS"])[1] != _build.LIB_PATH and "side-" in _build._dirs(["-DDXTLT_EXPERIMENTS"])[0]
+    # a variable left set in a shell never redirects the package's own build away from the shipped library: only an
+    # explicit argument makes a side build, and tools/ab_build_rev.sh is the one place that turns the variable into that argument
+    os.environ["DXTLT_EXTRA_HIPCC_FLAGS"] = "-DDXTLT_EXPERIMENTS"
+    try:
+        assert _build._extra_flags() == [] and _build._extra_flags(None) == [] and _build._extra_flags(["-DX"]) == ["-DX"]
+        assert _build.build(force=False) == _build.LIB_PATH
+    finally:
+        del os.environ["DXTLT_EXTRA_HIPCC_FLAGS"]
 
 
 def test_host_route_threshold_default_setter_and_environment(pkg):

@@ -125,24 +125,6 @@ def test_misaligned_device_pointers(pkg, oracle, dev, fmt, shift):
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
-def test_element_kernel_equals_tiled_kernel(pkg, oracle, dev, fmt):
-    if not pkg.tuning_mask() & 1:
-        pytest.skip("the element-granular kernel exists in the experiments side build only (-DDXTLT_EXPERIMENTS)")
-    n = 4 * TILE[fmt]
-    x = oracle.fill_splitmix64(n * BLOCK[fmt], 0xE1E)
-    for s in all_settings(fmt):
-        tiled = run_device(pkg, fmt, x, s, dev)
-        try:
-            pkg.set_tuning(0, 1)
-            generic = run_device(pkg, fmt, x, s, dev)
-            back = run_device(pkg, fmt, generic, s, dev, inverse=True)
-        finally:
-            pkg.set_tuning(0, 0)
-        assert np.array_equal(tiled, generic), (fmt, settings_id(s))
-        assert np.array_equal(back, x)
-
-
-@pytest.mark.parametrize("fmt", FORMATS)
 @pytest.mark.parametrize("threads", [64, 128, 256, 512])
 def test_every_tile_workgroup_size(pkg, oracle, dev, fmt, threads):
     n = 9 * TILE[fmt] + 16 * 3 + 1

@@ -20,7 +20,9 @@ BUILT=$(python3 - <<PY
 import importlib.util, sys
 spec = importlib.util.spec_from_file_location("_build", "$W/dxt-lossless-transform_amd/_build.py")
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-print(m.build(force=True))     # the shipped path, or build/side-<hash>/ when DXTLT_EXTRA_HIPCC_FLAGS is set (a side build)
+import os
+extra = os.environ.get("DXTLT_EXTRA_HIPCC_FLAGS", "").split()   # honoured HERE only (the package's own build() never reads it)
+print(m.build(force=True, extra_flags=extra))     # the shipped path of the copy under /tmp, or build/side-<hash>/ with extra flags
 PY
 )
 BUILT=$(echo "$BUILT" | tail -1)
