@@ -419,6 +419,48 @@ def test_bc7_items_ride_along_in_both_batch_calls(pkg, oracle):
         batch.transform_batch_host([("bc7", False, np.zeros(24, np.uint8), np.zeros(24, np.uint8), None)])
 
 
+@pytest.mark.gpu
+def test_many_mixed_batch_calls_in_flight_share_the_table_ring(pkg, oracle):
+    """Twelve device batch calls back to back on one stream without a synchronisation in between, every one holding BC7 forward, BC7
+    inverse and BC1-3 items (round 5: three table slots per call, so the second such call waited for the first one's kernels; now one
+    slot per call, and the ring of four is reused three times over here) -- and BC1 without the colour split, forward, at odd and even
+    counts (the batch launch with 128-lane tiles).  Every output against the oracle, guard bytes behind it."""
+    from dxt_lossless_transform_amd import batch
+
+    rng = np.random.default_rng(0x51075)
+    dev = torch.device("cuda:0")
+    calls, expect = [], []
+    for c in range(12):
+        items = []
+        for k in range(10):
+            if k < 2:
+                fmt, blocks, inverse, settings = "bc7", [3 * 1024 + 5, 1024, 777, 2048 + 1][(c + k) % 4], bool(k), None
+                x = rng.integers(0, 256, 16 * blocks, dtype=np.uint8)
+                if inverse:
+                    x = oracle.transform_bc7(x)
+                want = oracle.transform_bc7(x, inverse=inverse)
+            else:
+                fmt = FORMATS[k % 3]
+                blocks = int(rng.integers(1, 40_000)) if k % 2 else 512 * int(rng.integers(1, 60))
+                v, sa, sc = (1, 0, 0) if (fmt == "bc1" and k < 8) else (int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+                inverse = (k == 9)
+                x = oracle.fill_splitmix64(blocks * pkg.BLOCK_BYTES[fmt], 0x510 + 16 * c + k)
+                want = oracle.transform(fmt, x, v, bool(sc), bool(sa), inverse=inverse)
+                settings = settings_for(pkg, fmt, v, sa, sc)
+            xd = torch.from_numpy(x.copy()).to(dev)
+            yd = torch.full((x.size + 16,), 0x5A, dtype=torch.uint8, device=dev)
+            items.append((fmt, inverse, xd, yd[: x.size], settings))
+            expect.append((c, k, fmt, want, yd, x.size))
+        calls.append(batch.prepare_batch(items))
+    torch.cuda.synchronize()
+    for prepared in calls:            # nothing between the calls: each finds the previous ones' tables still in use
+        batch.run_prepared_batch(prepared)
+    torch.cuda.synchronize()
+    for c, k, fmt, want, yd, n in expect:
+        h = yd.cpu().numpy()
+        assert np.array_equal(h[:n], want) and (h[n:] == 0x5A).all(), (c, k, fmt, n)
+
+
 _SPAWN_FAILURE_SCRIPT = r'''
 import os, resource, sys, time
 sys.path.insert(0, sys.argv[1])

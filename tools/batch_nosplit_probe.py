@@ -21,6 +21,7 @@ from oracle import oracle_c
 ap = argparse.ArgumentParser()
 ap.add_argument("--settings", default="1,0;0,0;1,1", help="variant,split_colour;...")
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--more", action="store_true", help="more shapes: smaller buffers, the corpus by size class")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 pkg.load()
@@ -73,3 +74,11 @@ for text in args.settings.split(";"):
     run("1024 x 1 MiB (aligned: the array route)", [(1 << 20) // 8] * 1024, st)
     run("540 x 4096^2 with mips (1398101 blocks)", [1398101] * 540, st)
     run("mixed sizes, aligned bases (batch_kernel, form 1)", [(1 << 20) // 8, (2 << 20) // 8] * 512, st)
+    if args.more:
+        run("4096 x 256 KiB - 1 block", [(256 << 10) // 8 - 1] * 4096, st)
+        run("2000 x 1024^2 with mips (87383 blocks)", [87383] * 2000, st)
+        run("4000 x 512^2 with mips (21847 blocks)", [21847] * 4000, st)
+        run("8000 x 256^2 with mips (5463 blocks)", [5463] * 8000, st)
+        for lo, hi in ((0, 6000), (6000, 100000), (100000, 1 << 30)):
+            part = [n for _, _, n in texs if lo <= n < hi]
+            run(f"corpus textures of {lo}..{hi} blocks ({len(part)})", part * max(1, (1 << 27) // max(1, sum(part))), st)
