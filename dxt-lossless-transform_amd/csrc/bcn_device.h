@@ -897,8 +897,10 @@ __host__ __device__ constexpr int halo_tile_threads(int fmt, bool split_colour)
 }
 // Lanes of every tile of a BATCH launch, planned per (format, colour split, direction) like the single-buffer call's: the forward
 // launch of BC1 without the colour split takes the 128-lane tiles too (aligned, halo and edge tiles alike: the aligned tile shows the
-// 2 KiB + 2 KiB store shape just as the halo tile does).  -DDXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS=256 rebuilds the round-5 shape for
-// the same-box A/B (tools/batch_nosplit_probe.py, profiles/r06_batch_bc1_nosplit.txt).
+// 2 KiB + 2 KiB store shape just as the halo tile does).  Same-box A/B against -DDXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS=256, the round-5
+// shape (tools/batch_nosplit_probe.py, profiles/r06_batch_bc1_nosplit.txt): 64 x (16 MiB - 1 block) 0.72 -> 0.79, 1024 x (1 MiB - 1
+// block) 0.69 -> 0.77, mixed aligned sizes 0.76 -> 0.78, the mip-chained corpus level (-0.015 with YCoCg-R, +0.013 without).  The same
+// record holds the negative for the SPLIT setting: 128 lanes lose 0.015-0.045 on every size class of the corpus, so 256 stay there.
 #ifndef DXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS
 #define DXTLT_BATCH_BC1_NOSPLIT_FWD_THREADS 128
 #endif
