@@ -130,6 +130,17 @@ def test_kit_is_complete_and_stays_off_the_gpu_box():
         assert f"transform_{fmt}_with_settings(input.as_ptr(), out.as_mut_ptr(), len, s)" in src
         assert f"Bc{fmt[2]}TransformSettings::all_combinations()" in src
     assert "extern crate" not in src and all(line.split()[1].startswith(("std", "dxt_lossless_transform_bc")) for line in src.splitlines() if line.startswith("use "))
+    # no compiler here: at least every bracket of the source closes (strings, chars and comments skipped)
+    import re
+
+    code = re.sub(r'//[^\n]*|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])\'', "", src)
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for ch in code:
+        if ch in "([{":
+            stack.append(ch)
+        elif ch in pairs:
+            assert stack and stack.pop() == pairs[ch], "unbalanced bracket in the kit's main.rs"
+    assert not stack
     manifest = open(os.path.join(KIT, "Cargo.toml.in")).read()
     deps = manifest.split("[dependencies]")[1].split("[")[0]
     assert [line.split()[0] for line in deps.strip().splitlines()] == [f"dxt-lossless-transform-{fmt}" for fmt in inputs.FORMATS]
