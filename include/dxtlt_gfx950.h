@@ -152,7 +152,9 @@ int32_t dxtlt_transform_range_device(int32_t format, bool inverse, const void *d
  * per (format, direction) present in it -- every workgroup looks up the buffer it belongs to (a small table is copied
  * to the device on `hip_stream` first).  Per-buffer settings, any block counts and alignments.  Asynchronous; ordered
  * like a single call with respect to `hip_stream`; validated as a whole before anything is enqueued.  Items must not
- * overlap one another.
+ * overlap one another.  A call stages its tables in ONE of four per-thread slots and returns without waiting for the
+ * device; only the fifth call of a thread whose four predecessors are all still in flight waits (on the host) for the oldest
+ * of them -- so do not enqueue more than four batch calls of one thread behind an event that is recorded later.
  * Regular batches are recognised and served by shorter paths, with identical results: when all items of one format and
  * direction have ONE size the owning item is found by a division instead of a table walk; when they also share their
  * settings and their inputs and outputs each lie a constant stride apart (an array texture) no table is read at all; and
