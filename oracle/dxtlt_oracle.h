@@ -20,7 +20,10 @@
  * vector exists and the reference cannot be run here); everything the reference does pin is checked.
  * Forward-byte parity therefore rests on the code-defined layout plus an
  * independently written numpy restatement (oracle/oracle_np.py) agreeing with
- * this file on every case; see DESIGN.md "Oracle".
+ * this file on every case; see DESIGN.md "Oracle".  The road to a real pin is one
+ * command on a machine with cargo: tests/golden/reference_kit/run.sh writes the
+ * reference's own output bytes, and tests/test_reference_vectors.py then holds
+ * this oracle (and the HIP path) to them.
  *
  * All reference paths below are relative to /root/reference/src/core/.
  */
