@@ -1,7 +1,7 @@
 // UNCOMPILED (see ../README.md).
-// The shared library is built outside cargo by hipcc (dxt-lossless-transform_amd/_build.py: one object per source with
-// `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c`, then `hipcc -shared`).  Point DXTLT_GFX950_LIB_DIR at the
-// directory that holds libdxtlt_gfx950.so.
+// The shared library is built outside cargo by hipcc: `make -C dxt-lossless-transform_amd/csrc` (no Python needed; the package's
+// own _build.py does the same: one object per source with `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c`, then
+// `hipcc -shared`).  Point DXTLT_GFX950_LIB_DIR at the directory that holds libdxtlt_gfx950.so.
 fn main() {
     println!("cargo:rerun-if-env-changed=DXTLT_GFX950_LIB_DIR");
     if let Ok(dir) = std::env::var("DXTLT_GFX950_LIB_DIR") {

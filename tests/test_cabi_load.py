@@ -418,3 +418,21 @@ def test_rust_bodies_default_to_the_device_and_glue_is_no_std():
     assert 'feature = "cpu"' not in code, "only the two opt-in features gate code; `cpu` is internal (the kept bodies)"
     sys_src = open(os.path.join(os.path.dirname(root), "dxt-lossless-transform-gfx950-sys", "src", "lib.rs")).read()
     assert "#![no_std]" in sys_src
+
+
+def test_plain_makefile_builds_what_the_python_build_builds():
+    """csrc/Makefile (for maintainers who build from build.rs or a shell, without Python) names the same sources and compiler flags as
+    _build.py; `make -n` resolves every rule."""
+    import subprocess
+
+    from dxt_lossless_transform_amd import _build
+
+    mk = open(os.path.join(_build.CSRC, "Makefile")).read().replace("\\\n", " ")
+    sources = re.search(r"^SOURCES\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    flags = re.search(r"^FLAGS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert sources == _build.SOURCES
+    assert flags == _build.BASE_FLAGS
+    r = subprocess.run(["make", "-n", "-B", "-C", _build.CSRC, "LIB=/tmp/never_written.so", "OBJ_DIR=/tmp/never_written_obj"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count(" -x hip -c ") == len(_build.SOURCES) and "-shared -fPIC" in r.stdout
