@@ -436,3 +436,24 @@ def test_plain_makefile_builds_what_the_python_build_builds():
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     assert r.stdout.count(" -x hip -c ") == len(_build.SOURCES) and "-shared -fPIC" in r.stdout
+
+
+def test_every_rust_source_has_balanced_brackets():
+    """No Rust toolchain in this image: the least a source-only file can be held to is that every bracket closes (strings, chars,
+    lifetimes and comments skipped).  rust/ (the shim) and tests/golden/reference_kit/ (the pin-on-arrival kit)."""
+    import glob
+
+    paths = glob.glob(os.path.join(ROOT, "rust", "**", "*.rs"), recursive=True) + \
+        glob.glob(os.path.join(ROOT, "tests", "golden", "reference_kit", "**", "*.rs"), recursive=True)
+    assert len(paths) >= 10
+    for path in paths:
+        src = open(path).read()
+        code = re.sub(r'/\*.*?\*/', "", src, flags=re.S)
+        code = re.sub(r'//[^\n]*|b?"(?:\\.|[^"\\])*"|b?\'(?:\\.|[^\'\\])\'', "", code)
+        stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+        for n, ch in enumerate(code):
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in pairs:
+                assert stack and stack.pop() == pairs[ch], (os.path.relpath(path, ROOT), code[max(0, n - 60):n + 1])
+        assert not stack, os.path.relpath(path, ROOT)
