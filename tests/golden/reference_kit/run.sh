@@ -18,15 +18,19 @@ trap 'rm -rf "$WORK"' EXIT
 mkdir -p "$WORK/kit/src" "$WORK/in"
 sed "s|@REF@|$REF|g" "$HERE/Cargo.toml.in" > "$WORK/kit/Cargo.toml"
 cp "$HERE/src/main.rs" "$WORK/kit/src/main.rs"
+mkdir -p "$WORK/kit/src/bin" && cp "$HERE/src/bin/auto.rs" "$WORK/kit/src/bin/auto.rs"
 cp "$REF/src/Cargo.lock" "$WORK/kit/Cargo.lock" 2>/dev/null || true     # the reference's pinned dependency versions, where they apply
 python3 "$GOLDEN/make_reference_inputs.py" "$WORK/in"
-( cd "$WORK/kit" && cargo run --release -- "$WORK/in" "$WORK/out" ) || {
+( cd "$WORK/kit" && cargo run --release --bin dxtlt-reference-kit -- "$WORK/in" "$WORK/out" ) || {
   echo "retrying without the reference's Cargo.lock" >&2
   rm -f "$WORK/kit/Cargo.lock" && rm -rf "$WORK/out"
-  ( cd "$WORK/kit" && cargo run --release -- "$WORK/in" "$WORK/out" )
+  ( cd "$WORK/kit" && cargo run --release --bin dxtlt-reference-kit -- "$WORK/in" "$WORK/out" )
 }
+# second program: the choices of transform_bcN_auto.  Optional -- if it does not build, the transform outputs above stand alone.
+( cd "$WORK/kit" && cargo run --release --bin auto -- "$WORK/in" "$WORK/out" ) || echo "auto kit failed: AUTO_MANIFEST.txt not written (the transform outputs are unaffected)" >&2
 rm -rf "$GOLDEN/reference_out" && mkdir -p "$GOLDEN/reference_out"
 cp "$WORK/out/MANIFEST.txt" "$GOLDEN/reference_out/"
+cp "$WORK/out/AUTO_MANIFEST.txt" "$GOLDEN/reference_out/" 2>/dev/null || true
 ( git -C "$REF" rev-parse HEAD 2>/dev/null || echo unknown ) > "$GOLDEN/reference_out/REFERENCE_REV.txt"
 if [ "${KEEP_ALL:-0}" = 1 ]; then        # every output as a whole file (about 50 MB; not for committing)
   cp "$WORK"/out/*.out "$GOLDEN/reference_out/"

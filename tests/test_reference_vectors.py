@@ -13,7 +13,9 @@ below are dormant: ONE skip whose message is the command.  No output file is eve
 With the directory present:
   * CPU (-m "not gpu"): the C oracle AND the numpy oracle reproduce every manifest line (length + CRC-32), every whole file byte
     for byte, and the manifest is complete (every case x every settings combination);
-  * GPU (-m gpu): the HIP path through the C ABI does the same.
+  * GPU (-m gpu): the HIP path through the C ABI does the same;
+  * and when the kit's second program ran too (AUTO_MANIFEST.txt: what transform_bcN_auto chose, with a CRC estimator, for every
+    input and both candidate lists), oracle_auto on the CPU and dltbcNcore_transform_auto on the GPU make the same choices and bytes.
 The comparer itself is exercised either way against a throw-away directory under tmp_path."""
 import os
 import sys
@@ -74,6 +76,47 @@ def compare(directory, produce, what):
     return len(rows), whole
 
 
+def read_auto_manifest(directory):
+    """AUTO_MANIFEST.txt: `<case>.<fmt>.all<0|1> <settings id> <length> <crc32>` -> (case, fmt, use_all, (variant, split_alpha, split_colour), length, crc)"""
+    rows = []
+    with open(os.path.join(directory, "AUTO_MANIFEST.txt")) as f:
+        for line in f:
+            if line.strip():
+                name, sid, length, crc = line.split()
+                case, fmt, mode = name.rsplit(".", 2)
+                ids = {s: key for key, s in inputs.settings_ids(fmt)}
+                assert mode in ("all0", "all1") and sid in ids, line
+                rows.append((case, fmt, mode == "all1", ids[sid], int(length), int(crc, 16)))
+    return rows
+
+
+def crc_estimate(section) -> int:
+    """The kit's estimator (src/bin/auto.rs): CRC-32 of the section & 0xFFFFF -- every byte shown to the estimator matters"""
+    return zlib.crc32(bytes(section)) & 0xFFFFF
+
+
+def compare_auto(directory, produce, what):
+    """Every AUTO_MANIFEST line against produce(fmt, input, use_all) -> ((variant, split_alpha, split_colour), output array)."""
+    rows = read_auto_manifest(directory)
+    want_names = {(case, fmt, use_all) for fmt in inputs.FORMATS for case in inputs.case_names(fmt) for use_all in (False, True)}
+    assert {r[:3] for r in rows} == want_names, "the auto manifest does not cover every case x use_all_decorrelation_modes"
+    for case, fmt, use_all, choice, length, crc in rows:
+        got_choice, out = produce(fmt, inputs.case(case, fmt), use_all)
+        assert tuple(int(v) for v in got_choice) == choice, (what, case, fmt, use_all, "choice", got_choice, choice)
+        out = np.ascontiguousarray(out)
+        assert out.size == length and zlib.crc32(out.tobytes()) == crc, (what, case, fmt, use_all, "output")
+    return len(rows)
+
+
+def oracle_auto_produce():
+    from oracle import oracle_auto
+
+    def produce(fmt, x, use_all):
+        choice, out, _calls = oracle_auto.transform_auto(fmt, x, crc_estimate, use_all)
+        return choice, out
+    return produce
+
+
 def oracle_c_produce(oracle):
     return lambda fmt, x, s: oracle.transform(fmt, x, s[0], bool(s[2]), bool(s[1]))
 
@@ -84,6 +127,7 @@ def oracle_np_produce():
     return lambda fmt, x, s: oracle_np.transform(fmt, x, s[0], bool(s[2]), bool(s[1]))
 
 
+HAS_AUTO_MANIFEST = os.path.exists(os.path.join(REF_OUT, "AUTO_MANIFEST.txt"))
 needs_reference_out = pytest.mark.skipif(not os.path.exists(os.path.join(REF_OUT, "MANIFEST.txt")), reason=HOW)
 
 
@@ -95,6 +139,8 @@ def test_oracles_equal_the_reference_bytes(oracle):
     n, whole = compare(REF_OUT, oracle_c_produce(oracle), "C oracle")
     assert whole >= 1, "commit at least the small whole-file outputs (make_reference_inputs.py --commit-list)"
     compare(REF_OUT, oracle_np_produce(), "numpy oracle")
+    if HAS_AUTO_MANIFEST:      # the kit's second program (src/bin/auto.rs): the reference's transform_bcN_auto choices and bytes
+        assert compare_auto(REF_OUT, oracle_auto_produce(), "oracle_auto") > 0
 
 
 @pytest.mark.gpu
@@ -117,13 +163,33 @@ def test_hip_path_equals_the_reference_bytes(pkg):
         return yd.cpu().numpy()
 
     compare(REF_OUT, produce, "HIP")
+    if HAS_AUTO_MANIFEST:
+        # dltbcNcore_transform_auto (host pointers, the estimator as a C callback) against the reference's own choices and output bytes
+        import ctypes as C
+
+        import cabi
+
+        lib = cabi.bind(C.CDLL(pkg._lib.lib_path()))
+        core_settings = {"bc1": cabi.CoreSettings2, "bc2": cabi.CoreSettings2, "bc3": cabi.CoreSettings3}
+
+        def produce_auto(fmt, x, use_all):
+            est, _ = cabi.make_estimator("crc")
+            x = np.ascontiguousarray(x)
+            y = np.zeros_like(x)
+            out = core_settings[fmt]()
+            r = getattr(lib, f"dltbc{fmt[2]}core_transform_auto")(x.ctypes.data, x.size, y.ctypes.data, y.size, C.byref(est),
+                                                                 cabi.AutoSettings(use_all), C.byref(out))
+            assert r.ErrorCode == 0, (fmt, use_all, r.ErrorCode)
+            return (out.DecorrelationMode, int(out.SplitAlphaEndpoints) if fmt == "bc3" else 0, int(out.SplitColourEndpoints)), y
+
+        assert compare_auto(REF_OUT, produce_auto, "C API auto") > 0
 
 
 # ------------------------------------------------------------------------------------------------------------
 # always on: the kit is whole, its inputs are what they claim to be, and the comparer catches a wrong byte
 # ------------------------------------------------------------------------------------------------------------
 def test_kit_is_complete_and_stays_off_the_gpu_box():
-    for f in ("run.sh", "Cargo.toml.in", "src/main.rs"):
+    for f in ("run.sh", "Cargo.toml.in", "src/main.rs", "src/bin/auto.rs"):
         assert os.path.exists(os.path.join(KIT, f)), f
     src = open(os.path.join(KIT, "src", "main.rs")).read()
     for fmt in inputs.FORMATS:       # exactly the hot path's entry points, every settings combination, std only
@@ -143,7 +209,13 @@ def test_kit_is_complete_and_stays_off_the_gpu_box():
     assert not stack
     manifest = open(os.path.join(KIT, "Cargo.toml.in")).read()
     deps = manifest.split("[dependencies]")[1].split("[")[0]
-    assert [line.split()[0] for line in deps.strip().splitlines()] == [f"dxt-lossless-transform-{fmt}" for fmt in inputs.FORMATS]
+    assert [line.split()[0] for line in deps.strip().splitlines() if not line.startswith("#")] == \
+        [f"dxt-lossless-transform-{fmt}" for fmt in inputs.FORMATS] + ["dxt-lossless-transform-api-common"]
+    auto = open(os.path.join(KIT, "src", "bin", "auto.rs")).read()
+    for fmt in inputs.FORMATS:
+        assert f"transform_{fmt}_auto(input.as_ptr(), out.as_mut_ptr(), len, &options)" in auto
+    assert "Ok((crc32(section) & 0x000F_FFFF) as usize)" in auto and "for use_all in [false, true]" in auto
+    assert all(line.split()[1].startswith(("std", "dxt_lossless_transform_")) for line in auto.splitlines() if line.startswith("use "))
     root = os.path.dirname(os.path.dirname(GOLDEN))
     assert "tests/golden/reference_kit/" in open(os.path.join(root, ".gpurunignore")).read().split()
     if not os.path.exists(REF_OUT):  # this repository never writes reference outputs itself
@@ -216,3 +288,35 @@ def test_comparer_on_a_throw_away_directory(tmp_path, oracle):
     open(manifest, "w").write("\n".join(lines[1:]) + "\n")
     with pytest.raises(AssertionError, match="does not cover"):
         compare(d, produce, "C oracle")
+
+
+def test_auto_comparer_on_a_throw_away_directory(tmp_path):
+    """compare_auto's own check, like the one above: an AUTO_MANIFEST written from oracle_auto under tmp_path passes; a changed choice,
+    a changed output CRC and a missing line each fail.  Also: the estimator makes real choices (more than one setting wins somewhere)."""
+    d = str(tmp_path)
+    produce = oracle_auto_produce()
+    sid = {fmt: {key: s for key, s in inputs.settings_ids(fmt)} for fmt in inputs.FORMATS}
+    lines, winners = [], set()
+    for fmt in inputs.FORMATS:
+        for case in inputs.case_names(fmt):
+            for use_all in (False, True):
+                choice, out = produce(fmt, inputs.case(case, fmt), use_all)
+                winners.add((fmt, choice))
+                lines.append(f"{case}.{fmt}.all{int(use_all)} {sid[fmt][tuple(choice)]} {out.size} {zlib.crc32(out.tobytes()):08x}")
+    assert len(winners) >= 20          # 8 + 8 + 16 settings exist; the CRC estimator spreads its choices over them
+    path = os.path.join(d, "AUTO_MANIFEST.txt")
+    open(path, "w").write("\n".join(lines) + "\n")
+    assert compare_auto(d, produce, "oracle_auto") == len(lines) == 2 * 397
+
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("r2-256.bc3.all1 "))
+    name, s, length, crc = lines[k].split()
+    other = "v0a0c0" if s != "v0a0c0" else "v1a1c1"
+    open(path, "w").write("\n".join(lines[:k] + [f"{name} {other} {length} {crc}"] + lines[k + 1:]) + "\n")
+    with pytest.raises(AssertionError, match="choice"):
+        compare_auto(d, produce, "oracle_auto")
+    open(path, "w").write("\n".join(lines[:k] + [f"{name} {s} {length} {(int(crc, 16) ^ 1):08x}"] + lines[k + 1:]) + "\n")
+    with pytest.raises(AssertionError, match="output"):
+        compare_auto(d, produce, "oracle_auto")
+    open(path, "w").write("\n".join(lines[:-1]) + "\n")
+    with pytest.raises(AssertionError, match="does not cover"):
+        compare_auto(d, produce, "oracle_auto")
