@@ -38,7 +38,8 @@ using dxtlt::BatchEntry;
 // kSlots earlier calls of this thread are all still in flight.  (Until round 6 a call with BC7 forward, BC7 inverse and BC1-3
 // items took three slots: the next such call's second acquire landed on a slot the previous call had left pending and waited in
 // hipEventSynchronize for that call's kernels -- an "asynchronous" call that host-blocked with a single earlier call in flight,
-// which dxtlt_transform_batch_host hit on every chunk.)
+// which dxtlt_transform_batch_host hit on every chunk.  Sixteen mixed calls back to back: enqueued in 0.66 ms instead of 1.0 ms, finished
+// 20 % sooner: profiles/r06_batch_one_slot.txt.)
 constexpr int kSlots = 4;
 
 struct TableSlot {
