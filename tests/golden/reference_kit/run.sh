@@ -5,6 +5,9 @@
 #
 #     tests/golden/reference_kit/run.sh /path/to/dxt-lossless-transform          # the directory that holds src/Cargo.toml
 #
+# Needs: cargo (a toolchain recent enough for the reference itself), python3 with numpy (the inputs), network access for cargo to fetch
+# the reference's crates.io dependencies.  No GPU, no ROCm.
+#
 # Nothing of the reference is copied into this repository: the kit is built in a scratch directory and links the reference's
 # crates where they lie; only its OUTPUT (data) lands under tests/golden/reference_out/.  Commit MANIFEST.txt, REFERENCE_REV.txt and
 # the 288 small .out files `make_reference_inputs.py --commit-list` names; every output is pinned by its length + CRC-32 line.
